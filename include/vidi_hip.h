@@ -1,0 +1,154 @@
+/* vidi_hip.h — C ABI of libvidi_hip.so: the MI355X (gfx950) kernels behind the Vidi inference hot path.
+ *
+ * The reference (bytedance/vidi) is pure Python; it has no FFI of its own.  The seam this ABI sits
+ * under is the set of third-party kernel CALL SITES of the inference forward:
+ * every entry point below names the reference call site(s) whose arithmetic it replaces.  Paths
+ * are relative to Vidi1.5_9B/vidi/ ; "TP/" = transformers (pinned 4.50.0 by the reference).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, floats, a hipStream_t passed as void*.  No torch types.
+ *   - every call only ENQUEUES on `stream` (no allocation, no sync, graph-capture safe).
+ *   - return 0 on success; negative = VIDI_ERR_* (bad shape/dtype/alignment/argument);
+ *     positive = hipError_t from the launch.  Nothing throws across the ABI.
+ *   - dtype: VIDI_DT_BF16 / VIDI_DT_F16 select the storage + MFMA input type (fp32 accumulate).
+ *   - "T(x)" below means "rounded to the storage dtype": kernels round where eager PyTorch rounds.
+ */
+#ifndef VIDI_HIP_H
+#define VIDI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIDI_ABI_VERSION 1
+#define VIDI_DT_BF16 0
+#define VIDI_DT_F16 1
+#define VIDI_OK 0
+#define VIDI_ERR_SHAPE (-1)
+#define VIDI_ERR_DTYPE (-2)
+#define VIDI_ERR_ALIGN (-3)
+#define VIDI_ERR_ARG (-4)
+
+#define VIDI_ACT_NONE 0
+#define VIDI_ACT_GELU_TANH 1
+#define VIDI_ACT_GELU_ERF 2
+
+#define VIDI_NORM_GEMMA 0      /* TP/models/gemma2/modeling_gemma2.py:55-63                        */
+#define VIDI_NORM_GEMMA_ADD 1  /* residual + Gemma2RMSNorm(x): lmm/dattn/gemma.py:121,201,237       */
+#define VIDI_NORM_MM 2         /* model/mm_layer/norm.py:19-25 (weight * rms_norm(x))               */
+#define VIDI_NORM_MM_NOW 3     /* model/mm_layer/norm.py:9-16 (weight-free rms_norm)                */
+#define VIDI_NORM_LLM 4        /* multimodal.py:201-206 (+ gemma.py:353-356 normalizer), emits mask */
+#define VIDI_NORM_LAYER 5      /* nn.LayerNorm of the SigLIP / Whisper towers                       */
+
+int vidi_abi_version(void);
+const char* vidi_build_info(void);
+
+/* ---- dense projections: nn.Linear / Conv-as-GEMM call sites (cuBLAS in the reference) ------------
+ * Y[m][n] = epi( sum_k X[m][k] W[n][k] + bias[n] ),  X:[M,K] (ldx), W:[N,K] (ldw), Y:[M,N] (ldy).
+ * epi: T(.) -> act -> optional residual add  Y = T(T(.) + R[m % rmod][n]).
+ * batch>1 strides X/Y/R by bsX/bsY/bsR elements (W shared).  K % 64 == 0, N % 32 == 0.
+ * repkv_hd/repkv_g != 0: X column for logical k is (k/(g*hd))*hd + k%hd, i.e. the GEMM consumes
+ *   repeat_kv(V) without materialising it (gemma.py:77-78,96,196-197).
+ * tile_cfg: -1 auto, 0 = 128x128, 1 = 128x256, 2 = 256x256, 3 = conservative register-staged.
+ * Replaces: SigLIP q/k/v/out/fc1/fc2 + patch-embed conv (TP/models/siglip/modeling_siglip.py:124-130,
+ * 250-357), Whisper convs/linears (TP/models/whisper/modeling_whisper.py:566-567,279-282,375-376),
+ * projector MLP (model/mm_layer/mlp.py:9-28), Conv1d audio pool (multimodal.py:85-88,232),
+ * o_proj on V (gemma.py:196-197), down_proj, text q/k/v/o (TP gemma2:224-236). */
+int vidi_gemm(const void* X, const void* W, const void* bias, void* Y, const void* R,
+              int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int rmod,
+              long long bsX, long long bsY, long long bsR, int batch,
+              int act, int repkv_hd, int repkv_g, int tile_cfg, int dtype, void* stream);
+
+/* Gemma2MLP gate/up + GeGLU fused (TP gemma2:79-82 via gemma.py:116-123):
+ * Wgu:[2*I,K] holds gate/up rows interleaved in blocks of 32 (rows 64j..64j+31 = gate[32j..],
+ * rows 64j+32..64j+63 = up[32j..]);  Y[m][i] = T( T(gelu_tanh(T(g))) * T(u) ),  Y:[M,I]. */
+int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
+                    int tile_cfg, int dtype, void* stream);
+
+/* Encoder QKV projection: columns < vstart (Q|K) go row-major to Yqk (ldy); columns >= vstart (V)
+ * go to Vt[b][head][d][seqpad] (b = m / seq, key order perm16 inside each 16-slab) for vidi_attn_self.
+ * Replaces SiglipAttention / WhisperAttention q/k/v_proj (TP siglip:277-279, whisper:309-333). */
+int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, void* Vt,
+                     int M, int N, int K, int ldx, int ldw, int ldy,
+                     int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream);
+
+/* LLM K/V projection of the multimodal stream straight into the cross-attention caches
+ * (gemma.py:59-65: k_proj, v_proj, DynamicCache.update).  W:[2*kvd,K] = [Wk;Wv].
+ * Kc[kvh][tile][64][hd], Vtc[kvh][tile][hd][64 (perm16)], Vrow:[M,kvd] row-major copy of V for the
+ * diagonal-stream o_proj.  Token index = tok0 + m. */
+int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* Vrow,
+                       int M, int kvd, int K, int ldx, int ldw, int hd, int ntile64, int tok0,
+                       int tile_cfg, int dtype, void* stream);
+
+/* Skinny projection (M <= 8), HBM-bound weight streaming for decode: text q/k/v/o/gate/up/down and
+ * lm_head (gemma.py:565) at Lq = 1. */
+int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
+              int dtype, void* stream);
+
+/* fp32 projection on exact-fp32 MFMA: LearnablePosEmbd's fp32 MLP (mm_vision/pos.py:36-39,55;
+ * model/mm_layer/mlp.py:31-40). act: VIDI_ACT_NONE / VIDI_ACT_GELU_ERF. */
+int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
+                  int ldx, int ldw, int ldy, int act, void* stream);
+
+/* ---- attention --------------------------------------------------------------------------------
+ * Encoder self-attention, non-causal (flash-attn call inside HF Siglip/Whisper attention,
+ * multimodal.py:44-57).  QK:[B*N, ldqk] (Q at col h*D, K at col koff+h*D), Vt from vidi_gemm_qkv_vt,
+ * O:[B*N, ldo]. D in {72, 64, 32, 16}. */
+int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Npad, int H, int D,
+                   int ldqk, int koff, int ldo, float scale, int dtype, void* stream);
+
+/* Text->video / text->audio cross-attention, split-KV partial pass (flash_attn_func /
+ * flash_attn_varlen_func: lmm/dattn/xattn.py:123,253 via gemma.py:81-91).  Rows r = token*G + g
+ * for each kv head; keys [key_start, key_start+n_keys) of the tiled caches; mask: optional
+ * uint8[n_keys] key-padding mask (image/audio_attention_mask).  Writes W = 4*zsplit partials:
+ * Opart:[W][nkv][Rpad][HD] fp32, ML:[W][nkv][Rpad][2] fp32 (base-2 running max, sum). */
+size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD);
+int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
+                    int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
+                    float scale, float softcap, int zsplit, int dtype, void* stream);
+/* Merge partials -> Out:[tokens, ldo] (head (kvh*G+g) at column (kvh*G+g)*HD); optional OutF32 /
+ * OutML ([tokens][heads][2]) expose the un-rounded result + (m,l) for the cross-GPU LSE merge.
+ * zero_out=1 reproduces gemma.py:180-192 for a sample with no valid key. */
+int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF32, float* OutML,
+                    int W, int nkv, int R, int Rpad, int G, int HD, int ldo, int zero_out, int dtype, void* stream);
+
+/* Text causal self-attention with softcap / sliding window / key mask (gemma.py:165-175 ->
+ * TP gemma2:248-288 under FA2) over the text KV cache [B,Lmax,nkv*HD]. */
+int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
+                   int B, int Lq, int Lmax, int nq, int nkv, int HD, int past_len, int window,
+                   float scale, float softcap, int dtype, void* stream);
+/* apply_rotary_pos_emb in place (TP gemma2:146-168); cos/sin:[rows,HD] in the storage dtype. */
+int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
+              int dtype, void* stream);
+
+/* ---- row-wise normalisations (see VIDI_NORM_*) ------------------------------------------------ */
+int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
+              void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
+              float eps, float normalizer, int sample_flag, int dtype, void* stream);
+
+/* ---- data movement / elementwise -------------------------------------------------------------- */
+/* SiglipVisionEmbeddings conv as GEMM input (TP siglip:124-130,178): px:[T,3,S,S] -> A:[T*(S/P)^2,Kpad] */
+int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, int dtype, void* stream);
+/* Conv2DPool.forward + space_to_depth (mm_vision/pool.py:23-32, utils.py:134-150):
+ * f:[T,side*side,C] -> out:[T,h/m,w/m,C*m*m]; resize=0 means hw == padded grid (the "28" sentinel). */
+int vidi_pool_s2d(const void* f, void* out, int T, int side, int C, int h, int w, int m, int resize, int dtype, void* stream);
+/* f[t,y,x,:] = T(T(T(f+ph[y])+pw[x])+pt[t]) in place (multimodal.py:194-197,242); null tables skipped */
+int vidi_add_pos(void* f, const void* ph, const void* pw, const void* pt, int T, int oh, int ow, int H, int dtype, void* stream);
+/* y = T(T(a+b)+c), b/c optional (gemma.py:236) ; n elements, n % 8 == 0 */
+int vidi_add3(const void* a, const void* b, const void* c, void* y, long long n, int dtype, void* stream);
+/* embed_tokens gather * normalizer (multimodal.py:385, gemma.py:353-354); id < 0 -> zero row */
+int vidi_embed(const long long* ids, const void* E, void* out, int n, int H, long long vocab, float normalizer, int dtype, void* stream);
+/* GeGLU on the interleaved gate/up layout for the vidi_gemv path */
+int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* stream);
+/* final-logit softcap in place + greedy argmax (gemma.py:565-569, do_sample=False) */
+int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream);
+/* mel:[C,nmel,L] -> [C,L+2,nmel] zero-padded rows for the conv1-as-GEMM view (TP whisper:566,618) */
+int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, int dtype, void* stream);
+/* FractionalSinusoidalEmbedding rows i0..i0+rows of l (mm_vision/pos.py:11-26,47-53), fp32 */
+int vidi_sinusoid(float* pe, const float* div_term, int rows, int i0, int l, int N, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,67 @@
+"""Build libvidi_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is a plain
+C-ABI shared object (include/vidi_hip.h); Python binds it with ctypes (vidi_amd/hip.py)."""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libvidi_hip.so")
+SOURCES = ["gemm.hip", "attn_self.hip", "attn_cross.hip", "attn_text.hip", "rowops.hip", "elementwise.hip", "capi.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "vidi_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, force: bool) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    stamp = obj + ".sha"
+    dig = _digest([os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS])
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    if verbose:
+        print(f"[vidi_amd.build] {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,310 @@
+// Text -> multimodal cross-attention (T2V / T2A of Decomposed Attention): skinny Q (Lq ~ 40 at
+// prefill, 1 at decode) against ~10^5 cached video/audio keys.  Replaces the reference's
+// flash_attn_func / flash_attn_varlen_func call sites (Vidi1.5_9B/vidi/model/lmm/dattn/xattn.py:123,253
+// via gemma.py:81-91) — non-causal, logits softcap, key-padding mask, GQA.
+//
+// HBM-bound: every K/V byte is read once per (layer, modality): algorithmic bytes =
+// n_keys * 2 * n_kv_heads * head_dim * 2 B.  Design:
+//   * GQA-native: the G query heads sharing a KV head are stacked as rows (row = (token, g)), so
+//     K/V are never repeat_kv'ed (the reference doubles the bytes, gemma.py:77-78).
+//   * K cache is tile-contiguous  Kc[kvh][tile64][64 keys][HD];  V cache is stored transposed and
+//     tile-contiguous  Vtc[kvh][tile64][HD][64 positions]  with the perm16 key order, both written
+//     by the KV-projection GEMM epilogue.  A wave's 32-key sub-tile is 16 KB + 16 KB of perfectly
+//     linear 16-byte global_load_lds DMA.
+//   * split-KV at WAVE granularity: every wave owns a contiguous key range and its private 32 KB
+//     LDS ring, runs its own online softmax (no block barriers in the loop) and emits one partial
+//     (O, m, l); `attn_merge_kernel` combines partials (exact: the tanh softcap is per logit).
+//   * swapped MFMAs (S^T = K Q^T, O^T = Vt P^T): per-lane softmax statistics, P stays in registers.
+#include "kernels.h"
+
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
+    constexpr int QROW = HD * 2;                 // bytes per row
+    constexpr int CPR = HD / 8;                  // 16-byte chunks per K/Q row (32 for HD=256)
+    constexpr int KST = HD / 16;                 // k16 steps of QK^T
+    constexpr int DT = HD / 32;                  // output d tiles
+    constexpr int KBYTES = 32 * QROW;            // K sub-tile (32 keys)
+    constexpr int VBYTES = HD * 64;              // Vt sub-tile (HD rows x 32 positions x 2 B)
+    constexpr int KLD = KBYTES / 1024;           // DMA instructions per K sub-tile
+    constexpr int VLD = VBYTES / 1024;
+    static_assert(CPR >= 16 && (CPR & (CPR - 1)) == 0, "HD must be 128 or 256");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;                             // [32 rows][QROW], chunk-swizzled
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    char* sK = smem + 32 * QROW + wave * (KBYTES + VBYTES);
+    char* sV = sK + KBYTES;
+
+    const int kvh = blockIdx.x, rt = blockIdx.y;
+    const int r0 = rt * 32;
+
+    // ---- stage the 32-row Q tile (rows beyond R are zero) -------------------------------------
+    for (int i = tid; i < 32 * CPR; i += 256) {
+        const int row = i / CPR, c = i % CPR, r = r0 + row;
+        u32x4 v = {0, 0, 0, 0};
+        if (r < p.R) {
+            const int tq = r / p.G, g = r % p.G;
+            v = *(const u32x4*)(p.Q + (size_t)tq * p.ldq + (kvh * p.G + g) * HD + c * 8);
+        }
+        *(u32x4*)(sQ + row * QROW + ((c ^ (row & 15)) << 4)) = v;
+    }
+    __syncthreads();
+
+    // Q fragments stay in registers for the whole key sweep (B operand: column = row l31)
+    u32x4 qf[KST];
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks)
+        qf[ks] = *(const u32x4*)(sQ + l31 * QROW + (((2 * ks + hi) ^ (l31 & 15)) << 4));
+
+    // ---- this wave's key range (32-key sub-tiles) ----------------------------------------------
+    const int nsub = (p.n_keys + 31) / 32;
+    const int wtot = gridDim.z * 4;
+    const int wg = blockIdx.z * 4 + wave;
+    const int per = (nsub + wtot - 1) / wtot;
+    const int st_begin = min(wg * per, nsub), st_end = min(st_begin + per, nsub);
+
+    const u16* kc_head = p.Kc + (size_t)kvh * p.ntile64 * 64 * HD;
+    const u16* vt_head = p.Vtc + (size_t)kvh * p.ntile64 * HD * 64;
+
+    auto issue_k = [&](int st) {
+        const int kb = p.key_start + st * 32;
+        const u16* src = kc_head + (size_t)kb * HD;                 // 32 consecutive keys are contiguous
+#pragma unroll
+        for (int j = 0; j < KLD; ++j) {
+            const int pidx = j * 64 + lane, row = pidx / CPR, cl = pidx % CPR;
+            const int cg = cl ^ (row & 15);
+            glds16(src + row * HD + cg * 8, sK + j * 1024);
+        }
+    };
+    auto issue_v = [&](int st) {
+        const int kb = p.key_start + st * 32;
+        const u16* src = vt_head + (size_t)(kb >> 6) * HD * 64 + ((kb >> 5) & 1) * 32;
+#pragma unroll
+        for (int j = 0; j < VLD; ++j) {
+            const int pidx = j * 64 + lane, d = pidx >> 2, cl = pidx & 3;
+            const int cg = cl ^ ((d >> 2) & 3);
+            glds16(src + d * 64 + cg * 8, sV + j * 1024);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float L2E = 1.4426950408889634f;
+    const bool use_cap = p.softcap > 0.f;
+    const float pre = use_cap ? p.scale / p.softcap : p.scale * L2E;   // x/cap, or base-2 logits
+    const float capl2 = p.softcap * L2E;
+
+    if (st_begin < st_end) {
+        issue_k(st_begin);
+        issue_v(st_begin);
+    }
+    for (int st = st_begin; st < st_end; ++st) {
+        const bool has_next = (st + 1 < st_end);
+        // K(st) landed?  (V(st) may still be in flight)
+        wait_vmcnt<VLD>();
+        // ---- S^T = K Q^T : Q fragments are register-resident; K fragments stream from LDS in
+        //      batches of 4 k16-steps, the next batch's reads issued ahead of this batch's MFMAs ----
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        {
+            u32x4 kf[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                kf[0][e] = *(const u32x4*)(sK + l31 * QROW + ((((2 * e + hi)) ^ (l31 & 15)) << 4));
+#pragma unroll
+            for (int kb4 = 0; kb4 < KST / 4; ++kb4) {
+                if (kb4 + 1 < KST / 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        kf[(kb4 + 1) & 1][e] = *(const u32x4*)(sK + l31 * QROW + (((2 * ((kb4 + 1) * 4 + e) + hi) ^ (l31 & 15)) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = T::mfma32(kf[kb4 & 1][e], qf[kb4 * 4 + e], s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // all K-fragment reads are consumed by the MFMAs above -> the K ring slot is free
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (has_next) issue_k(st + 1);
+
+        // ---- logits: scale, softcap, mask; online softmax in base 2 --------------------------
+        const int kb_local = st * 32;
+        float mx = -INFINITY;
+        if (use_cap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // cap*tanh(y) in base-2 units: tanh(y) = 1 - 2/(exp(2y)+1)
+                const float e2 = __expf(2.0f * s[r] * pre);
+                s[r] = capl2 * (1.0f - 2.0f / (e2 + 1.0f));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= pre;
+        }
+        if (kb_local + 32 > p.n_keys) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb_local + krow32(r, hi) >= p.n_keys) s[r] = -INFINITY;
+        }
+        if (p.mask) {
+            // 32 mask bytes of this sub-tile (the cache region is padded to 64 keys => in bounds)
+            const unsigned char* mp = p.mask + kb_local + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned mv = *(const unsigned*)(mp + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((mv >> (8 * e)) & 0xffu) == 0) s[4 * j + e] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+        m_run = m_new;
+        float pv[16], psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = exp2f(s[r] - m_use);
+            psum += pv[r];
+        }
+        l_run = l_run * alpha + psum;
+        const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        }
+        // V(st) landed?  (K(st+1) may be in flight)
+        if (has_next) wait_vmcnt<KLD>(); else wait_vmcnt<0>();
+        // ---- O^T += Vt P^T : 2 d-tiles (4 fragments) per batch, reads one batch ahead ----------
+        {
+            u32x4 vf[2][4];
+            auto read_v = [&](int buf, int dt0) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int d = (dt0 + e) * 32 + l31;
+                    const int swz = (d >> 2) & 3;
+                    vf[buf][2 * e] = *(const u32x4*)(sV + d * 64 + (((0 + hi) ^ swz) << 4));
+                    vf[buf][2 * e + 1] = *(const u32x4*)(sV + d * 64 + (((2 + hi) ^ swz) << 4));
+                }
+            };
+            read_v(0, 0);
+#pragma unroll
+            for (int b2 = 0; b2 < DT / 2; ++b2) {
+                if (b2 + 1 < DT / 2) read_v((b2 + 1) & 1, (b2 + 1) * 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    o[b2 * 2 + e] = T::mfma32(vf[b2 & 1][2 * e], pf0, o[b2 * 2 + e]);
+                    o[b2 * 2 + e] = T::mfma32(vf[b2 & 1][2 * e + 1], pf1, o[b2 * 2 + e]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (has_next) issue_v(st + 1);
+    }
+
+    // ---- emit this wave's partial ---------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const int r = r0 + l31;
+    if (r < p.R) {
+        const size_t base = ((size_t)wg * p.nkv + kvh) * p.Rpad + r;
+        if (hi == 0) {
+            p.ML[base * 2] = m_run;          // base-2 logit units
+            p.ML[base * 2 + 1] = l_tot;
+        }
+        float* orow = p.Opart + base * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 ov = {o[dt][4 * j], o[dt][4 * j + 1], o[dt][4 * j + 2], o[dt][4 * j + 3]};
+                *(f32x4*)(orow + dt * 32 + 8 * j + 4 * hi) = ov;
+            }
+    }
+}
+
+// Combine W partials per (row, kv head): O = sum_w 2^(m_w-m) O_w / sum_w 2^(m_w-m) l_w.
+// Optionally also emits (m, l) so that a further cross-GPU merge can be applied to the result.
+
+template <typename T, int HD>
+__global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
+    const int r = blockIdx.x, kvh = blockIdx.y, d = threadIdx.x;
+    float m = -INFINITY;
+    for (int w = 0; w < p.W; ++w) m = fmaxf(m, p.ML[(((size_t)w * p.nkv + kvh) * p.Rpad + r) * 2]);
+    float num = 0.f, den = 0.f;
+    if (m != -INFINITY) {
+        for (int w = 0; w < p.W; ++w) {
+            const size_t base = ((size_t)w * p.nkv + kvh) * p.Rpad + r;
+            const float mw = p.ML[base * 2];
+            if (mw == -INFINITY) continue;
+            const float sc = exp2f(mw - m);
+            den += sc * p.ML[base * 2 + 1];
+            num += sc * p.Opart[base * HD + d];
+        }
+    }
+    const int tq = r / p.G, g = r % p.G;
+    const size_t oidx = (size_t)tq * p.ldo + (kvh * p.G + g) * HD + d;
+    float out = (den > 0.f && !p.zero_out) ? num / den : 0.f;
+    if (p.Out) p.Out[oidx] = T::from_f32(out);
+    if (p.OutF32) p.OutF32[oidx] = (den > 0.f) ? num / den : 0.f;
+    if (p.OutML && d == 0) {
+        p.OutML[((size_t)tq * p.nkv * p.G + kvh * p.G + g) * 2] = m;
+        p.OutML[((size_t)tq * p.nkv * p.G + kvh * p.G + g) * 2 + 1] = den;
+    }
+}
+
+int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st) {
+    if (p.R <= 0 || p.n_keys <= 0 || p.G <= 0 || p.nkv <= 0 || zsplit <= 0) return VIDI_ERR_SHAPE;
+    if (p.key_start % 64 != 0 || p.Rpad % 32 != 0 || p.Rpad < p.R) return VIDI_ERR_SHAPE;
+    if ((p.ldq % 8) || ((uintptr_t)p.Q & 15) || ((uintptr_t)p.Kc & 15) || ((uintptr_t)p.Vtc & 15)) return VIDI_ERR_ALIGN;
+    if (HD != 256 && HD != 128) return VIDI_ERR_SHAPE;
+    const dim3 grid(p.nkv, p.Rpad / 32, zsplit);
+    const int lds = 32 * HD * 2 + 4 * (32 * HD * 2 + HD * 64);
+#define LAUNCH(TT, HH)                                                                        \
+    do {                                                                                      \
+        auto kern = attn_cross_kernel<TT, HH>;                                                \
+        static bool done = false;                                                             \
+        if (!done) {                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return (int)e;                                               \
+            done = true;                                                                      \
+        }                                                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                \
+    } while (0)
+    if (dtype == VIDI_DT_BF16) { if (HD == 256) LAUNCH(BF16, 256); else LAUNCH(BF16, 128); }
+    else if (dtype == VIDI_DT_F16) { if (HD == 256) LAUNCH(F16, 256); else LAUNCH(F16, 128); }
+    else return VIDI_ERR_DTYPE;
+#undef LAUNCH
+    return (int)hipGetLastError();
+}
+
+int vidi_attn_merge_dispatch(const AttnMergeParams& p, int HD, int dtype, hipStream_t st) {
+    if (p.R <= 0 || p.W <= 0) return VIDI_ERR_SHAPE;
+    const dim3 grid(p.R, p.nkv);
+    if (dtype == VIDI_DT_BF16) {
+        if (HD == 256) hipLaunchKernelGGL((attn_merge_kernel<BF16, 256>), grid, dim3(256), 0, st, p);
+        else if (HD == 128) hipLaunchKernelGGL((attn_merge_kernel<BF16, 128>), grid, dim3(128), 0, st, p);
+        else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (HD == 256) hipLaunchKernelGGL((attn_merge_kernel<F16, 256>), grid, dim3(256), 0, st, p);
+        else if (HD == 128) hipLaunchKernelGGL((attn_merge_kernel<F16, 128>), grid, dim3(128), 0, st, p);
+        else return VIDI_ERR_SHAPE;
+    } else {
+        return VIDI_ERR_DTYPE;
+    }
+    return (int)hipGetLastError();
+}

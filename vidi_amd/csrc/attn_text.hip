@@ -1,0 +1,117 @@
+// T2T causal self-attention over the short text stream (prompt ~40 tokens + <=1024 generated) and
+// the RoPE that precedes it.  Reference: Gemma2Attention.forward under FA2
+// (Vidi1.5_9B/vidi/model/lmm/dattn/gemma.py:165-175; TP gemma2/modeling_gemma2.py:146-168, 248-288):
+// causal, logits softcap, sliding window on even layers (FA2 window_size=(W,W): i-W <= j <= i),
+// right-padding key mask, GQA.  Tiny FLOPs; one wave per (batch, head, query row).
+#include "kernels.h"
+
+
+template <typename T, int HD>
+__global__ __launch_bounds__(64) void attn_text_kernel(AttnTextParams p) {
+    constexpr int EPL = HD / 64;                      // elements per lane
+    extern __shared__ float sc[];                     // [Lk] scores -> probabilities
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int kvh = h / (p.nq / p.nkv);
+    const int qi = p.past_len + i;
+    const int lo = (p.window > 0) ? max(0, qi - p.window) : 0;
+    const int hiK = qi;                               // inclusive
+    const u16* q = p.Q + ((size_t)b * p.Lq + i) * p.nq * HD + h * HD + lane * EPL;
+    float qf[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qf[e] = T::to_f32(q[e]);
+    const size_t kvstride = (size_t)p.nkv * HD;
+    const u16* kb = p.Kc + (size_t)b * p.Lmax * kvstride + kvh * HD + lane * EPL;
+    const u16* vb = p.Vc + (size_t)b * p.Lmax * kvstride + kvh * HD + lane * EPL;
+    const unsigned char* km = p.kmask ? p.kmask + (size_t)b * p.Lmax : nullptr;
+
+    float mx = -INFINITY;
+    for (int j = lo; j <= hiK; ++j) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], T::to_f32(kb[(size_t)j * kvstride + e]), d);
+        d = wave_sum(d) * p.scale;
+        if (p.softcap > 0.f) d = p.softcap * tanhf(d / p.softcap);
+        if (km && km[j] == 0) d = -INFINITY;
+        if (lane == 0) sc[j - lo] = d;
+        mx = fmaxf(mx, d);
+    }
+    __syncthreads();
+    const int n = hiK - lo + 1;
+    float lsum = 0.f;
+    const float m_use = (mx == -INFINITY) ? 0.f : mx;
+    for (int j = lane; j < n; j += 64) {
+        const float pj = __expf(sc[j] - m_use);
+        lsum += pj;
+        sc[j] = rnd<T>(pj);                           // flash-attn feeds P in the model dtype to PV
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    float o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float pj = sc[j];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = fmaf(pj, T::to_f32(vb[(size_t)(lo + j) * kvstride + e]), o[e]);
+    }
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    u16* op = p.O + ((size_t)b * p.Lq + i) * p.nq * HD + h * HD + lane * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) op[e] = T::from_f32(o[e] * inv);
+}
+
+// RoPE (rotate_half form) applied in place to Q [rows, nq*HD] and K [rows, nkv*HD];
+// cos/sin [rows, HD] are in the model dtype like the reference's (cast after fp32 computation).
+// Each product and the sum round to the model dtype as eager torch does.
+template <typename T>
+__global__ void rope_kernel(u16* Q, u16* K, const u16* cs, const u16* sn, int rows, int nq, int nkv, int HD) {
+    const int half = HD / 2;
+    const size_t total = (size_t)rows * (nq + nkv) * half;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = idx % half;
+        const size_t t = idx / half;
+        const int hh = t % (nq + nkv);
+        const size_t row = t / (nq + nkv);
+        u16* base = (hh < nq) ? Q + (row * nq + hh) * HD : K + (row * nkv + (hh - nq)) * HD;
+        const float x1 = T::to_f32(base[d]), x2 = T::to_f32(base[d + half]);
+        const float c1 = T::to_f32(cs[row * HD + d]), c2 = T::to_f32(cs[row * HD + d + half]);
+        const float s1 = T::to_f32(sn[row * HD + d]), s2 = T::to_f32(sn[row * HD + d + half]);
+        const float y1 = rnd<T>(x1 * c1) + rnd<T>(-x2 * s1);
+        const float y2 = rnd<T>(x2 * c2) + rnd<T>(x1 * s2);
+        base[d] = T::from_f32(y1);
+        base[d + half] = T::from_f32(y2);
+    }
+}
+
+int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStream_t st) {
+    if (p.B <= 0 || p.Lq <= 0 || p.nq <= 0 || p.nkv <= 0 || p.nq % p.nkv) return VIDI_ERR_SHAPE;
+    if (p.past_len + p.Lq > p.Lmax) return VIDI_ERR_SHAPE;
+    const dim3 grid(p.Lq, p.nq, p.B);
+    const int lds = (p.past_len + p.Lq) * 4;
+    if (lds > 64 * 1024) return VIDI_ERR_SHAPE;
+    if (dtype == VIDI_DT_BF16) {
+        if (HD == 256) hipLaunchKernelGGL((attn_text_kernel<BF16, 256>), grid, dim3(64), lds, st, p);
+        else if (HD == 128) hipLaunchKernelGGL((attn_text_kernel<BF16, 128>), grid, dim3(64), lds, st, p);
+        else if (HD == 64) hipLaunchKernelGGL((attn_text_kernel<BF16, 64>), grid, dim3(64), lds, st, p);
+        else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (HD == 256) hipLaunchKernelGGL((attn_text_kernel<F16, 256>), grid, dim3(64), lds, st, p);
+        else if (HD == 128) hipLaunchKernelGGL((attn_text_kernel<F16, 128>), grid, dim3(64), lds, st, p);
+        else if (HD == 64) hipLaunchKernelGGL((attn_text_kernel<F16, 64>), grid, dim3(64), lds, st, p);
+        else return VIDI_ERR_SHAPE;
+    } else {
+        return VIDI_ERR_DTYPE;
+    }
+    return (int)hipGetLastError();
+}
+
+int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int rows, int nq, int nkv, int HD, int dtype, hipStream_t st) {
+    if (rows <= 0 || HD % 2) return VIDI_ERR_SHAPE;
+    const size_t total = (size_t)rows * (nq + nkv) * (HD / 2);
+    const int blocks = (int)min((total + 255) / 256, (size_t)4096);
+    if (dtype == VIDI_DT_BF16) hipLaunchKernelGGL(rope_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (u16*)Q, (u16*)K, (const u16*)cs, (const u16*)sn, rows, nq, nkv, HD);
+    else if (dtype == VIDI_DT_F16) hipLaunchKernelGGL(rope_kernel<F16>, dim3(blocks), dim3(256), 0, st, (u16*)Q, (u16*)K, (const u16*)cs, (const u16*)sn, rows, nq, nkv, HD);
+    else return VIDI_ERR_DTYPE;
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,207 @@
+// extern "C" entry points of libvidi_hip.so (declared in include/vidi_hip.h).
+#include "kernels.h"
+#include "../../include/vidi_hip.h"
+
+extern "C" {
+
+int vidi_abi_version(void) { return VIDI_ABI_VERSION; }
+const char* vidi_build_info(void) { return "vidi_hip gfx950 " __DATE__ " " __TIME__; }
+
+static GemmParams base_params(const void* X, const void* W, const void* bias, void* Y, const void* R,
+                              int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int rmod) {
+    GemmParams p;
+    __builtin_memset(&p, 0, sizeof(p));
+    p.X = (const u16*)X; p.W = (const u16*)W; p.bias = (const u16*)bias; p.Y = (u16*)Y; p.R = (const u16*)R;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldr = ldr;
+    p.rmod = rmod > 0 ? rmod : 0x7fffffff;
+    return p;
+}
+
+int vidi_gemm(const void* X, const void* W, const void* bias, void* Y, const void* R,
+              int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int rmod,
+              long long bsX, long long bsY, long long bsR, int batch,
+              int act, int repkv_hd, int repkv_g, int tile_cfg, int dtype, void* stream) {
+    if (!X || !W || !Y) return VIDI_ERR_ARG;
+    if (R && (ldr % 4)) return VIDI_ERR_ALIGN;
+    GemmParams p = base_params(X, W, bias, Y, R, M, N, K, ldx, ldw, ldy, ldr, rmod);
+    p.bsX = bsX; p.bsY = bsY; p.bsR = bsR; p.act = act;
+    const int repkv = (repkv_hd > 0 && repkv_g > 1) ? 1 : 0;
+    if (repkv) {
+        if (repkv_hd % 8) return VIDI_ERR_SHAPE;
+        p.rep_hd = repkv_hd; p.rep_g = repkv_g;
+    }
+    return vidi_gemm_dispatch(p, batch, MODE_PLAIN, repkv, tile_cfg, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
+                    int tile_cfg, int dtype, void* stream) {
+    if (!X || !Wgu || !Y) return VIDI_ERR_ARG;
+    if (I % 32) return VIDI_ERR_SHAPE;
+    GemmParams p = base_params(X, Wgu, nullptr, Y, nullptr, M, 2 * I, K, ldx, ldw, ldy, 0, 0);
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_GEGLU, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, void* Vt,
+                     int M, int N, int K, int ldx, int ldw, int ldy,
+                     int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream) {
+    if (!X || !W || !Yqk || !Vt) return VIDI_ERR_ARG;
+    if (vstart % 4 || hd % 4 || seq <= 0 || seqpad % 16 || seqpad < ((seq + 15) / 16) * 16 || M % seq) return VIDI_ERR_SHAPE;
+    if ((N - vstart) != nheads * hd) return VIDI_ERR_SHAPE;
+    GemmParams p = base_params(X, W, bias, Yqk, nullptr, M, N, K, ldx, ldw, ldy, 0, 0);
+    p.vstart = vstart; p.hd = hd; p.seq = seq; p.seqpad = seqpad; p.nheads = nheads; p.Vt = (u16*)Vt;
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_QKV_VT, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* Vrow,
+                       int M, int kvd, int K, int ldx, int ldw, int hd, int ntile64, int tok0,
+                       int tile_cfg, int dtype, void* stream) {
+    if (!X || !W || !Kc || !Vtc || !Vrow) return VIDI_ERR_ARG;
+    if (kvd % hd || hd % 4 || tok0 < 0 || (tok0 + M + 63) / 64 > ntile64) return VIDI_ERR_SHAPE;
+    GemmParams p = base_params(X, W, nullptr, Vrow, nullptr, M, 2 * kvd, K, ldx, ldw, kvd, 0, 0);
+    p.Kc = (u16*)Kc; p.Vtc = (u16*)Vtc; p.Vrow = (u16*)Vrow; p.kvd = kvd; p.hd = hd; p.ntile64 = ntile64; p.tok0 = tok0;
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_KV_CACHE, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
+              int dtype, void* stream) {
+    if (!X || !W || !Y) return VIDI_ERR_ARG;
+    return vidi_gemv_dispatch(X, W, Y, M, N, K, ldx, ldw, ldy, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
+                  int ldx, int ldw, int ldy, int act, void* stream) {
+    if (!X || !W || !Y) return VIDI_ERR_ARG;
+    return vidi_gemm_f32_dispatch(X, W, bias, Y, M, N, K, ldx, ldw, ldy, act, (hipStream_t)stream);
+}
+
+int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Npad, int H, int D,
+                   int ldqk, int koff, int ldo, float scale, int dtype, void* stream) {
+    if (!QK || !Vt || !O) return VIDI_ERR_ARG;
+    AttnSelfParams p;
+    p.QK = (const u16*)QK; p.Vt = (const u16*)Vt; p.O = (u16*)O;
+    p.B = B; p.N = N; p.Npad = Npad; p.H = H; p.ldqk = ldqk; p.koff = koff; p.ldo = ldo; p.scale = scale;
+    return vidi_attn_self_dispatch(p, D, dtype, (hipStream_t)stream);
+}
+
+size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD) {
+    const size_t W = (size_t)zsplit * 4;
+    return W * nkv * Rpad * (size_t)(HD + 2) * sizeof(float);
+}
+
+int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
+                    int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
+                    float scale, float softcap, int zsplit, int dtype, void* stream) {
+    if (!Q || !Kc || !Vtc || !Opart || !ML) return VIDI_ERR_ARG;
+    if ((key_start + n_keys + 63) / 64 > ntile64) return VIDI_ERR_SHAPE;
+    AttnCrossParams p;
+    p.Q = (const u16*)Q; p.Kc = (const u16*)Kc; p.Vtc = (const u16*)Vtc; p.mask = (const unsigned char*)mask;
+    p.Opart = Opart; p.ML = ML; p.R = R; p.Rpad = Rpad; p.G = G; p.nkv = nkv; p.ldq = ldq;
+    p.ntile64 = ntile64; p.key_start = key_start; p.n_keys = n_keys; p.scale = scale; p.softcap = softcap;
+    return vidi_attn_cross_dispatch(p, HD, zsplit, dtype, (hipStream_t)stream);
+}
+
+int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF32, float* OutML,
+                    int W, int nkv, int R, int Rpad, int G, int HD, int ldo, int zero_out, int dtype, void* stream) {
+    if (!Opart || !ML || (!Out && !OutF32)) return VIDI_ERR_ARG;
+    AttnMergeParams p;
+    p.Opart = Opart; p.ML = ML; p.Out = (u16*)Out; p.OutF32 = OutF32; p.OutML = OutML;
+    p.W = W; p.nkv = nkv; p.R = R; p.Rpad = Rpad; p.G = G; p.ldo = ldo; p.zero_out = zero_out;
+    return vidi_attn_merge_dispatch(p, HD, dtype, (hipStream_t)stream);
+}
+
+int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
+                   int B, int Lq, int Lmax, int nq, int nkv, int HD, int past_len, int window,
+                   float scale, float softcap, int dtype, void* stream) {
+    if (!Q || !Kc || !Vc || !O) return VIDI_ERR_ARG;
+    AttnTextParams p;
+    p.Q = (const u16*)Q; p.Kc = (const u16*)Kc; p.Vc = (const u16*)Vc; p.kmask = (const unsigned char*)kmask; p.O = (u16*)O;
+    p.B = B; p.Lq = Lq; p.Lmax = Lmax; p.nq = nq; p.nkv = nkv; p.past_len = past_len; p.window = window;
+    p.scale = scale; p.softcap = softcap;
+    return vidi_attn_text_dispatch(p, HD, dtype, (hipStream_t)stream);
+}
+
+int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
+              int dtype, void* stream) {
+    if (!Q || !K || !cos_ || !sin_) return VIDI_ERR_ARG;
+    return vidi_rope_dispatch(Q, K, cos_, sin_, rows, nq, nkv, HD, dtype, (hipStream_t)stream);
+}
+
+int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
+              void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
+              float eps, float normalizer, int sample_flag, int dtype, void* stream) {
+    if ((!X && !XF32) || !Y) return VIDI_ERR_ARG;
+    NormParams p;
+    p.X = (const u16*)X; p.XF32 = XF32; p.Wt = (const u16*)W; p.Bias = (const u16*)Bias; p.Res = (const u16*)Res;
+    p.Y = (u16*)Y; p.Mask = (unsigned char*)Mask; p.rows = rows; p.H = H; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
+    p.eps = eps; p.normalizer = normalizer; p.sample_flag = sample_flag;
+    return vidi_norm_dispatch(p, mode, dtype, (hipStream_t)stream);
+}
+
+int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, int dtype, void* stream) {
+    if (!px || !A || T <= 0 || S % P || Kpad < 3 * P * P) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)px, A};
+    const long long i[4] = {T, S, P, Kpad};
+    return vidi_ew_dispatch(EW_IM2COL, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_pool_s2d(const void* f, void* out, int T, int side, int C, int h, int w, int m, int resize, int dtype, void* stream) {
+    if (!f || !out || T <= 0 || m <= 0) return VIDI_ERR_ARG;
+    if (!resize && (h != side + 1 || w != side + 1)) return VIDI_ERR_SHAPE;
+    void* a[2] = {(void*)f, out};
+    const long long i[7] = {T, side, C, h, w, m, resize};
+    return vidi_ew_dispatch(EW_POOL, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_add_pos(void* f, const void* ph, const void* pw, const void* pt, int T, int oh, int ow, int H, int dtype, void* stream) {
+    if (!f) return VIDI_ERR_ARG;
+    void* a[4] = {f, (void*)ph, (void*)pw, (void*)pt};
+    const long long i[4] = {T, oh, ow, H};
+    return vidi_ew_dispatch(EW_ADDPOS, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_add3(const void* a_, const void* b, const void* c, void* y, long long n, int dtype, void* stream) {
+    if (!a_ || !y) return VIDI_ERR_ARG;
+    void* a[4] = {(void*)a_, (void*)b, (void*)c, y};
+    const long long i[1] = {n};
+    return vidi_ew_dispatch(EW_ADD3, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_embed(const long long* ids, const void* E, void* out, int n, int H, long long vocab, float normalizer, int dtype, void* stream) {
+    if (!ids || !E || !out) return VIDI_ERR_ARG;
+    void* a[3] = {(void*)ids, (void*)E, out};
+    const long long i[3] = {n, H, vocab};
+    const float f[1] = {normalizer};
+    return vidi_ew_dispatch(EW_EMBED, a, i, f, dtype, (hipStream_t)stream);
+}
+
+int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* stream) {
+    if (!Yp || !out) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)Yp, out};
+    const long long i[2] = {M, I};
+    return vidi_ew_dispatch(EW_GEGLU_UNPACK, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream) {
+    if (!logits || !idx || B <= 0 || V <= 0) return VIDI_ERR_ARG;
+    void* a[2] = {logits, (void*)idx};
+    const long long i[3] = {B, V, ld};
+    const float f[1] = {cap};
+    return vidi_ew_dispatch(EW_SOFTCAP_ARGMAX, a, i, f, dtype, (hipStream_t)stream);
+}
+
+int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, int dtype, void* stream) {
+    if (!mel || !out) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)mel, out};
+    const long long i[3] = {C, nmel, L};
+    return vidi_ew_dispatch(EW_MEL_T, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_sinusoid(float* pe, const float* div_term, int rows, int i0, int l, int N, int d, void* stream) {
+    if (!pe || !div_term) return VIDI_ERR_ARG;
+    return vidi_sinusoid_dispatch(pe, div_term, rows, i0, l, N, d, (hipStream_t)stream);
+}
+
+}  // extern "C"

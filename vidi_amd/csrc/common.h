@@ -1,0 +1,132 @@
+// Shared device helpers for the vidi_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- C-ABI constants (mirrored in include/vidi_hip.h) -------------------------------------
+#define VIDI_DT_BF16 0
+#define VIDI_DT_F16 1
+
+#define VIDI_OK 0
+#define VIDI_ERR_SHAPE (-1)
+#define VIDI_ERR_DTYPE (-2)
+#define VIDI_ERR_ALIGN (-3)
+#define VIDI_ERR_ARG (-4)
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- scalar conversions -------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ u16 f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float f16_to_f32(u16 v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+__device__ __forceinline__ u16 f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    u16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
+}
+
+struct BF16 {
+    static constexpr int id = VIDI_DT_BF16;
+    static __device__ __forceinline__ float to_f32(u16 v) { return bf16_to_f32(v); }
+    static __device__ __forceinline__ u16 from_f32(float f) { return f32_to_bf16(f); }
+    static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c, 0, 0, 0);
+    }
+};
+struct F16 {
+    static constexpr int id = VIDI_DT_F16;
+    static __device__ __forceinline__ float to_f32(u16 v) { return f16_to_f32(v); }
+    static __device__ __forceinline__ u16 from_f32(float f) { return f32_to_f16(f); }
+    static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    }
+};
+
+// round an fp32 value to the storage dtype and back (the reference rounds every module output)
+template <typename T>
+__device__ __forceinline__ float rnd(float f) { return T::to_f32(T::from_f32(f)); }
+
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)T::from_f32(lo) | ((unsigned)T::from_f32(hi) << 16);
+}
+template <typename T>
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = T::to_f32((u16)(v[i] & 0xffffu));
+        f[2 * i + 1] = T::to_f32((u16)(v[i] >> 16));
+    }
+}
+template <typename T>
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2<T>(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// ---- math ---------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3))) — torch gelu(approximate='tanh')
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float inner = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// MFMA 32x32 C/D layout: lane l holds column (l & 31); register r holds row krow32(r, l >> 5).
+__device__ __forceinline__ int krow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+// Key permutation inside a 16-slab so that MFMA operand slot (g = lane>>5, e) of a 16-deep
+// contraction is register r = 8*slab + e of a swapped-QK^T score tile: position p = 8g+e holds
+// key (e&3) + 8*(e>>2) + 4g.  perm16(key) gives the storage position of `key` (involution-free map).
+__host__ __device__ __forceinline__ int perm16(int x) { return 8 * ((x >> 2) & 1) + (x & 3) + 4 * (x >> 3); }
+
+// async global -> LDS, 16 B per lane, LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else static_assert(N < 0, "unsupported vmcnt");
+}

@@ -1,0 +1,493 @@
+// MFMA GEMM family for the Vidi hot path (gfx950).
+//
+//   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] )        X:[M,K] activations, W:[N,K] nn.Linear weight
+//
+// Both operands are K-contiguous, so both are staged with 16-byte `global_load_lds` DMA into an
+// XOR-swizzled LDS image and read back as 8-element MFMA fragments with ds_read_b128.  The MFMA is
+// issued "swapped": the weight tile is the A operand and the activation tile the B operand, so the
+// 32x32 accumulator holds D[row = n][col = m].  Each lane then owns ONE token (m = lane & 31) and
+// four consecutive output features per register quad, which makes every epilogue a plain 8-byte
+// store and lets GeGLU / bias / residual / KV-cache layouts be applied per lane without shuffles.
+//
+// Roofline: MFMA-bound (2.5 PFLOP/s dense bf16/fp16).  Algorithmic FLOPs = 2*M*N*K.
+#include "kernels.h"
+
+
+
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV>
+__global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
+    constexpr int NT = WN * WM * 64;
+    constexpr int TN = BN / WN / 32, TM = BM / WM / 32;
+    constexpr int W_LOADS = BN * 8 / NT, X_LOADS = BM * 8 / NT;
+    constexpr int LPT = W_LOADS + X_LOADS;
+    constexpr int STAGE_BYTES = (BN + BM) * 128;
+    static_assert(BN * 8 % NT == 0 && BM * 8 % NT == 0, "tile/threads mismatch");
+    static_assert(MODE != MODE_GEGLU || (TN % 2 == 0), "GeGLU needs gate/up tile pairs per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+
+    // ---- block -> tile: XCD-contiguous remap (bijective), then grouped ordering --------------
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    int tile_n, tile_m;
+    {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+        const int rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        constexpr int GROUP_M = 8;
+        const int per_group = GROUP_M * tiles_n;
+        const int g = rb / per_group, first_m = g * GROUP_M;
+        const int gm = min(tiles_m - first_m, GROUP_M);
+        const int in_g = rb - g * per_group;
+        tile_m = first_m + in_g % gm;
+        tile_n = in_g / gm;
+    }
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
+    const long long bz = blockIdx.y;
+    const u16* Xb = p.X + bz * p.bsX;
+
+    // ---- per-thread DMA source pointers (k0 added per stage) ----------------------------------
+    const u16* wsrc[W_LOADS];
+    const u16* xsrc[X_LOADS];
+    int xcol[X_LOADS];
+#pragma unroll
+    for (int j = 0; j < W_LOADS; ++j) {
+        const int pidx = j * NT + tid, row = pidx >> 3, cl = pidx & 7, cg = cl ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        wsrc[j] = p.W + (size_t)n * p.ldw + cg * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < X_LOADS; ++j) {
+        const int pidx = j * NT + tid, row = pidx >> 3, cl = pidx & 7, cg = cl ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, p.M - 1);
+        xsrc[j] = Xb + (size_t)m * p.ldx;
+        xcol[j] = cg * 8;
+        if constexpr (!REPKV) xsrc[j] += cg * 8;
+    }
+
+    auto load_stage = [&](int stage, int kt) {
+        char* sW = smem + stage * STAGE_BYTES;
+        char* sX = sW + BN * 128;
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) glds16(wsrc[j] + k0, sW + (j * NT + wave * 64) * 16);
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j) {
+            if constexpr (REPKV) {
+                const int k = k0 + xcol[j];
+                const int phys = (k / (p.rep_g * p.rep_hd)) * p.rep_hd + (k % p.rep_hd);
+                glds16(xsrc[j] + phys, sX + (j * NT + wave * 64) * 16);
+            } else {
+                glds16(xsrc[j] + k0, sX + (j * NT + wave * 64) * 16);
+            }
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw = (l31 >> 1) & 7;                         // row swizzle (tile bases are multiples of 32)
+    const int w_row_off = (wn * TN * 32 + l31) * 128;
+    const int x_row_off = (wm * TM * 32 + l31) * 128;
+
+    const int nk = p.K / 64;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) load_stage(s, s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = min(STAGES - 2, nk - 1 - kt);
+        if constexpr (STAGES == 2) {
+            wait_vmcnt<0>();
+        } else if constexpr (STAGES == 3) {
+            if (rem >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        } else {
+            if (rem >= 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) load_stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+
+        const char* sW = smem + (kt % STAGES) * STAGE_BYTES;
+        const char* sX = sW + BN * 128;
+        // fragments of k16-step s+1 are read before the MFMAs of step s (software pipeline in regs)
+        u32x4 wf[2][TN], xf[2][TM];
+        auto read_frags = [&](int buf, int s) {
+            const int coff = ((2 * s + hi) ^ sw) << 4;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf[buf][a] = *(const u32x4*)(sW + w_row_off + a * 32 * 128 + coff);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xf[buf][b] = *(const u32x4*)(sX + x_row_off + b * 32 * 128 + coff);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < 3) read_frags((s + 1) & 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma32(wf[s & 1][a], xf[s & 1][b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    u16* Yb = p.Y + bz * p.bsY;
+    const u16* Rb = p.R ? p.R + bz * p.bsR : nullptr;
+    const bool act_tanh = (p.act == ACT_GELU_TANH), act_erf = (p.act == ACT_GELU_ERF);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * TM * 32 + b * 32 + l31;
+        if (m >= p.M) continue;
+        const int mr = Rb ? (m % p.rmod) : 0;
+        if constexpr (MODE == MODE_GEGLU) {
+#pragma unroll
+            for (int a = 0; a < TN; a += 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nw = n0 + wn * TN * 32 + a * 32;          // W-row base of the gate tile
+                    if (nw >= p.N) continue;
+                    const int no = (nw >> 1) + 8 * j + 4 * hi;          // output feature
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = rnd<T>(acc[a][b][4 * j + e]);
+                        const float u = rnd<T>(acc[a + 1][b][4 * j + e]);
+                        v[e] = rnd<T>(gelu_tanh_f(g)) * u;
+                    }
+                    u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                    *(u32x2*)(Yb + (size_t)m * p.ldy + no) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * TN * 32 + a * 32 + 8 * j + 4 * hi;
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * j + e];
+                    if (p.bias) {
+                        const u32x2 bv = *(const u32x2*)(p.bias + n);
+                        v[0] += T::to_f32((u16)(bv[0] & 0xffff)); v[1] += T::to_f32((u16)(bv[0] >> 16));
+                        v[2] += T::to_f32((u16)(bv[1] & 0xffff)); v[3] += T::to_f32((u16)(bv[1] >> 16));
+                    }
+                    if (act_tanh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(rnd<T>(v[e]));
+                    }
+                    if (act_erf) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(rnd<T>(v[e]));
+                    }
+                    if (Rb) {
+                        const u32x2 rv = *(const u32x2*)(Rb + (size_t)mr * p.ldr + n);
+                        v[0] = rnd<T>(v[0]) + T::to_f32((u16)(rv[0] & 0xffff)); v[1] = rnd<T>(v[1]) + T::to_f32((u16)(rv[0] >> 16));
+                        v[2] = rnd<T>(v[2]) + T::to_f32((u16)(rv[1] & 0xffff)); v[3] = rnd<T>(v[3]) + T::to_f32((u16)(rv[1] >> 16));
+                    }
+                    const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                    if constexpr (MODE == MODE_PLAIN) {
+                        *(u32x2*)(Yb + (size_t)m * p.ldy + n) = o;
+                    } else if constexpr (MODE == MODE_QKV_VT) {
+                        if (n < p.vstart) {
+                            *(u32x2*)(Yb + (size_t)m * p.ldy + n) = o;
+                        } else {
+                            const int c = n - p.vstart, h = c / p.hd, d = c % p.hd;
+                            const int bi = m / p.seq, tok = m % p.seq;
+                            const int pos = (tok & ~15) | perm16(tok & 15);
+                            u16* dst = p.Vt + (((size_t)bi * p.nheads + h) * p.hd + d) * p.seqpad + pos;
+                            dst[0] = (u16)(o[0] & 0xffff); dst[(size_t)p.seqpad] = (u16)(o[0] >> 16);
+                            dst[2 * (size_t)p.seqpad] = (u16)(o[1] & 0xffff); dst[3 * (size_t)p.seqpad] = (u16)(o[1] >> 16);
+                        }
+                    } else {   // MODE_KV_CACHE
+                        const int tok = p.tok0 + m, tile = tok >> 6, tk = tok & 63;
+                        if (n < p.kvd) {
+                            const int kvh = n / p.hd, d = n % p.hd;
+                            *(u32x2*)(p.Kc + (((size_t)kvh * p.ntile64 + tile) * 64 + tk) * p.hd + d) = o;
+                        } else {
+                            const int c = n - p.kvd, kvh = c / p.hd, d = c % p.hd;
+                            *(u32x2*)(p.Vrow + (size_t)m * p.kvd + c) = o;
+                            const int pos = (tk & ~15) | perm16(tk & 15);
+                            u16* dst = p.Vtc + (((size_t)kvh * p.ntile64 + tile) * p.hd + d) * 64 + pos;
+                            dst[0] = (u16)(o[0] & 0xffff); dst[64] = (u16)(o[0] >> 16);
+                            dst[128] = (u16)(o[1] & 0xffff); dst[192] = (u16)(o[1] >> 16);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- conservative variant: register-staged (global_load -> ds_write), same LDS image ----------
+// Used by the self-test to cross-check the LDS-DMA path and as a fallback selectable from the ABI.
+template <typename T, int MODE, bool REPKV>
+__global__ __launch_bounds__(256) void gemm_kernel_regstage(GemmParams p) {
+    constexpr int BN = 128, BM = 128, WM = 2, TN = 2, TM = 2, NT = 256;
+    __shared__ __attribute__((aligned(16))) char smem[(BN + BM) * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave / WM, wm = wave % WM;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
+    const long long bz = blockIdx.y;
+    const u16* Xb = p.X + bz * p.bsX;
+    f32x16 acc[TN][TM];
+    for (int a = 0; a < TN; ++a) for (int b = 0; b < TM; ++b) for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+    char* sW = smem; char* sX = smem + BN * 128;
+    for (int kt = 0; kt < p.K / 64; ++kt) {
+        const int k0 = kt * 64;
+        u32x4 wr[4], xr[4];
+        for (int j = 0; j < 4; ++j) {
+            const int pidx = j * NT + tid, row = pidx >> 3, c = pidx & 7;
+            const int n = min(n0 + row, p.N - 1), m = min(m0 + row, p.M - 1);
+            wr[j] = *(const u32x4*)(p.W + (size_t)n * p.ldw + k0 + c * 8);
+            int k = k0 + c * 8;
+            if constexpr (REPKV) k = (k / (p.rep_g * p.rep_hd)) * p.rep_hd + (k % p.rep_hd);
+            xr[j] = *(const u32x4*)(Xb + (size_t)m * p.ldx + k);
+        }
+        __syncthreads();
+        for (int j = 0; j < 4; ++j) {
+            const int pidx = j * NT + tid, row = pidx >> 3, c = pidx & 7;
+            const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+            *(u32x4*)(sW + off) = wr[j];
+            *(u32x4*)(sX + off) = xr[j];
+        }
+        __syncthreads();
+        for (int s = 0; s < 4; ++s) {
+            const int coff = ((2 * s + hi) ^ sw) << 4;
+            u32x4 wf[TN], xf[TM];
+            for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(sW + (wn * 64 + a * 32 + l31) * 128 + coff);
+            for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(sX + (wm * 64 + b * 32 + l31) * 128 + coff);
+            for (int a = 0; a < TN; ++a) for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma32(wf[a], xf[b], acc[a][b]);
+        }
+    }
+    u16* Yb = p.Y + bz * p.bsY;
+    for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * 64 + b * 32 + l31;
+        if (m >= p.M) continue;
+        for (int a = 0; a < TN; ++a) for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + a * 32 + 8 * j + 4 * hi;
+            if (n >= p.N) continue;
+            float v[4];
+            for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * j + e];
+            if (p.bias) for (int e = 0; e < 4; ++e) v[e] += T::to_f32(p.bias[n + e]);
+            const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+            *(u32x2*)(Yb + (size_t)m * p.ldy + n) = o;
+        }
+    }
+}
+
+// ---- skinny GEMM (M <= 8): HBM-bound weight streaming for decode -------------------------------
+//   Y[m][n] = sum_k X[m][k] W[n][k].  Every wave owns RPW weight rows per step and streams them
+//   with 16-byte non-temporal loads straight into VGPRs (no LDS round trip: each weight byte is
+//   used once); the few activation rows are re-read from L1/L2.  Wave-reduce at the end.
+//   Algorithmic bytes = N*K*2 (weights); roofline = HBM.
+template <typename T, int MMAX, int RPW>
+__global__ __launch_bounds__(256) void gemv_kernel(const u16* __restrict__ X, const u16* __restrict__ W, u16* __restrict__ Y,
+                                                   int M, int N, int K, int ldx, int ldw, int ldy) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = K / 8;                          // 16-byte chunks per row
+    const int waves_total = gridDim.x * 4;
+    for (int nb = (blockIdx.x * 4 + wave) * RPW; nb < N; nb += waves_total * RPW) {
+        float acc[RPW][MMAX];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < MMAX; ++m) acc[r][m] = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            u32x4 wv[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int n = min(nb + r, N - 1);
+                wv[r] = __builtin_nontemporal_load((const u32x4*)(W + (size_t)n * ldw + c * 8));
+            }
+            float xf[MMAX][8];
+#pragma unroll
+            for (int m = 0; m < MMAX; ++m) {
+                const int mm = min(m, M - 1);
+                const u32x4 xv = *(const u32x4*)(X + (size_t)mm * ldx + c * 8);
+                unpack8<T>(xv, xf[m]);
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                float wf[8];
+                unpack8<T>(wv[r], wf);
+#pragma unroll
+                for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r][m] = fmaf(wf[e], xf[m][e], acc[r][m]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < MMAX; ++m) {
+                const float s = wave_sum(acc[r][m]);
+                if (lane == 0 && nb + r < N && m < M) Y[(size_t)m * ldy + nb + r] = T::from_f32(s);
+            }
+    }
+}
+
+// ---- fp32 GEMM on f32-input MFMA (exact fp32): the positional-embedding MLPs run in fp32 -------
+//   Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]); all fp32, K % 16 == 0.
+//   mfma_f32_32x32x2f32: A lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31].
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ Y,
+                                                       int M, int N, int K, int ldx, int ldw, int ldy, int act) {
+    constexpr int BN = 128, BM = 128, BK = 16, LDT = BK + 1;   // +1 pad: conflict-free column reads
+    __shared__ float sW[BN * LDT], sX[BM * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wm = wave & 1;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int n0 = (blockIdx.x % tiles_n) * BN, m0 = (blockIdx.x / tiles_n) * BM;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();
+        for (int i = tid; i < BN * BK / 4; i += 256) {              // 4 floats per thread-step
+            const int row = i / (BK / 4), c4 = (i % (BK / 4)) * 4;
+            const int n = min(n0 + row, N - 1), m = min(m0 + row, M - 1);
+            const f32x4 wv = *(const f32x4*)(W + (size_t)n * ldw + k0 + c4);
+            const f32x4 xv = *(const f32x4*)(X + (size_t)m * ldx + k0 + c4);
+            for (int e = 0; e < 4; ++e) { sW[row * LDT + c4 + e] = wv[e]; sX[row * LDT + c4 + e] = xv[e]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float wf[2], xf[2];
+            for (int a = 0; a < 2; ++a) wf[a] = sW[(wn * 64 + a * 32 + l31) * LDT + 2 * s + hi];
+            for (int b = 0; b < 2; ++b) xf[b] = sX[(wm * 64 + b * 32 + l31) * LDT + 2 * s + hi];
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    for (int b = 0; b < 2; ++b) {
+        const int m = m0 + wm * 64 + b * 32 + l31;
+        if (m >= M) continue;
+        for (int a = 0; a < 2; ++a) for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + a * 32 + 8 * j + 4 * hi;
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= N) continue;
+                float v = acc[a][b][4 * j + e] + (bias ? bias[n + e] : 0.f);
+                if (act == ACT_GELU_ERF) v = gelu_erf_f(v);
+                Y[(size_t)m * ldy + n + e] = v;
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// host-side dispatch (C ABI in capi.hip calls these)
+// =============================================================================================
+template <typename K>
+static hipError_t set_lds(K kern, int bytes) {
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV>
+static int launch_cfg(const GemmParams& p, int batch, hipStream_t st) {
+    constexpr int LDS = STAGES * (BN + BM) * 128;
+    auto kern = gemm_kernel<T, BN, BM, WN, WM, STAGES, MODE, REPKV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = set_lds(kern, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(WN * WM * 64), LDS, st, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int MODE, bool REPKV>
+static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t st) {
+    if (tile_cfg == 3) {
+        if constexpr (MODE == MODE_PLAIN) {
+            const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);
+            hipLaunchKernelGGL((gemm_kernel_regstage<T, MODE, REPKV>), dim3(tiles, batch), dim3(256), 0, st, p);
+            return (int)hipGetLastError();
+        } else {
+            return VIDI_ERR_ARG;
+        }
+    }
+    if (tile_cfg < 0) {
+        // heuristic: big-tile deep pipeline when there is enough work to fill 256 CUs with it
+        const long long t256 = (long long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
+        const long long t128x256 = (long long)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
+        if (p.N % 256 == 0 && t256 >= 512) tile_cfg = 2;
+        else if (t128x256 >= 512) tile_cfg = 1;
+        else tile_cfg = 0;
+    }
+    switch (tile_cfg) {
+        case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV>(p, batch, st);
+        case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
+        case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
+        default: return VIDI_ERR_ARG;
+    }
+}
+
+template <typename T>
+static int launch_dtype(const GemmParams& p, int batch, int mode, int repkv, int tile_cfg, hipStream_t st) {
+    switch (mode) {
+        case MODE_PLAIN: return repkv ? launch_mode<T, MODE_PLAIN, true>(p, batch, tile_cfg, st)
+                                      : launch_mode<T, MODE_PLAIN, false>(p, batch, tile_cfg, st);
+        case MODE_GEGLU: return launch_mode<T, MODE_GEGLU, false>(p, batch, tile_cfg, st);
+        case MODE_QKV_VT: return launch_mode<T, MODE_QKV_VT, false>(p, batch, tile_cfg, st);
+        case MODE_KV_CACHE: return launch_mode<T, MODE_KV_CACHE, false>(p, batch, tile_cfg, st);
+        default: return VIDI_ERR_ARG;
+    }
+}
+
+int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int tile_cfg, int dtype, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return VIDI_ERR_SHAPE;
+    if (p.K % 64 != 0 || p.N % 32 != 0) return VIDI_ERR_SHAPE;
+    if (mode == MODE_GEGLU && p.N % 64 != 0) return VIDI_ERR_SHAPE;
+    if ((p.ldx % 8) || (p.ldw % 8) || (p.ldy % 4)) return VIDI_ERR_ALIGN;
+    if (((uintptr_t)p.X & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.Y & 7)) return VIDI_ERR_ALIGN;
+    if (dtype == VIDI_DT_BF16) return launch_dtype<BF16>(p, batch, mode, repkv, tile_cfg, st);
+    if (dtype == VIDI_DT_F16) return launch_dtype<F16>(p, batch, mode, repkv, tile_cfg, st);
+    return VIDI_ERR_DTYPE;
+}
+
+int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
+                       int dtype, hipStream_t st) {
+    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0) return VIDI_ERR_SHAPE;
+    if (((uintptr_t)W & 15) || ((uintptr_t)X & 15)) return VIDI_ERR_ALIGN;
+    auto go = [&](auto kern, int rpw) -> int {
+        const int blocks = max(1, min((N + 4 * rpw - 1) / (4 * rpw), 256 * 8));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, (const u16*)X, (const u16*)W, (u16*)Y, M, N, K, ldx, ldw, ldy);
+        return (int)hipGetLastError();
+    };
+    if (dtype == VIDI_DT_BF16) {
+        if (M <= 1) return go(gemv_kernel<BF16, 1, 4>, 4);
+        if (M <= 2) return go(gemv_kernel<BF16, 2, 4>, 4);
+        if (M <= 4) return go(gemv_kernel<BF16, 4, 2>, 2);
+        return go(gemv_kernel<BF16, 8, 2>, 2);
+    } else if (dtype == VIDI_DT_F16) {
+        if (M <= 1) return go(gemv_kernel<F16, 1, 4>, 4);
+        if (M <= 2) return go(gemv_kernel<F16, 2, 4>, 4);
+        if (M <= 4) return go(gemv_kernel<F16, 4, 2>, 2);
+        return go(gemv_kernel<F16, 8, 2>, 2);
+    }
+    return VIDI_ERR_DTYPE;
+}
+
+int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
+                           int ldx, int ldw, int ldy, int act, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0 || (ldx % 4) || (ldw % 4)) return VIDI_ERR_SHAPE;
+    const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, st, X, W, bias, Y, M, N, K, ldx, ldw, ldy, act);
+    return (int)hipGetLastError();
+}

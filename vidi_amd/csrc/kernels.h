@@ -1,0 +1,84 @@
+// Internal interface between the kernel translation units and the C ABI (capi.hip).
+#pragma once
+#include "common.h"
+
+enum { MODE_PLAIN = 0, MODE_GEGLU = 1, MODE_QKV_VT = 2, MODE_KV_CACHE = 3 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
+enum { NORM_GEMMA = 0, NORM_GEMMA_ADD = 1, NORM_MM = 2, NORM_MM_NOW = 3, NORM_LLM = 4, NORM_LAYER = 5 };
+#define EW_IM2COL 0
+#define EW_POOL 1
+#define EW_ADDPOS 2
+#define EW_ADD3 3
+#define EW_EMBED 4
+#define EW_GEGLU_UNPACK 5
+#define EW_SOFTCAP_ARGMAX 6
+#define EW_MEL_T 7
+
+struct GemmParams {
+    const u16* X; const u16* W; const u16* bias; u16* Y; const u16* R;
+    int M, N, K;
+    int ldx, ldw, ldy, ldr;
+    long long bsX, bsY, bsR;      // batch strides (elements); W/bias shared across the batch
+    int act, rmod;
+    int rep_hd, rep_g;            // REPKV: logical k -> physical column (k/(g*hd))*hd + k%hd
+    // MODE_QKV_VT: columns >= vstart go to Vt[b][h][d][seqpad] (key order permuted per 16-slab)
+    int vstart, hd, seq, seqpad, nheads; u16* Vt;
+    // MODE_KV_CACHE: N = 2*kvd; K half -> Kc tiled, V half -> Vrow row-major + Vtc tiled
+    u16* Kc; u16* Vtc; u16* Vrow; int kvd, ntile64, tok0;
+};
+
+struct AttnSelfParams {
+    const u16* QK; const u16* Vt; u16* O;
+    int B, N, Npad, H;
+    int ldqk, koff, ldo;
+    float scale;
+};
+
+struct AttnCrossParams {
+    const u16* Q;            // [tokens_q, ldq]; head (kvh*G+g) at column (kvh*G+g)*HD
+    const u16* Kc; const u16* Vtc; const unsigned char* mask;   // mask: [n_keys] (1 = valid) or null
+    float* Opart; float* ML; // Opart[W][nkv][Rpad][HD], ML[W][nkv][Rpad][2]
+    int R;                   // query rows per kv head = tokens_q * G
+    int Rpad;                // R rounded up to 32
+    int G, nkv, ldq;
+    int ntile64;             // tiles per kv head in the cache
+    int key_start;           // first key (multiple of 64) of this modality's region in the cache
+    int n_keys;              // number of keys in the region
+    float scale, softcap;    // softcap <= 0: disabled
+};
+
+struct AttnMergeParams {
+    const float* Opart; const float* ML; u16* Out; float* OutF32; float* OutML;
+    int W, nkv, R, Rpad, G, ldo;
+    int zero_out;            // 1: sample has no valid key at all -> output zeros (gemma.py:180-192)
+};
+
+struct AttnTextParams {
+    const u16* Q;                 // [B, Lq, nq*HD]  (RoPE already applied)
+    const u16* Kc; const u16* Vc; // [B, Lmax, nkv*HD] text KV cache (RoPE'd keys)
+    const unsigned char* kmask;   // [B, Lmax] 1 = valid key (null: all valid)
+    u16* O;                       // [B, Lq, nq*HD]
+    int B, Lq, Lmax, nq, nkv;
+    int past_len;                 // key index of query row 0
+    int window;                   // <= 0: no sliding window
+    float scale, softcap;
+};
+
+struct NormParams {
+    const u16* X; const u16* Wt; const u16* Bias; const u16* Res; u16* Y; unsigned char* Mask;
+    const float* XF32;       // NORM_MM_NOW only: fp32 input that is first rounded to T (pos-embed path)
+    int rows, H; long long ldx, ldy, ldr;
+    float eps, normalizer; int sample_flag;
+};
+
+int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int tile_cfg, int dtype, hipStream_t st);
+int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int dtype, hipStream_t st);
+int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t st);
+int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
+int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);
+int vidi_attn_merge_dispatch(const AttnMergeParams& p, int HD, int dtype, hipStream_t st);
+int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStream_t st);
+int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int rows, int nq, int nkv, int HD, int dtype, hipStream_t st);
+int vidi_norm_dispatch(const NormParams& p, int mode, int dtype, hipStream_t st);
+int vidi_ew_dispatch(int op, void** a, const long long* i, const float* f, int dtype, hipStream_t st);
+int vidi_sinusoid_dispatch(float* pe, const float* div, int rows, int i0, int l, int N, int d, hipStream_t st);

@@ -1,0 +1,137 @@
+// Row-wise normalisations of the hot path — all HBM-bound: one wave per row, 16-byte loads, the
+// whole row held in registers between the reduction and the write (one read + one write per
+// element).  Algorithmic bytes = rows * H * 2 B * (reads + writes).
+//
+// Reference formulas:
+//   GEMMA   : y = T( x32 * rsqrt(mean(x32^2)+eps) * (1 + w32) )                  TP gemma2:55-63
+//   GEMMA_ADD: y = T( res + T(gemma(x)) )   — `residual + post_norm(x)`          gemma.py:201,237,121
+//   MM      : y = T( w * T( x32 * rsqrt(mean(x32^2)+eps) ) )                     mm_layer/norm.py:9-25
+//   MM_NOW  : y = T( x32 * rsqrt(mean(x32^2)+eps) )   (weight-free rms_norm)     mm_layer/norm.py:9-16
+//   LLMNORM : mask = (sum|x| != 0) & sample_flag ; y = T(T(T(MM(x)) * mask) * normalizer)
+//                                                     multimodal.py:201-206 + gemma.py:353-356
+//   LAYERNORM: y = T( (x32-mean)*rsqrt(var+eps)*w + b )                           nn.LayerNorm
+#include "kernels.h"
+
+
+
+template <typename T, int MODE, int MAXC>
+__global__ __launch_bounds__(256) void norm_kernel(NormParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nchunk = p.H / 8;
+    float x[MAXC][8];
+    float s1 = 0.f, s2 = 0.f, sa = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            if constexpr (MODE == NORM_MM_NOW) {
+                if (p.XF32) {
+                    const float* src = p.XF32 + row * p.ldx + ch * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(src[e]);
+                } else {
+                    unpack8<T>(*(const u32x4*)(p.X + row * p.ldx + ch * 8), x[c]);
+                }
+            } else {
+                unpack8<T>(*(const u32x4*)(p.X + row * p.ldx + ch * 8), x[c]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += x[c][e];
+                s2 += x[c][e] * x[c][e];
+                sa += fabsf(x[c][e]);
+            }
+        }
+    }
+    s2 = wave_sum(s2);
+    float mean = 0.f, rs;
+    if constexpr (MODE == NORM_LAYER) {
+        mean = wave_sum(s1) / p.H;
+        // two-pass variance on the registers (matches torch's numerically stable form)
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + c * 64 < nchunk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v += (x[c][e] - mean) * (x[c][e] - mean);
+        rs = rsqrtf(wave_sum(v) / p.H + p.eps);
+    } else {
+        rs = rsqrtf(s2 / p.H + p.eps);
+    }
+    float maskv = 1.f;
+    if constexpr (MODE == NORM_LLM) {
+        sa = wave_sum(sa);
+        maskv = (sa != 0.f && p.sample_flag) ? 1.f : 0.f;
+        if (lane == 0 && p.Mask) p.Mask[row] = (unsigned char)(maskv != 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float w[8], y[8];
+            if constexpr (MODE != NORM_MM_NOW) unpack8<T>(*(const u32x4*)(p.Wt + ch * 8), w);
+            if constexpr (MODE == NORM_GEMMA || MODE == NORM_GEMMA_ADD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = x[c][e] * rs * (1.0f + w[e]);
+                if constexpr (MODE == NORM_GEMMA_ADD) {
+                    float r[8];
+                    unpack8<T>(*(const u32x4*)(p.Res + row * p.ldr + ch * 8), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = r[e] + rnd<T>(y[e]);
+                }
+            } else if constexpr (MODE == NORM_MM) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = w[e] * rnd<T>(x[c][e] * rs);
+            } else if constexpr (MODE == NORM_MM_NOW) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = x[c][e] * rs;
+            } else if constexpr (MODE == NORM_LLM) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = rnd<T>(rnd<T>(w[e] * rnd<T>(x[c][e] * rs)) * maskv) * p.normalizer;
+            } else {
+                float bb[8];
+                unpack8<T>(*(const u32x4*)(p.Bias + ch * 8), bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (x[c][e] - mean) * rs * w[e] + bb[e];
+            }
+            *(u32x4*)(p.Y + row * p.ldy + ch * 8) = pack8<T>(y);
+        }
+    }
+}
+
+template <typename T, int MODE>
+static int norm_launch(const NormParams& p, hipStream_t st) {
+    const int nchunk = p.H / 8;
+    const int grid = (p.rows + 3) / 4;
+    if (nchunk <= 64) hipLaunchKernelGGL((norm_kernel<T, MODE, 1>), dim3(grid), dim3(256), 0, st, p);
+    else if (nchunk <= 192) hipLaunchKernelGGL((norm_kernel<T, MODE, 3>), dim3(grid), dim3(256), 0, st, p);
+    else if (nchunk <= 512) hipLaunchKernelGGL((norm_kernel<T, MODE, 8>), dim3(grid), dim3(256), 0, st, p);
+    else return VIDI_ERR_SHAPE;
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int norm_mode(const NormParams& p, int mode, hipStream_t st) {
+    switch (mode) {
+        case NORM_GEMMA: return norm_launch<T, NORM_GEMMA>(p, st);
+        case NORM_GEMMA_ADD: return norm_launch<T, NORM_GEMMA_ADD>(p, st);
+        case NORM_MM: return norm_launch<T, NORM_MM>(p, st);
+        case NORM_MM_NOW: return norm_launch<T, NORM_MM_NOW>(p, st);
+        case NORM_LLM: return norm_launch<T, NORM_LLM>(p, st);
+        case NORM_LAYER: return norm_launch<T, NORM_LAYER>(p, st);
+        default: return VIDI_ERR_ARG;
+    }
+}
+
+int vidi_norm_dispatch(const NormParams& p, int mode, int dtype, hipStream_t st) {
+    if (p.rows <= 0 || p.H <= 0 || p.H % 8) return VIDI_ERR_SHAPE;
+    if ((p.ldx % 8 && !p.XF32) || (p.ldy % 8)) return VIDI_ERR_ALIGN;
+    if (mode == NORM_GEMMA_ADD && (!p.Res || p.ldr % 8)) return VIDI_ERR_ARG;
+    if (mode != NORM_MM_NOW && !p.Wt) return VIDI_ERR_ARG;
+    if (mode == NORM_LAYER && !p.Bias) return VIDI_ERR_ARG;
+    if (dtype == VIDI_DT_BF16) return norm_mode<BF16>(p, mode, st);
+    if (dtype == VIDI_DT_F16) return norm_mode<F16>(p, mode, st);
+    return VIDI_ERR_DTYPE;
+}
