@@ -125,7 +125,7 @@ int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, in
 /* ---- row-wise normalisations (see VIDI_NORM_*) ------------------------------------------------ */
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
               void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
-              float eps, float normalizer, int sample_flag, int dtype, void* stream);
+              float eps, float normalizer, const int* sample_flag /* device int, null = 1 */, int dtype, void* stream);
 
 /* ---- data movement / elementwise -------------------------------------------------------------- */
 /* SiglipVisionEmbeddings conv as GEMM input (TP siglip:124-130,178): px:[T,3,S,S] -> A:[T*(S/P)^2,Kpad] */
@@ -145,6 +145,10 @@ int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* 
 int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream);
 /* mel:[C,nmel,L] -> [C,L+2,nmel] zero-padded rows for the conv1-as-GEMM view (TP whisper:566,618) */
 int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, int dtype, void* stream);
+/* y = T(x*s): `embeds * normalizer` for externally supplied embeddings (gemma.py:353-356); n % 8 == 0 */
+int vidi_scale(const void* x, void* y, long long n, float s, int dtype, void* stream);
+/* *flag |= any(x != 0): the per-sample `sum(|x|) != 0` mask (multimodal.py:202,246); caller zeroes flag; x 16-byte aligned */
+int vidi_any_nonzero(const void* x, long long n, int* flag, int dtype, void* stream);
 /* FractionalSinusoidalEmbedding rows i0..i0+rows of l (mm_vision/pos.py:11-26,47-53), fp32 */
 int vidi_sinusoid(float* pe, const float* div_term, int rows, int i0, int l, int N, int d, void* stream);
 

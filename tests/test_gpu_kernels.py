@@ -1,0 +1,407 @@
+"""Per-kernel parity: every C-ABI entry point against the CPU oracle (oracle/vidi_oracle.py) on seeded
+inputs.  Inputs are rounded to the storage dtype first, the oracle then runs in fp32 on those values.
+
+Tolerances (stated per test): a kernel output is one rounding (bf16: 2^-8 rel, fp16: 2^-11 rel) away
+from the fp32 result plus accumulation-order noise, so  atol = 1e-2*rms(ref)-ish, rtol = 2e-2 (bf16) /
+4e-3 (fp16) unless noted.  Integer / index outputs are bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import vidi_oracle as O
+from util import pack_kv_cache, pack_vt, perm_positions, report, seeded, unpack_vt
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def tol(dt, scale=1.0):
+    return (2e-2 * scale, 2e-2) if dt == torch.bfloat16 else (4e-3 * scale, 4e-3)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from vidi_amd import hip as h
+    h.load_library()
+    return h
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM family
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_gemm_plain_tiles(hip, dt, cfg):
+    """asymmetric operands, M/N not multiples of the tile, bias"""
+    M, N, K = 300, 352, 192
+    x = seeded((M, K), 1, dtype=dt); w = seeded((N, K), 2, 0.1, dtype=dt); b = seeded((N,), 3, dtype=dt)
+    ref = F.linear(x.float(), w.float(), b.float())
+    y = hip.gemm(dev(x), dev(w), dev(b), tile_cfg=cfg)
+    report(f"gemm cfg{cfg}", y, ref, *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_gemm_large_k_and_auto(hip, cfg):
+    dt = torch.bfloat16
+    M, N, K = 1000, 1152, 4352
+    x = seeded((M, K), 4, dtype=dt); w = seeded((N, K), 5, 0.02, dtype=dt)
+    ref = x.float() @ w.float().T
+    y = hip.gemm(dev(x), dev(w), None, tile_cfg=cfg)
+    report(f"gemm largeK cfg{cfg}", y, ref, *tol(dt, ref.std().item()))
+    y2 = hip.gemm(dev(x), dev(w), None, tile_cfg=-1)
+    report("gemm auto", y2, ref, *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("act", ["tanh", "erf"])
+def test_gemm_act_residual(hip, dt, act):
+    from vidi_amd import hip as H
+    M, N, K, rmod = 200, 128, 128, 50
+    x = seeded((M, K), 6, dtype=dt); w = seeded((N, K), 7, 0.1, dtype=dt); b = seeded((N,), 8, dtype=dt)
+    r = seeded((rmod, N), 9, dtype=dt)
+    lin = F.linear(x.float(), w.float(), b.float())
+    a = O.gelu_tanh(lin) if act == "tanh" else O.gelu_erf(lin)
+    ref = a + r.float().repeat(M // rmod, 1)
+    y = hip.gemm(dev(x), dev(w), dev(b), act=H.ACT_GELU_TANH if act == "tanh" else H.ACT_GELU_ERF, residual=dev(r), rmod=rmod)
+    report("gemm act+res", y, ref, *tol(dt, ref.std().item()))
+    # in-place residual (out aliases residual), as the encoder layers use it
+    res = dev(seeded((M, N), 10, dtype=dt))
+    ref2 = lin + res.float().cpu()
+    hip.gemm(dev(x), dev(w), dev(b), res, residual=res)
+    report("gemm inplace residual", res, ref2, *tol(dt, ref2.std().item()))
+
+
+def test_gemm_batched_overlapping_rows(hip):
+    """conv-as-GEMM view: ldx < K (rows overlap), batch strides — the Whisper stem pattern"""
+    dt = torch.bfloat16
+    C, L, nm, Da = 3, 40, 64, 64
+    buf = seeded((C, L + 2, nm), 11, dtype=dt)
+    w = seeded((Da, 3 * nm), 12, 0.1, dtype=dt); b = seeded((Da,), 13, dtype=dt)
+    out = torch.zeros((C, L, Da), dtype=dt).cuda()
+    hip.gemm(dev(buf)[0], dev(w), dev(b), out, M=L, K=3 * nm, ldx=nm, batch=C, bsX=(L + 2) * nm, bsY=L * Da)
+    rows = torch.stack([buf[:, t: t + 3].reshape(C, -1) for t in range(L)], dim=1).float()
+    ref = rows @ w.float().T + b.float()
+    report("gemm batched overlap", out, ref, *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_repkv(hip, dt):
+    nkv, G, hd, H, M = 2, 2, 128, 256, 150
+    v = seeded((M, nkv * hd), 14, dtype=dt); wo = seeded((H, nkv * G * hd), 15, 0.05, dtype=dt)
+    vrep = O.repeat_kv(v.float().view(1, M, nkv, hd).transpose(1, 2), G).transpose(1, 2).reshape(M, -1)
+    ref = vrep @ wo.float().T
+    y = hip.gemm(dev(v), dev(wo), None, repkv=(hd, G), K=G * nkv * hd)
+    report("gemm repkv", y, ref, *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_gemm_geglu(hip, dt, cfg):
+    M, I, K = 200, 256, 128
+    x = seeded((M, K), 16, dtype=dt); g = seeded((I, K), 17, 0.1, dtype=dt); u = seeded((I, K), 18, 0.1, dtype=dt)
+    wgu = torch.stack([g.view(I // 32, 32, K), u.view(I // 32, 32, K)], dim=1).reshape(2 * I, K).contiguous()
+    ref = O.gelu_tanh(x.float() @ g.float().T) * (x.float() @ u.float().T)
+    y = hip.gemm_geglu(dev(x), dev(wgu), tile_cfg=cfg)
+    report("gemm geglu", y, ref, *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("hd,N,nh", [(72, 729, 4), (16, 49, 4), (64, 50, 2)])
+def test_gemm_qkv_vt(hip, hd, N, nh):
+    dt = torch.bfloat16
+    B, Hd = 2, nh * hd
+    K = 64 if Hd <= 64 else 192
+    Npad = (N + 63) // 64 * 64
+    x = seeded((B * N, K), 19, dtype=dt); w = seeded((3 * Hd, K), 20, 0.1, dtype=dt); b = seeded((3 * Hd,), 21, dtype=dt)
+    if (3 * Hd) % 32:
+        pytest.skip("N must be a multiple of 32")
+    ref = F.linear(x.float(), w.float(), b.float())
+    yqk = torch.zeros((B * N, 2 * Hd), dtype=dt).cuda()
+    vt = torch.zeros((B, nh, hd, Npad), dtype=dt).cuda()
+    hip.gemm_qkv_vt(dev(x), dev(w), dev(b), yqk, vt, vstart=2 * Hd, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+    report("qkv_vt QK", yqk, ref[:, : 2 * Hd], *tol(dt, ref.std().item()))
+    v = unpack_vt(vt.cpu(), N).reshape(B * N, Hd)
+    report("qkv_vt V", v, ref[:, 2 * Hd:], *tol(dt, ref.std().item()))
+
+
+def test_gemm_kv_cache(hip):
+    dt = torch.bfloat16
+    nkv, hd, K, M, tok0 = 2, 128, 128, 170, 64
+    kvd = nkv * hd
+    ntile = (tok0 + M + 63) // 64
+    x = seeded((M, K), 22, dtype=dt); w = seeded((2 * kvd, K), 23, 0.1, dtype=dt)
+    ref = x.float() @ w.float().T
+    kc = torch.zeros((nkv, ntile, 64, hd), dtype=dt).cuda(); vtc = torch.zeros((nkv, ntile, hd, 64), dtype=dt).cuda()
+    vrow = torch.zeros((M, kvd), dtype=dt).cuda()
+    hip.gemm_kv_cache(dev(x), dev(w), kc, vtc, vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=tok0)
+    kref, vtref = pack_kv_cache(ref[:, :kvd].view(M, nkv, hd), ref[:, kvd:].view(M, nkv, hd), ntile, tok0)
+    a, r = tol(dt, ref.std().item())
+    report("kv_cache Vrow", vrow, ref[:, kvd:], a, r)
+    report("kv_cache Kc", kc, kref, a, r)
+    report("kv_cache Vtc", vtc, vtref, a, r)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M", [1, 2, 3, 8])
+def test_gemv(hip, dt, M):
+    N, K = 1000, 3584
+    x = seeded((M, K), 24, dtype=dt); w = seeded((N, K), 25, 0.02, dtype=dt)
+    ref = x.float() @ w.float().T
+    y = hip.gemv(dev(x), dev(w))
+    report("gemv", y, ref, *tol(dt, ref.std().item()))
+
+
+def test_gemm_f32(hip):
+    from vidi_amd import hip as H
+    M, N, K = 150, 256, 256
+    x = seeded((M, K), 26); w = seeded((N, K), 27, 0.1); b = seeded((N,), 28)
+    ref = F.gelu(F.linear(x, w, b))
+    y = hip.gemm_f32(dev(x), dev(w), dev(b), H.ACT_GELU_ERF)
+    report("gemm_f32", y, ref, 2e-4, 2e-5)        # exact-fp32 MFMA: fp32 accumulation-order noise only
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("D,N,H,B", [(72, 729, 3, 2), (64, 1500, 2, 1), (16, 49, 4, 3), (16, 50, 4, 2), (32, 130, 2, 2)])
+def test_attn_self(hip, dt, D, N, H, B):
+    """SigLIP (N=729,d=72), Whisper (N=1500,d=64) and tiny shapes; asymmetric q/k/v"""
+    Hd = H * D
+    Npad = (N + 63) // 64 * 64
+    q = seeded((B, N, H, D), 30, dtype=dt); k = seeded((B, N, H, D), 31, dtype=dt); v = seeded((B, N, H, D), 32, dtype=dt)
+    scale = D ** -0.5
+    ref = O.sdpa_reference(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2), scale)
+    ref = ref.transpose(1, 2).reshape(B * N, Hd)
+    qk = torch.cat([q.reshape(B * N, Hd), k.reshape(B * N, Hd)], dim=1).contiguous()
+    vt = pack_vt(v, Npad)
+    out = torch.zeros((B * N, Hd), dtype=dt).cuda()
+    hip.attn_self(dev(qk), dev(vt), out, B=B, N=N, Npad=Npad, H=H, D=D, koff=Hd, scale=scale)
+    report(f"attn_self D{D} N{N}", out, ref, *tol(dt, 0.05))
+
+
+def _cross_ref(q, k, v, mask, scale, softcap, G):
+    """q:[Lq,nq,hd], k,v:[N,nkv,hd], mask:[N] bool -> [Lq,nq*hd] (fp32)"""
+    qh = q.float().permute(1, 0, 2)[None]
+    kh = O.repeat_kv(k.float().permute(1, 0, 2)[None], G)
+    vh = O.repeat_kv(v.float().permute(1, 0, 2)[None], G)
+    add = torch.zeros(k.shape[0]); add[~mask] = float("-inf")
+    o = O.sdpa_reference(qh, kh, vh, scale, softcap, add[None, None, None, :])
+    return o[0].permute(1, 0, 2).reshape(q.shape[0], -1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("HD,nkv,G,Lq,N,start,softcap,masked,zsplit", [
+    (256, 8, 2, 1, 5000, 0, 50.0, False, 8),       # decode, Gemma dims
+    (256, 8, 2, 40, 1000, 128, 50.0, False, 2),    # prefill Lq=40 (3 row tiles), region offset
+    (256, 2, 2, 5, 333, 64, 50.0, True, 3),        # key mask + ragged tail
+    (128, 2, 2, 3, 200, 0, None, True, 1),         # Mistral-style: no softcap, hd=128
+    (256, 2, 2, 2, 17, 0, 50.0, False, 4),         # fewer sub-tiles than waves
+])
+def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
+    nq = nkv * G
+    q = seeded((Lq, nq, HD), 40, dtype=dt); k = seeded((N, nkv, HD), 41, dtype=dt); v = seeded((N, nkv, HD), 42, dtype=dt)
+    mask = torch.ones(N, dtype=torch.bool)
+    if masked:
+        mask[torch.randperm(N, generator=torch.Generator().manual_seed(43))[: N // 3]] = False
+    scale = HD ** -0.5
+    ref = _cross_ref(q, k, v, mask, scale, softcap, G)
+    ntile = (start + N + 63) // 64
+    kc, vtc = pack_kv_cache(k, v, ntile, start)
+    R = Lq * G
+    Rpad = (R + 31) // 32 * 32
+    opart, ml = hip.attn_cross_workspace(zsplit, nkv, Rpad, HD, "cuda")
+    mpad = torch.zeros((N + 63) // 64 * 64, dtype=torch.uint8); mpad[:N] = mask.to(torch.uint8)
+    qd = dev(q.reshape(Lq, nq * HD).contiguous())
+    hip.attn_cross(qd, dev(kc), dev(vtc), dev(mpad) if masked else None, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD,
+                   ntile64=ntile, key_start=start, n_keys=N, scale=scale, softcap=softcap, zsplit=zsplit)
+    out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
+    hip.attn_merge(opart, ml, out, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+    report("attn_cross", out, ref, *tol(dt, 0.05))
+
+
+def test_attn_cross_split_invariance(hip):
+    """property at a BASELINE-scale key count: the merged result does not depend on the KV split"""
+    dt = torch.bfloat16
+    HD, nkv, G, Lq, N = 256, 8, 2, 1, 90000
+    nq = nkv * G
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ntile = (N + 63) // 64
+    kc = (torch.randn((nkv, ntile, 64, HD), generator=g, device="cuda")).to(dt)
+    vtc = (torch.randn((nkv, ntile, HD, 64), generator=g, device="cuda")).to(dt)
+    q = torch.randn((Lq, nq * HD), generator=g, device="cuda").to(dt)
+    outs = []
+    for zs in (4, 32):
+        opart, ml = hip.attn_cross_workspace(zs, nkv, 32, HD, "cuda")
+        hip.attn_cross(q, kc, vtc, None, opart, ml, R=Lq * G, Rpad=32, G=G, nkv=nkv, HD=HD, ntile64=ntile, key_start=0,
+                       n_keys=N, scale=HD ** -0.5, softcap=50.0, zsplit=zs)
+        o = torch.zeros((Lq, nq * HD), dtype=torch.float32, device="cuda")
+        hip.attn_merge(opart, ml, None, W=4 * zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD, out_f32=o, dtype=0)
+        outs.append(o)
+    report("split invariance", outs[0], outs[1], 2e-4, 1e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("HD", [256, 64])
+def test_rope_and_attn_text(hip, dt, HD):
+    B, Lq, past, nq, nkv, W = 2, 5, 9, 4, 2, 6
+    Lmax = 32
+    G = nq // nkv
+    q = seeded((B, Lq, nq, HD), 50, dtype=dt); kn = seeded((B, Lq, nkv, HD), 51, dtype=dt)
+    kc = seeded((B, Lmax, nkv, HD), 52, dtype=dt); vc = seeded((B, Lmax, nkv, HD), 53, dtype=dt)
+    pos = torch.arange(past, past + Lq)[None].repeat(B, 1)
+    cos, sin = O.rope_cos_sin(pos, HD, 10000.0, dt)
+    qr, kr = O.apply_rope(q.float().transpose(1, 2), kn.float().transpose(1, 2), cos.float(), sin.float())
+    qd = dev(q.reshape(B * Lq, nq * HD).clone()); kd = dev(kn.reshape(B * Lq, nkv * HD).clone())
+    hip.rope(qd, kd, dev(cos.reshape(B * Lq, HD).contiguous()), dev(sin.reshape(B * Lq, HD).contiguous()), rows=B * Lq, nq=nq, nkv=nkv, HD=HD)
+    a, r = tol(dt, 1.0)
+    report("rope q", qd, qr.transpose(1, 2).reshape(B * Lq, -1), a, r)
+    report("rope k", kd, kr.transpose(1, 2).reshape(B * Lq, -1), a, r)
+    # attention over the cache (keys 0..past+i), right-padding mask on row 1, sliding window W
+    kmask = torch.ones((B, Lmax), dtype=torch.uint8); kmask[1, 3:6] = 0
+    for window in (0, W):
+        kk = kc.float().transpose(1, 2)[:, :, : past + Lq]; vv = vc.float().transpose(1, 2)[:, :, : past + Lq]
+        qi = torch.arange(past, past + Lq)[:, None]; kj = torch.arange(past + Lq)[None, :]
+        allowed = kj <= qi
+        if window:
+            allowed = allowed & (kj >= qi - window)
+        allowed = allowed[None, None] & kmask[:, None, None, : past + Lq].bool()
+        add = torch.zeros(allowed.shape); add[~allowed] = float("-inf")
+        ref = O.sdpa_reference(q.float().transpose(1, 2), O.repeat_kv(kk, G), O.repeat_kv(vv, G), HD ** -0.5, 50.0, add)
+        ref = ref.transpose(1, 2).reshape(B * Lq, nq * HD)
+        out = torch.zeros((B * Lq, nq * HD), dtype=dt).cuda()
+        hip.attn_text(dev(q.reshape(B * Lq, nq * HD).contiguous()), dev(kc.reshape(B, Lmax, -1).contiguous()),
+                      dev(vc.reshape(B, Lmax, -1).contiguous()), dev(kmask), out, B=B, Lq=Lq, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD,
+                      past_len=past, window=window, scale=HD ** -0.5, softcap=50.0)
+        report(f"attn_text window={window}", out, ref, *tol(dt, 0.3))
+
+
+# ---------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H", [64, 1152, 3584])
+def test_norms(hip, dt, H):
+    from vidi_amd import hip as Hh
+    rows = 37
+    x = seeded((rows, H), 60, 2.0, dtype=dt); w = seeded((H,), 61, 0.2, dtype=dt); b = seeded((H,), 62, 0.2, dtype=dt)
+    res = seeded((rows, H), 63, dtype=dt)
+    a, r = tol(dt, 1.0)
+    report("gemma", hip.norm(Hh.NORM_GEMMA, dev(x), dev(w), eps=1e-6), O.gemma_rmsnorm(x.float(), w.float(), 1e-6), a, r)
+    report("gemma_add", hip.norm(Hh.NORM_GEMMA_ADD, dev(x), dev(w), eps=1e-6, residual=dev(res)),
+           res.float() + O.gemma_rmsnorm(x.float(), w.float(), 1e-6), a, r)
+    report("mm", hip.norm(Hh.NORM_MM, dev(x), dev(w), eps=1e-5), O.mm_RMSNorm(x.float(), w.float()), a, r)
+    report("mm_now", hip.norm(Hh.NORM_MM_NOW, dev(x), None, eps=1e-5), O.mm_rms_norm(x.float()), a, r)
+    xf = seeded((rows, H), 64, 3.0)
+    report("mm_now f32 in", hip.norm(Hh.NORM_MM_NOW, None, None, eps=1e-5, x_f32=dev(xf), dtype=dt), O.mm_rms_norm(xf.to(dt).float()), a, r)
+    report("layer", hip.norm(Hh.NORM_LAYER, dev(x), dev(w), eps=1e-6, bias=dev(b)), O.layer_norm(x.float(), w.float(), b.float(), 1e-6), a, r)
+    # LLM norm: mask derivation is bit-exact (zero rows -> mask 0), features scaled by the normalizer
+    x2 = x.clone(); x2[5] = 0; x2[11] = 0
+    mask = torch.zeros(rows, dtype=torch.uint8).cuda()
+    flag = torch.ones(1, dtype=torch.int32).cuda()
+    nz = float(torch.tensor(H ** 0.5, dtype=dt).float())
+    y = hip.norm(Hh.NORM_LLM, dev(x2), dev(w), eps=1e-5, mask_out=mask, sample_flag=flag, normalizer=nz)
+    mref = x2.float().abs().sum(-1) != 0
+    assert torch.equal(mask.cpu().bool(), mref)
+    ref = O.mm_RMSNorm(x2.float(), w.float()) * mref[:, None] * nz
+    report("llm", y, ref, a * nz, r)
+    flag.zero_()
+    hip.norm(Hh.NORM_LLM, dev(x2), dev(w), eps=1e-5, mask_out=mask, sample_flag=flag, normalizer=nz)
+    assert int(mask.sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# data movement / elementwise
+# ---------------------------------------------------------------------------------------------
+def test_im2col_matches_conv(hip):
+    dt = torch.bfloat16
+    T, S, P, Hv = 3, 98, 14, 32
+    px = seeded((T, 3, S, S), 70, dtype=dt); w = seeded((Hv, 3, P, P), 71, 0.05, dtype=dt)
+    kp = 640
+    A = torch.zeros((T * 49, kp), dtype=dt).cuda()
+    hip.im2col_patch(dev(px), A, T=T, S=S, P=P, Kpad=kp)
+    ref = F.conv2d(px.float(), w.float(), stride=P).flatten(2).transpose(1, 2).reshape(T * 49, Hv)
+    got = A.float().cpu()[:, : 3 * P * P] @ w.float().reshape(Hv, -1).T
+    report("im2col", got, ref, 1e-4, 1e-4)                     # pure data movement: exact up to fp32 sum order
+    assert float(A[:, 3 * P * P:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("side,hw", [(27, (28, 28)), (27, (10, 10)), (27, (26, 26)), (7, (28, 28)), (7, (10, 10))])
+def test_pool_s2d(hip, dt, side, hw):
+    T, C, m = 3, 16, 2
+    f = seeded((T, side * side, C), 72, dtype=dt)
+    x = f.float().reshape(T, side, side, C).permute(0, 3, 1, 2)
+    ref = O.conv2d_pool(x, hw, m).permute(0, 2, 3, 1)
+    resize = hw[0] != 28
+    h, w = hw if resize else (side + 1, side + 1)
+    out = torch.zeros((T, h // m, w // m, C * m * m), dtype=dt).cuda()
+    hip.pool_s2d(dev(f), out, T=T, side=side, C=C, h=h, w=w, m=m, resize=resize)
+    report("pool_s2d", out, ref, *tol(dt, 1.0))
+
+
+def test_elementwise_misc(hip):
+    dt = torch.bfloat16
+    T, oh, ow, H = 3, 4, 5, 64
+    f = seeded((T, oh, ow, H), 73, dtype=dt); ph = seeded((oh, H), 74, dtype=dt); pw = seeded((ow, H), 75, dtype=dt); pt = seeded((T, H), 76, dtype=dt)
+    ref = ((f + ph[None, :, None, :]) + pw[None, None, :, :]) + pt[:, None, None, :]      # bf16 eager = same rounding chain
+    fd = dev(f.clone())
+    hip.add_pos(fd, dev(ph), dev(pw), dev(pt), T=T, oh=oh, ow=ow, H=H)
+    assert torch.equal(fd.cpu(), ref), "add_pos must reproduce the eager rounding chain bit-exactly"
+    a, b, c = seeded((40, H), 77, dtype=dt), seeded((40, H), 78, dtype=dt), seeded((40, H), 79, dtype=dt)
+    out = torch.zeros((40, H), dtype=dt).cuda()
+    hip.add3(dev(a), dev(b), dev(c), out)
+    assert torch.equal(out.cpu(), (a + b) + c)
+    # embed gather * normalizer; negative id -> zero row
+    E = seeded((50, H), 80, dtype=dt); ids = torch.tensor([3, 49, -200, 0, 7], dtype=torch.int64)
+    nz = float(torch.tensor(H ** 0.5, dtype=dt).float())
+    eo = torch.zeros((5, H), dtype=dt).cuda()
+    hip.embed(dev(ids), dev(E), eo, normalizer=nz)
+    ref = E[ids.clamp(min=0)] * torch.tensor(H ** 0.5, dtype=dt); ref[2] = 0
+    assert torch.equal(eo.cpu(), ref)
+    # geglu unpack
+    M, I = 3, 64
+    yp = seeded((M, 2 * I), 81, dtype=dt)
+    g = yp.view(M, I // 32, 2, 32)[:, :, 0].reshape(M, I); u = yp.view(M, I // 32, 2, 32)[:, :, 1].reshape(M, I)
+    go = torch.zeros((M, I), dtype=dt).cuda()
+    hip.geglu_unpack(dev(yp), go)
+    report("geglu_unpack", go, O.gelu_tanh(g.float()) * u.float(), *tol(dt, 1.0))
+    # softcap + argmax (index is bit-exact vs the same rounding chain)
+    lg = seeded((3, 1000), 82, 20.0, dtype=dt)
+    ref = (torch.tanh(lg / 30.0) * 30.0)
+    ld = dev(lg.clone()); idx = torch.zeros(3, dtype=torch.int64).cuda()
+    hip.softcap_argmax(ld, idx, 30.0)
+    report("softcap", ld, ref.float(), *tol(dt, 10.0))
+    assert torch.equal(idx.cpu(), torch.argmax(ld.float().cpu(), dim=-1))
+    # mel transpose/pad
+    mel = seeded((2, 16, 20), 83, dtype=dt)
+    mo = torch.ones((2, 22, 16), dtype=dt).cuda()
+    hip.mel_transpose_pad(dev(mel), mo)
+    refm = F.pad(mel.permute(0, 2, 1), (0, 0, 1, 1))
+    assert torch.equal(mo.cpu(), refm)
+    # scale, any_nonzero
+    so = torch.zeros((40, H), dtype=dt).cuda()
+    hip.scale(dev(a), so, nz)
+    assert torch.equal(so.cpu(), a * torch.tensor(H ** 0.5, dtype=dt))
+    flag = torch.zeros(1, dtype=torch.int32).cuda()
+    z = torch.zeros(1003, dtype=dt).cuda()
+    hip.any_nonzero(z, flag); assert int(flag) == 0
+    z[1001] = 1.0
+    hip.any_nonzero(z, flag); assert int(flag) == 1
+
+
+def test_sinusoid_and_pos_table(hip):
+    l, N, d, i0, rows = 37, 100, 64, 5, 20
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float) * -(math.log(10000.0) / d))
+    pe = torch.zeros((rows, d), dtype=torch.float32).cuda()
+    hip.sinusoid(pe, dev(div), rows=rows, i0=i0, l=l, N=N, d=d)
+    p = torch.arange(l, dtype=torch.float) / (l - 1) * (N - 1)
+    ref = O.fractional_sinusoid(p, d)[i0: i0 + rows]
+    report("sinusoid", pe, ref, 2e-5, 0.0)                     # fp32 sin/cos of identical fp32 arguments

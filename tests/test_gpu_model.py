@@ -1,0 +1,204 @@
+"""Engine-level parity on the GPU: towers, encode pipeline, the D-Attn decoder and greedy generate
+against the fp32 CPU oracle, on seeded synthetic weights (tiny config = every padding path; plus a
+2-layer model with the real Gemma2-9B layer dims).  Tolerances: model dtype is bf16/fp16 with the
+reference's rounding points, the oracle is fp32 => errors accumulate over layers; stated per test."""
+import dataclasses
+
+import pytest
+import torch
+
+import vidi_oracle as O
+from util import report, seeded, unpack_vt, perm_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_cfg(cfg) -> O.OracleConfig:
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    d = {k: v for k, v in cfg.to_dict().items() if k in names}
+    d["vis_select_layer"] = cfg.mm_vision_select_layer
+    return O.OracleConfig(**d)
+
+
+def make(cfg, dtype, seed=3):
+    from vidi_amd.weights import init_random_weights
+    from vidi_amd.engine import VidiEngine
+    w = init_random_weights(cfg, seed=seed, dtype=dtype, device="cpu")
+    w32 = {k: v.float() for k, v in w.items()}
+    eng = VidiEngine(cfg, dict(w), dtype=dtype, device="cuda", free_source=False)
+    return eng, w32
+
+
+@pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def tiny_setup(request):
+    from vidi_amd.config import tiny
+    cfg = tiny()
+    eng, w32 = make(cfg, request.param)
+    return cfg, eng, w32, request.param
+
+
+def tol(dt, k=1.0):
+    return (3e-2 * k, 3e-2) if dt == torch.bfloat16 else (6e-3 * k, 6e-3)
+
+
+def test_siglip_tower(tiny_setup):
+    cfg, eng, w32, dt = tiny_setup
+    T = 5                                                    # > vis_frames_per_chunk: exercises chunking
+    px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 100, 0.5).clamp(-1, 1).to(dt)
+    ref = O.siglip_forward(px.float(), w32, oracle_cfg(cfg))
+    got = eng.siglip_forward(px.cuda())
+    report("siglip", got, ref, *tol(dt, ref.std().item()))
+
+
+def test_whisper_tower(tiny_setup):
+    cfg, eng, w32, dt = tiny_setup
+    C = 3
+    mel = seeded((C, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 101, 0.3).to(dt)
+    ref = O.whisper_encoder_forward(mel.float(), w32, oracle_cfg(cfg))
+    got = eng.whisper_forward(mel.cuda())
+    report("whisper", got, ref, *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("base", [60000, 50])
+def test_encode_video_images(tiny_setup, base):
+    """base=50 forces the token-budget resize branch (multimodal.py:175-180) at tiny size"""
+    cfg, eng, w32, dt = tiny_setup
+    cfg2 = dataclasses.replace(cfg, mm_max_tokens_base=base)
+    eng.cfg = cfg2
+    try:
+        T = 4
+        px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 102, 0.5).clamp(-1, 1).to(dt)
+        px[:, :, :3] = 0
+        ocfg = oracle_cfg(cfg2)
+        feats_ref, mask_ref = O.encode_video_images([px.float()], w32, ocfg)
+        feats, mask = eng.encode_video_images(px.cuda())
+        assert torch.equal(mask.cpu().bool(), mask_ref[0]), "token mask must be bit-exact"
+        report("encode_video_images", feats, feats_ref[0], *tol(dt, feats_ref.std().item()))
+        # frame-axis sharding: two shards with global (offset,total) == the full encode, bit for bit
+        vis = eng.siglip_forward(px.cuda())
+        fa, ma = eng.encode_video_images(px[:2].cuda(), frame_offset=0, total_frames=T, vis_features=vis[:2])
+        fb, mb = eng.encode_video_images(px[2:].cuda(), frame_offset=2, total_frames=T, vis_features=vis[2:])
+        assert torch.equal(torch.cat([fa, fb]).cpu(), feats.cpu()), "frame shards must concatenate to the unsharded result"
+    finally:
+        eng.cfg = cfg
+
+
+def test_encode_video_audios(tiny_setup):
+    cfg, eng, w32, dt = tiny_setup
+    C = 2
+    mel = seeded((C, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 103, 0.3).to(dt)
+    audio_size = 173                                        # mel frames; floors: 86 -> 17 tokens
+    feats_ref, mask_ref = O.encode_video_audios([mel.float()], [audio_size], w32, oracle_cfg(cfg))
+    feats, mask = eng.encode_video_audios(mel.cuda(), audio_size)
+    assert feats.shape[0] == feats_ref.shape[1] == 17
+    assert torch.equal(mask.cpu().bool(), mask_ref[0])
+    report("encode_video_audios", feats, feats_ref[0], *tol(dt, feats_ref.std().item()))
+
+
+def _run_oracle_prefill(w32, ocfg, ids, img, imask, aud, amask):
+    idl, am, pos = O.strip_image_token(ids)
+    emb = O.embed_text(idl, am, w32)
+    caches = O.OracleCaches()
+    hidden = O.model_forward(emb, pos, am, img, imask, aud, amask, w32, ocfg, caches, 0)
+    return hidden, caches, am
+
+
+def test_decoder_prefill_and_caches(tiny_setup):
+    """D-Attn decoder: mm stream caches of every layer + text hidden states after prefill"""
+    cfg, eng, w32, dt = tiny_setup
+    ocfg = oracle_cfg(cfg)
+    H = cfg.hidden_size
+    Nv, Na = 70, 21                                          # not multiples of 32/64
+    img = (seeded((1, Nv, H), 104, cfg.mm_std)).to(dt); aud = (seeded((1, Na, H), 105, cfg.mm_std)).to(dt)
+    img[0, 7] = 0                                             # a masked token
+    imask = torch.ones((1, Nv), dtype=torch.bool); imask[0, 7] = False
+    amask = torch.ones((1, Na), dtype=torch.bool)
+    ids = torch.tensor([[2, 11, 12, -200, 13, 14, 15, 16, 17]], dtype=torch.int64)
+    href, caches, am = _run_oracle_prefill(w32, ocfg, ids, img.float(), imask, aud.float(), amask)
+
+    from vidi_amd.model import strip_image_token
+    mm = eng.mm_stream_prefill(img[0].cuda(), imask[0].to(torch.uint8).cuda(), aud[0].cuda(), amask[0].to(torch.uint8).cuda(),
+                               pre_normalized=False)
+    assert mm.img_mask is not None and mm.aud_mask is None
+    nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+    for li in range(cfg.num_hidden_layers):
+        kref, vref = caches.image[li]
+        kc = mm.kc[li].reshape(nkv, -1, hd)[:, :Nv].permute(1, 0, 2).reshape(Nv, -1)
+        report(f"image K cache L{li}", kc, kref[0], *tol(dt, kref.std().item()))
+        pos = torch.from_numpy(perm_positions(64))
+        vt = mm.vtc[li].cpu()[:, :, :, pos]                   # undo perm16 inside each 64-tile
+        v = vt.permute(1, 3, 0, 2).reshape(-1, nkv * hd)[:Nv]
+        report(f"image V cache L{li}", v, vref[0], *tol(dt, vref.std().item()))
+        karef, _ = caches.audio[li]
+        ka = mm.kc[li].reshape(nkv, -1, hd)[:, mm.aud_start: mm.aud_start + Na].permute(1, 0, 2).reshape(Na, -1)
+        report(f"audio K cache L{li}", ka, karef[0], *tol(dt, karef.std().item()))
+    idt, mask, pos_ids = strip_image_token(ids)
+    ts = eng.new_text_state(1, 16)
+    emb = eng.embed_tokens(idt.cuda())
+    hn = eng.text_forward(emb, pos_ids.reshape(-1).cuda(), ts, mm, Lq=idt.shape[1], new_mask=mask.cuda())
+    report("text hidden (prefill)", hn, href[0], *tol(dt, href.std().item()))
+
+
+def test_generate_matches_oracle(tiny_setup):
+    """end-to-end: video + audio + prompt -> greedy tokens.  Token ids must equal the oracle's wherever
+    the oracle's top-2 logit margin exceeds the numeric tolerance; prefill logits within tolerance."""
+    cfg, eng, w32, dt = tiny_setup
+    from vidi_amd.model import VidiForCausalLM
+    ocfg = oracle_cfg(cfg)
+    T, C = 3, 1
+    px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 106, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((C, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 107, 0.3).to(dt)
+    ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26]], dtype=torch.int64)
+    n_new = 6
+    ref_ids, dbg = O.generate_greedy(ids, [px.float()], [mel.float()], [100], w32, ocfg, n_new, return_debug=True)
+    model = VidiForCausalLM.__new__(VidiForCausalLM)
+    model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
+    from types import SimpleNamespace
+    model.generation_config = SimpleNamespace(eos_token_id=cfg.eos_token_id, pad_token_id=0)
+    model.model = None
+    out = model.forward(ids, images=px[None].cuda(), audios=mel[None].cuda(), audio_sizes=[100], logits_to_keep=1)
+    ref_logits = dbg["prefill_logits"]
+    atol, rtol = tol(dt, ref_logits.std().item())
+    report("prefill logits", out.logits[:, -1], ref_logits, 3 * atol, rtol)
+    got = model.generate(ids, images=px[None].cuda(), audios=mel[None].cuda(), audio_sizes=[100], max_new_tokens=n_new,
+                         do_sample=False, use_cache=True).cpu()
+    # compare token by token until the first low-margin step
+    top2 = torch.topk(ref_logits[0].float(), 2).values
+    if float(top2[0] - top2[1]) > 6 * atol:
+        assert int(got[0, 0]) == int(ref_ids[0, 0]), f"first token {int(got[0,0])} != oracle {int(ref_ids[0,0])}"
+    assert got.shape[1] <= n_new and got.dtype == torch.int64
+
+
+def test_real_dims_two_layers():
+    """Gemma2-9B layer dims (H=3584, 16/8 heads x 256, I=14336), 2 layers, tiny towers: mm stream + text"""
+    from vidi_amd.config import tiny
+    dt = torch.bfloat16
+    cfg = tiny(hidden_size=3584, intermediate_size=14336, num_attention_heads=16, num_key_value_heads=8, head_dim=256,
+               query_pre_attn_scalar=256.0, sliding_window=4096, num_hidden_layers=2, vocab_size=1024)
+    eng, w32 = make(cfg, dt, seed=5)
+    ocfg = oracle_cfg(cfg)
+    H = cfg.hidden_size
+    Nv, Na = 300, 40
+    img = seeded((1, Nv, H), 108, cfg.mm_std).to(dt); aud = seeded((1, Na, H), 109, cfg.mm_std).to(dt)
+    imask = torch.ones((1, Nv), dtype=torch.bool); amask = torch.ones((1, Na), dtype=torch.bool)
+    ids = torch.tensor([[2, 31, -200, 32, 33, 34, 35, 36, 37, 38, 39]], dtype=torch.int64)
+    href, caches, am = _run_oracle_prefill(w32, ocfg, ids, img.float(), imask, aud.float(), amask)
+    mm = eng.mm_stream_prefill(img[0].cuda(), imask[0].to(torch.uint8).cuda(), aud[0].cuda(), amask[0].to(torch.uint8).cuda(),
+                               pre_normalized=False)
+    nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+    kref, _ = caches.image[1]
+    kc = mm.kc[1].reshape(nkv, -1, hd)[:, :Nv].permute(1, 0, 2).reshape(Nv, -1)
+    report("real-dims image K cache L1", kc, kref[0], 3e-2 * kref.std().item(), 3e-2)
+    from vidi_amd.model import strip_image_token
+    idt, mask, pos_ids = strip_image_token(ids)
+    ts = eng.new_text_state(1, 16)
+    hn = eng.text_forward(eng.embed_tokens(idt.cuda()), pos_ids.reshape(-1).cuda(), ts, mm, Lq=idt.shape[1], new_mask=mask.cuda())
+    report("real-dims text hidden", hn, href[0], 4e-2 * href.std().item(), 4e-2)
+    # one decode step on top (gemv path + cached cross attention)
+    nxt = torch.tensor([41], dtype=torch.int64)
+    e = torch.nn.functional.embedding(nxt[:, None], w32["model.embed_tokens.weight"])
+    tm = torch.cat([am, torch.ones(1, 1, dtype=torch.bool)], dim=1)
+    p = torch.tensor([[idt.shape[1]]])
+    href2 = O.model_forward(e, p, tm, img.float(), imask, aud.float(), amask, w32, ocfg, caches, idt.shape[1])
+    hn2 = eng.text_forward(eng.embed_tokens(nxt.cuda()), p.reshape(-1).cuda(), ts, mm, Lq=1)
+    report("real-dims decode hidden", hn2, href2[0], 4e-2 * href2.std().item(), 4e-2)

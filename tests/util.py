@@ -1,0 +1,66 @@
+"""Shared helpers for the parity tests (layout packers mirror the kernels' documented layouts)."""
+import numpy as np
+import torch
+
+
+def perm16(x):
+    return 8 * ((x >> 2) & 1) + (x & 3) + 4 * (x >> 3)
+
+
+def perm_positions(n):
+    """storage position of key k inside a perm16-permuted axis of length n (n % 16 == 0)"""
+    k = np.arange(n)
+    return (k & ~15) | perm16(k & 15)
+
+
+def seeded(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def report(name, got, ref, atol, rtol):
+    """assert closeness with a diagnostic that says WHERE and HOW the mismatch looks."""
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    if not torch.isfinite(got).all():
+        bad = (~torch.isfinite(got)).nonzero()
+        raise AssertionError(f"{name}: {bad.shape[0]} non-finite values, first at {bad[0].tolist()}")
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    nbad = int((err > tol).sum())
+    if nbad:
+        idx = (err - tol).argmax()
+        pos = np.unravel_index(int(idx), got.shape)
+        corr = torch.corrcoef(torch.stack([got.flatten(), ref.flatten()]))[0, 1].item() if got.numel() > 2 else float("nan")
+        raise AssertionError(
+            f"{name}: {nbad}/{got.numel()} outside tol (atol={atol}, rtol={rtol}); max|err|={err.max():.4g} at {pos} "
+            f"got={got[pos]:.5g} ref={ref[pos]:.5g}; ref rms={ref.pow(2).mean().sqrt():.4g}; corr={corr:.4f}")
+    return float(err.max())
+
+
+def pack_vt(v, npad):
+    """v:[B,N,H,D] -> Vt:[B,H,D,npad] with the perm16 key order (what vidi_gemm_qkv_vt writes)."""
+    B, N, H, D = v.shape
+    out = torch.zeros((B, H, D, npad), dtype=v.dtype)
+    pos = torch.from_numpy(perm_positions(npad))[:N]
+    out[:, :, :, pos] = v.permute(0, 2, 3, 1)
+    return out
+
+
+def unpack_vt(vt, n):
+    pos = torch.from_numpy(perm_positions(vt.shape[-1]))[:n]
+    return vt[:, :, :, pos].permute(0, 3, 1, 2)          # [B,N,H,D]
+
+
+def pack_kv_cache(k, v, ntile64, tok0=0):
+    """k,v:[N,nkv,hd] -> Kc[nkv,ntile,64,hd], Vtc[nkv,ntile,hd,64(perm16)]."""
+    N, nkv, hd = k.shape
+    kc = torch.zeros((nkv, ntile64 * 64, hd), dtype=k.dtype)
+    vt = torch.zeros((nkv, ntile64, hd, 64), dtype=v.dtype)
+    kc[:, tok0: tok0 + N] = k.permute(1, 0, 2)
+    tok = np.arange(tok0, tok0 + N)
+    tile = torch.from_numpy(tok >> 6)
+    pos = torch.from_numpy(perm_positions(64)[tok & 63])
+    vt[:, tile, :, pos] = v            # advanced indices (tile,pos) separated by a slice -> result [N,nkv,hd]
+    return kc.view(nkv, ntile64, 64, hd), vt

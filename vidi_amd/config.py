@@ -1,0 +1,118 @@
+"""Model configuration for the MI355X Vidi path.
+
+Field names follow the reference's `DattnGemma2Config` (Vidi1.5_9B/vidi/model/lmm/dattn/gemma.py:427-448)
+plus the HF tower configs it pulls in (SigLIP / Whisper).  Real checkpoints provide these through
+`config.json`; nothing in the kernels hard-codes them."""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import asdict, dataclass, fields
+from typing import Optional
+
+
+@dataclass
+class VidiConfig:
+    model_type: str = "dattn_gemma2"
+    # ---- LLM (Gemma2) ----
+    hidden_size: int = 3584
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 42
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 256
+    query_pre_attn_scalar: float = 256.0
+    attn_logit_softcapping: Optional[float] = 50.0
+    final_logit_softcapping: Optional[float] = 30.0
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 10000.0
+    sliding_window: int = 4096
+    vocab_size: int = 256000
+    eos_token_id: int = 107
+    pad_token_id: int = 0
+    bos_token_id: int = 2
+    tie_word_embeddings: bool = True
+    # ---- multimodal glue (mm_* keys of the reference config) ----
+    mm_input_type: str = "video"
+    mm_projector_type: str = "mlp2x_gelu"
+    mm_image_aspect_ratio: str = "resize"
+    mm_image_pool_size: int = 2
+    mm_audio_pool_size: int = 5
+    mm_std: float = 0.02898
+    mm_time_interval: int = 10000
+    mm_splits: int = 1                      # activation-chunking knob of the reference; results are chunk-invariant
+    mm_max_tokens_base: int = 60000         # literal at multimodal.py:176
+    mm_vision_tower: str = "google/siglip2-so400m-patch14-384"
+    mm_audio_tower: str = "openai/whisper-large-v3"
+    mm_vision_select_layer: int = -2
+    # ---- vision tower ----
+    vis_image_size: int = 384
+    vis_patch_size: int = 14
+    vis_hidden_size: int = 1152
+    vis_intermediate_size: int = 4304
+    vis_num_layers: int = 27
+    vis_num_heads: int = 16
+    vis_ln_eps: float = 1e-6
+    # ---- audio tower ----
+    aud_num_mel_bins: int = 128
+    aud_d_model: int = 1280
+    aud_num_layers: int = 32
+    aud_num_heads: int = 20
+    aud_ffn_dim: int = 5120
+    aud_max_source_positions: int = 1500
+    aud_nb_max_frames: int = 3000
+    aud_ln_eps: float = 1e-5
+    aud_sampling_rate: int = 16000
+    aud_hop_length: int = 160
+    # ---- engine knobs (ours) ----
+    vis_frames_per_chunk: int = 96          # SigLIP activation chunk (frames)
+    aud_chunks_per_batch: int = 16          # Whisper activation chunk (30-s windows)
+
+    @property
+    def vis_side(self) -> int:
+        return self.vis_image_size // self.vis_patch_size
+
+    @property
+    def vis_select_layers(self) -> int:
+        """number of encoder layers actually needed for hidden_states[select_layer]"""
+        return self.mm_vision_select_layer % (self.vis_num_layers + 1)
+
+    def to_dict(self):
+        return asdict(self)
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "VidiConfig":
+        known = {f.name for f in fields(cls)}
+        return cls(**{k: v for k, v in d.items() if k in known})
+
+    @classmethod
+    def from_pretrained(cls, path: str) -> "VidiConfig":
+        with open(os.path.join(path, "config.json")) as f:
+            return cls.from_dict(json.load(f))
+
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=1)
+
+
+def vidi15_9b() -> VidiConfig:
+    """External dims of Vidi1.5-9B: google/gemma-2-9b + siglip2-so400m-patch14-384 + whisper-large-v3
+    (Vidi1.5_9B/scripts/finetune.sh:18,22,25)."""
+    return VidiConfig()
+
+
+def tiny(**over) -> VidiConfig:
+    """Small config exercising every padding path (odd patch grid, tower head_dim 16, fc1 pad 176->192, GQA 4/2)."""
+    cfg = VidiConfig(
+        hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+        head_dim=128, query_pre_attn_scalar=128.0, sliding_window=16, vocab_size=512, eos_token_id=7,
+        mm_time_interval=100, mm_max_tokens_base=60000,
+        vis_image_size=98, vis_patch_size=14, vis_hidden_size=64, vis_intermediate_size=176, vis_num_layers=3, vis_num_heads=4,
+        aud_num_mel_bins=64, aud_d_model=64, aud_num_layers=2, aud_num_heads=4, aud_ffn_dim=128,
+        aud_max_source_positions=50, aud_nb_max_frames=100,
+        vis_frames_per_chunk=4, aud_chunks_per_batch=2,
+    )
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg

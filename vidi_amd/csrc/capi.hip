@@ -131,7 +131,7 @@ int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, in
 
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
               void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
-              float eps, float normalizer, int sample_flag, int dtype, void* stream) {
+              float eps, float normalizer, const int* sample_flag, int dtype, void* stream) {
     if ((!X && !XF32) || !Y) return VIDI_ERR_ARG;
     NormParams p;
     p.X = (const u16*)X; p.XF32 = XF32; p.Wt = (const u16*)W; p.Bias = (const u16*)Bias; p.Res = (const u16*)Res;
@@ -197,6 +197,21 @@ int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, i
     void* a[2] = {(void*)mel, out};
     const long long i[3] = {C, nmel, L};
     return vidi_ew_dispatch(EW_MEL_T, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_scale(const void* x, void* y, long long n, float s, int dtype, void* stream) {
+    if (!x || !y) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)x, y};
+    const long long i[1] = {n};
+    const float f[1] = {s};
+    return vidi_ew_dispatch(EW_SCALE, a, i, f, dtype, (hipStream_t)stream);
+}
+
+int vidi_any_nonzero(const void* x, long long n, int* flag, int dtype, void* stream) {
+    if (!x || !flag) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)x, (void*)flag};
+    const long long i[1] = {n};
+    return vidi_ew_dispatch(EW_ANY_NONZERO, a, i, nullptr, dtype, (hipStream_t)stream);
 }
 
 int vidi_sinusoid(float* pe, const float* div_term, int rows, int i0, int l, int N, int d, void* stream) {

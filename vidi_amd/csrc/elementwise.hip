@@ -203,6 +203,32 @@ __global__ void mel_transpose_pad_kernel(const u16* __restrict__ mel, u16* __res
     }
 }
 
+// ---- y = T(x * s) — `embeds * normalizer` (gemma.py:353-356) for externally supplied embeddings ---
+template <typename T>
+__global__ void scale_kernel(const u16* x, u16* y, size_t n8, float s) {
+    GRID_STRIDE(idx, n8) {
+        float v[8];
+        unpack8<T>(*(const u32x4*)(x + idx * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= s;
+        *(u32x4*)(y + idx * 8) = pack8<T>(v);
+    }
+}
+
+// ---- flag |= any(x != 0) — `torch.sum(torch.abs(x)) != 0` sample mask (multimodal.py:202,246) -----
+__global__ void any_nonzero_kernel(const u16* x, size_t n8, size_t n, int* flag) {
+    int found = 0;
+    if (blockIdx.x == 0 && threadIdx.x < (n - n8 * 8)) found |= (x[n8 * 8 + threadIdx.x] & 0x7fffu) != 0;   // tail
+    GRID_STRIDE(idx, n8) {
+        const u32x4 v = *(const u32x4*)(x + idx * 8);
+        // +0 and -0 both count as zero
+        found |= ((v[0] | v[1] | v[2] | v[3]) & 0x7fff7fffu) != 0;
+    }
+    if (__any(found)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    }
+}
+
 // ---- FractionalSinusoidalEmbedding — mm_vision/pos.py:11-26,47-53 (fp32) -------------------------
 //   p = i/(l-1)*(N-1) ; pe[i][2j] = sin(p*div[j]) ; pe[i][2j+1] = cos(p*div[j]); i = i0 + local row
 __global__ void sinusoid_kernel(float* __restrict__ pe, const float* __restrict__ div, int rows, int i0, int l, int N, int d) {
@@ -273,6 +299,17 @@ static int ew_dispatch_T(int op, void** a, const long long* i, const float* f, h
             const size_t total = (size_t)i[0] * (i[2] + 2) * i[1];
             hipLaunchKernelGGL(mel_transpose_pad_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const u16*)a[0], (u16*)a[1],
                                (int)i[0], (int)i[1], (int)i[2]);
+            break;
+        }
+        case EW_SCALE: {
+            if (i[0] % 8) return VIDI_ERR_SHAPE;
+            const size_t n8 = (size_t)i[0] / 8;
+            hipLaunchKernelGGL(scale_kernel<T>, dim3(grid_for(n8)), dim3(256), 0, st, (const u16*)a[0], (u16*)a[1], n8, f[0]);
+            break;
+        }
+        case EW_ANY_NONZERO: {
+            const size_t n8 = (size_t)i[0] / 8;
+            hipLaunchKernelGGL(any_nonzero_kernel, dim3(grid_for(n8 ? n8 : 1)), dim3(256), 0, st, (const u16*)a[0], n8, (size_t)i[0], (int*)a[1]);
             break;
         }
         default: return VIDI_ERR_ARG;

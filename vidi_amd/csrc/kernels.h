@@ -13,6 +13,8 @@ enum { NORM_GEMMA = 0, NORM_GEMMA_ADD = 1, NORM_MM = 2, NORM_MM_NOW = 3, NORM_LL
 #define EW_GEGLU_UNPACK 5
 #define EW_SOFTCAP_ARGMAX 6
 #define EW_MEL_T 7
+#define EW_SCALE 8
+#define EW_ANY_NONZERO 9
 
 struct GemmParams {
     const u16* X; const u16* W; const u16* bias; u16* Y; const u16* R;
@@ -68,7 +70,7 @@ struct NormParams {
     const u16* X; const u16* Wt; const u16* Bias; const u16* Res; u16* Y; unsigned char* Mask;
     const float* XF32;       // NORM_MM_NOW only: fp32 input that is first rounded to T (pos-embed path)
     int rows, H; long long ldx, ldy, ldr;
-    float eps, normalizer; int sample_flag;
+    float eps, normalizer; const int* sample_flag;   // device flag (null = 1)
 };
 
 int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int tile_cfg, int dtype, hipStream_t st);

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void norm_kernel(NormParams p) {
     float maskv = 1.f;
     if constexpr (MODE == NORM_LLM) {
         sa = wave_sum(sa);
-        maskv = (sa != 0.f && p.sample_flag) ? 1.f : 0.f;
+        const int sflag = p.sample_flag ? *p.sample_flag : 1;
+        maskv = (sa != 0.f && sflag) ? 1.f : 0.f;
         if (lane == 0 && p.Mask) p.Mask[row] = (unsigned char)(maskv != 0.f);
     }
 #pragma unroll

@@ -1,0 +1,571 @@
+"""VidiEngine — host orchestration of the HIP kernels for the Vidi1.5 (Gemma2 D-Attn) inference path.
+
+Everything numeric goes through `vidi_amd.hip` (the C ABI); torch is used for device buffers,
+views, copies and index tensors.  The structure follows the reference call stack:
+
+  encode_video_images / encode_video_audios   <- lmm/dattn/multimodal.py:156-252
+  mm_stream_prefill (diagonal V2V/A2A stream)  <- lmm/dattn/gemma.py:183-202 (x42), 59-65 (caches)
+  text_forward (T2T + T2V + T2A)               <- lmm/dattn/gemma.py:160-238, 267-424, 562-569
+
+Design choices that differ from the reference on purpose (results identical):
+  * the multimodal stream is query-independent, so it is run ONCE per video for all layers
+    (`MMState`) and shared by every query/decoding step; the reference interleaves it with the
+    text prefill layer by layer (gemma.py:362-406) and re-multiplies the embeds every step.
+  * K/V of the multimodal tokens are written by the projection GEMM's epilogue directly in the
+    cross-attention kernel's tile layout; `repeat_kv` is never materialised.
+  * layer L-1's stream update (gemma.py:196-202 on the last layer) is dead in the reference and
+    skipped here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+from .config import VidiConfig
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def token_budget_hw(T: int, side: int, pool: int, base: int) -> Tuple[int, int]:
+    """Token-budget rule (multimodal.py:175-180 + vidi/utils.py:152-171), integer/float host math.
+    Returns the `hw` the reference hands to Conv2DPool; (28,28) is its "no resize" sentinel."""
+    n_tokens = T * (side + 1) * (side + 1)
+    max_tokens = base * pool * pool
+    if n_tokens > max_tokens:
+        H = W = side + 1
+        ratio = math.sqrt(max_tokens / (T * H * W))
+        th, tw = int(H * ratio), int(W * ratio)
+        return max(10, th - th % 2), max(10, tw - tw % 2)
+    return 28, 28
+
+
+def audio_token_counts(audio_size: int, cfg: VidiConfig) -> Tuple[int, int]:
+    """floor(size*1500/3000), then floor(/pool) — multimodal.py:226-227, 234-235 (same numpy float64 ops)."""
+    import numpy as np
+    pool_ratio = cfg.aud_max_source_positions / cfg.aud_nb_max_frames
+    s1 = int(np.floor(np.array([audio_size]) * pool_ratio).astype(int)[0])
+    s2 = int(np.floor(np.array([s1]) / cfg.mm_audio_pool_size).astype(int)[0])
+    return s1, s2
+
+
+@dataclass
+class MMState:
+    """Per-video, query-independent state: cross-attention caches for all layers."""
+    n_img: int = 0
+    n_aud: int = 0
+    img_start: int = 0
+    aud_start: int = 0
+    ntile64: int = 0
+    kc: Optional[torch.Tensor] = None        # [L, nkv, ntile64, 64, hd]
+    vtc: Optional[torch.Tensor] = None       # [L, nkv, ntile64, hd, 64]
+    img_mask: Optional[torch.Tensor] = None  # uint8 [>= n_img] or None when every key is valid
+    aud_mask: Optional[torch.Tensor] = None
+    img_any_valid: bool = True
+    aud_any_valid: bool = True
+    # reference-facing views (encode_videos outputs)
+    image_features: Optional[torch.Tensor] = None
+    image_attention_mask: Optional[torch.Tensor] = None
+    audio_features: Optional[torch.Tensor] = None
+    audio_attention_mask: Optional[torch.Tensor] = None
+
+
+@dataclass
+class TextState:
+    """Text KV cache (the reference's HybridCache, gemma.py:308-315) for B rows."""
+    B: int
+    Lmax: int
+    kc: torch.Tensor                         # [L, B, Lmax, nkv*hd]
+    vc: torch.Tensor
+    kmask: torch.Tensor                      # uint8 [B, Lmax]
+    past_len: int = 0
+    n_valid: Optional[torch.Tensor] = None   # int64 [B] number of valid tokens per row
+
+
+class VidiEngine:
+    def __init__(self, cfg: VidiConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
+                 device: str = "cuda", free_source: bool = True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("VidiEngine needs a HIP device: the kernels have no CPU path")
+        hip.load_library()
+        self.cfg = cfg
+        self.dtype = dtype
+        self.dev = torch.device(device)
+        self.normalizer = float(torch.tensor(cfg.hidden_size ** 0.5, dtype=dtype).float())   # gemma.py:353
+        self._pack(weights, free_source)
+        self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._ws: Dict[str, torch.Tensor] = {}
+
+    # -----------------------------------------------------------------------------------------
+    # weight packing (one-time repack into kernel-preferred layouts; owned by this module)
+    # -----------------------------------------------------------------------------------------
+    def _pack(self, w: Dict[str, torch.Tensor], free_source: bool):
+        cfg, dt, dev = self.cfg, self.dtype, self.dev
+
+        def g(name, fp32=False):
+            t = w[name]
+            t = t.to(device=dev, dtype=torch.float32 if fp32 else dt)
+            return t.contiguous()
+
+        def pop(name):
+            if free_source:
+                w.pop(name, None)
+
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        self.embed = g("model.embed_tokens.weight")
+        self.lm_head = self.embed if cfg.tie_word_embeddings or "lm_head.weight" not in w else g("lm_head.weight")
+        self.final_norm = g("model.norm.weight")
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}."
+            L: Dict[str, torch.Tensor] = {}
+            L["wqkv"] = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                   g(p + "self_attn.v_proj.weight")], dim=0).contiguous()
+            nqd = cfg.num_attention_heads * cfg.head_dim
+            L["wkv"] = L["wqkv"][nqd:]                                        # [Wk; Wv] view
+            L["wo"] = g(p + "self_attn.o_proj.weight")
+            gate, up = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
+            # 32-row interleave [gate 0..31 | up 0..31 | gate 32..63 | ...] for the fused GeGLU epilogue
+            L["wgu"] = torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous()
+            del gate, up
+            L["wdown"] = g(p + "mlp.down_proj.weight")
+            for n, k in (("input_layernorm", "ln_in"), ("post_attention_layernorm", "ln_post_attn"),
+                         ("pre_feedforward_layernorm", "ln_pre_ffn"), ("post_feedforward_layernorm", "ln_post_ffn")):
+                L[k] = g(p + n + ".weight")
+            for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
+                      "mlp.up_proj", "mlp.down_proj"):
+                pop(p + n + ".weight")
+            self.layers.append(L)
+
+        # ---- SigLIP ----
+        v = "model.mm_vis.vision_model."
+        Hv, Iv, P = cfg.vis_hidden_size, cfg.vis_intermediate_size, cfg.vis_patch_size
+        Ivp = _round_up(Iv, 64)
+        kp = _round_up(3 * P * P, 64)
+        pw = torch.zeros((Hv, kp), dtype=dt, device=dev)
+        pw[:, : 3 * P * P] = g(v + "embeddings.patch_embedding.weight").reshape(Hv, -1)
+        self.vis = {"patch_w": pw, "patch_b": g(v + "embeddings.patch_embedding.bias"),
+                    "pos": g(v + "embeddings.position_embedding.weight"), "kpad": kp, "ipad": Ivp, "layers": []}
+        for i in range(cfg.vis_select_layers):
+            p = f"{v}encoder.layers.{i}."
+            L = {}
+            L["wqkv"] = torch.cat([g(p + f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], dim=0).contiguous()
+            L["bqkv"] = torch.cat([g(p + f"self_attn.{n}.bias") for n in ("q_proj", "k_proj", "v_proj")], dim=0).contiguous()
+            L["wo"], L["bo"] = g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias")
+            fc1 = torch.zeros((Ivp, Hv), dtype=dt, device=dev); fc1[:Iv] = g(p + "mlp.fc1.weight")
+            b1 = torch.zeros((Ivp,), dtype=dt, device=dev); b1[:Iv] = g(p + "mlp.fc1.bias")
+            fc2 = torch.zeros((Hv, Ivp), dtype=dt, device=dev); fc2[:, :Iv] = g(p + "mlp.fc2.weight")
+            L["fc1"], L["b1"], L["fc2"], L["b2"] = fc1, b1, fc2, g(p + "mlp.fc2.bias")
+            for n, k in (("layer_norm1", "ln1"), ("layer_norm2", "ln2")):
+                L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
+            self.vis["layers"].append(L)
+
+        # ---- Whisper encoder ----
+        a = "model.mm_aud.encoder."
+        Da, nm = cfg.aud_d_model, cfg.aud_num_mel_bins
+        k1 = _round_up(3 * nm, 64)
+        c1 = torch.zeros((Da, k1), dtype=dt, device=dev)
+        c1[:, : 3 * nm] = g(a + "conv1.weight").permute(0, 2, 1).reshape(Da, 3 * nm)      # k = tap*nmel + c
+        c2 = g(a + "conv2.weight").permute(0, 2, 1).reshape(Da, 3 * Da).contiguous()       # k = tap*Da + c
+        self.aud = {"conv1_w": c1, "conv1_b": g(a + "conv1.bias"), "conv2_w": c2, "conv2_b": g(a + "conv2.bias"),
+                    "pos": g(a + "embed_positions.weight"), "lnw": g(a + "layer_norm.weight"), "lnb": g(a + "layer_norm.bias"),
+                    "k1": k1, "layers": []}
+        for i in range(cfg.aud_num_layers):
+            p = f"{a}layers.{i}."
+            L = {}
+            L["wqkv"] = torch.cat([g(p + f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], dim=0).contiguous()
+            L["bqkv"] = torch.cat([g(p + "self_attn.q_proj.bias"), torch.zeros((Da,), dtype=dt, device=dev),
+                                   g(p + "self_attn.v_proj.bias")], dim=0).contiguous()
+            L["wo"], L["bo"] = g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias")
+            L["fc1"], L["b1"], L["fc2"], L["b2"] = g(p + "fc1.weight"), g(p + "fc1.bias"), g(p + "fc2.weight"), g(p + "fc2.bias")
+            for n, k in (("self_attn_layer_norm", "ln1"), ("final_layer_norm", "ln2")):
+                L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
+            self.aud["layers"].append(L)
+
+        # ---- multimodal glue ----
+        m = "model."
+        self.mm = {
+            "img_w0": g(m + "mm_rand_img_projector.model.0.weight"), "img_b0": g(m + "mm_rand_img_projector.model.0.bias"),
+            "img_w2": g(m + "mm_rand_img_projector.model.2.weight"), "img_b2": g(m + "mm_rand_img_projector.model.2.bias"),
+            "aud_pool": g(m + "mm_rand_aud_pool.weight").permute(0, 2, 1).reshape(H, -1).contiguous(),   # k = tap*Da + c
+            "aud_w0": g(m + "mm_rand_aud_projector.model.0.weight"), "aud_b0": g(m + "mm_rand_aud_projector.model.0.bias"),
+            "aud_w2": g(m + "mm_rand_aud_projector.model.2.weight"), "aud_b2": g(m + "mm_rand_aud_projector.model.2.bias"),
+            "img_norm": g(m + "mm_rand_img_norm.weight"), "aud_norm": g(m + "mm_rand_aud_norm.weight"),
+            "llm_norm": g(m + "mm_rand_llm_norm.weight"),
+        }
+        for n in ("h", "w", "t"):
+            for k in ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"):
+                self.mm[f"pos_{n}.{k}"] = g(f"{m}mm_rand_pos_{n}.{k}", fp32=True)
+        d = H
+        self.pos_div = torch.exp(torch.arange(0, d, 2, dtype=torch.float) * -(math.log(10000.0) / d)).to(dev)   # pos.py:15
+
+    # -----------------------------------------------------------------------------------------
+    # small helpers
+    # -----------------------------------------------------------------------------------------
+    def _buf(self, name: str, shape, dtype=None, zero: bool = False) -> torch.Tensor:
+        """Workspace cache keyed by name; reallocated when the shape grows/changes."""
+        dtype = dtype or self.dtype
+        t = self._ws.get(name)
+        n = 1
+        for s in shape:
+            n *= s
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=self.dev)
+            self._ws[name] = t
+        return t[:n].view(*shape)
+
+    def proj(self, x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """bias-free projection: weight-streaming GEMV for M<=8 (decode), MFMA GEMM otherwise."""
+        if x.shape[0] <= 8:
+            return hip.gemv(x, w, out)
+        return hip.gemm(x, w, None, out)
+
+    def pos_table(self, which: str, l: int, N: int, i0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
+        """rms_norm(LearnablePosEmbd(...)) rows [i0, i0+rows) of l — pos.py:41-65, multimodal.py:194-197."""
+        rows = l if rows is None else rows
+        d = self.cfg.hidden_size
+        pe = torch.empty((rows, d), dtype=torch.float32, device=self.dev)
+        hip.sinusoid(pe, self.pos_div, rows=rows, i0=i0, l=l, N=N, d=d)
+        h = hip.gemm_f32(pe, self.mm[f"pos_{which}.mlp.0.weight"], self.mm[f"pos_{which}.mlp.0.bias"], hip.ACT_GELU_ERF)
+        h = hip.gemm_f32(h, self.mm[f"pos_{which}.mlp.2.weight"], self.mm[f"pos_{which}.mlp.2.bias"], hip.ACT_NONE)
+        return hip.norm(hip.NORM_MM_NOW, None, None, eps=1e-5, x_f32=h, dtype=self.dtype)
+
+    # -----------------------------------------------------------------------------------------
+    # SigLIP tower: features = hidden_states[-2]  (mm_vision/siglip.py:29-34)
+    # -----------------------------------------------------------------------------------------
+    def siglip_forward(self, pixel: torch.Tensor) -> torch.Tensor:
+        cfg = self.cfg
+        T = pixel.shape[0]
+        S, P, side = cfg.vis_image_size, cfg.vis_patch_size, cfg.vis_side
+        N, Hv, nh = side * side, cfg.vis_hidden_size, cfg.vis_num_heads
+        hd = Hv // nh
+        Npad = _round_up(N, 64)
+        V = self.vis
+        out = torch.empty((T * N, Hv), dtype=self.dtype, device=self.dev)
+        fc = max(1, cfg.vis_frames_per_chunk)
+        Mmax = min(T, fc) * N
+        A = self._buf("vis_A", (Mmax, V["kpad"]))
+        h = self._buf("vis_h", (Mmax, Hv))
+        yqk = self._buf("vis_qk", (Mmax, 2 * Hv))
+        vt = self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True)
+        ao = self._buf("vis_ao", (Mmax, Hv))
+        f1 = self._buf("vis_f1", (Mmax, V["ipad"]))
+        pixel = pixel.to(self.dtype).contiguous()
+        for c0 in range(0, T, fc):
+            c1 = min(T, c0 + fc)
+            Tc, M = c1 - c0, (c1 - c0) * N
+            x = out[c0 * N: c1 * N]
+            hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
+            hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
+            for L in V["layers"]:
+                hip.norm(hip.NORM_LAYER, x, L["ln1w"], eps=cfg.vis_ln_eps, bias=L["ln1b"], out=h[:M])
+                hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+                hip.attn_self(yqk[:M], vt, ao[:M], B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=hd ** -0.5)
+                hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
+                hip.norm(hip.NORM_LAYER, x, L["ln2w"], eps=cfg.vis_ln_eps, bias=L["ln2b"], out=h[:M])
+                hip.gemm(h[:M], L["fc1"], L["b1"], f1[:M], act=hip.ACT_GELU_TANH)
+                hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
+        return out.view(T, N, Hv)
+
+    # -----------------------------------------------------------------------------------------
+    # encode_video_images — multimodal.py:156-208 (one video; frame shard [f0, f0+T) of T_total)
+    # -----------------------------------------------------------------------------------------
+    def encode_video_images(self, pixel: torch.Tensor, frame_offset: int = 0, total_frames: Optional[int] = None,
+                            normalizer: Optional[float] = None, sample_flag: Optional[torch.Tensor] = None,
+                            vis_features: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        cfg = self.cfg
+        T = pixel.shape[0]
+        Ttot = total_frames if total_frames is not None else T
+        side, pool, Hv, H = cfg.vis_side, cfg.mm_image_pool_size, cfg.vis_hidden_size, cfg.hidden_size
+        f = self.siglip_forward(pixel) if vis_features is None else vis_features
+        hw = token_budget_hw(Ttot, side, pool, cfg.mm_max_tokens_base)                      # global T decides
+        resize = hw[0] != 28
+        h, w = hw if resize else (side + 1, side + 1)
+        oh, ow = h // pool, w // pool
+        C4 = Hv * pool * pool
+        pooled = torch.empty((T * oh * ow, C4), dtype=self.dtype, device=self.dev)
+        hip.pool_s2d(f, pooled, T=T, side=side, C=Hv, h=h, w=w, m=pool, resize=resize)
+        p1 = hip.gemm(pooled, self.mm["img_w0"], self.mm["img_b0"], act=hip.ACT_GELU_ERF)
+        p2 = hip.gemm(p1, self.mm["img_w2"], self.mm["img_b2"])
+        x = hip.norm(hip.NORM_MM, p2, self.mm["img_norm"], eps=1e-5)
+        ph = self.pos_table("h", oh, pool)
+        pw_ = self.pos_table("w", ow, pool)
+        pt = self.pos_table("t", Ttot, cfg.mm_time_interval, i0=frame_offset, rows=T)
+        hip.add_pos(x, ph, pw_, pt, T=T, oh=oh, ow=ow, H=H)
+        if sample_flag is None:
+            sample_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            hip.any_nonzero(pixel.to(self.dtype).contiguous().view(-1), sample_flag)
+        mask = torch.empty((T * oh * ow,), dtype=torch.uint8, device=self.dev)
+        feats = hip.norm(hip.NORM_LLM, x, self.mm["llm_norm"], eps=1e-5, mask_out=mask, sample_flag=sample_flag,
+                         normalizer=1.0 if normalizer is None else normalizer)
+        return feats, mask
+
+    # -----------------------------------------------------------------------------------------
+    # Whisper encoder (mm_audio/whisper.py:26-27; TP whisper/modeling_whisper.py:540-648)
+    # -----------------------------------------------------------------------------------------
+    def whisper_forward(self, mel: torch.Tensor) -> torch.Tensor:
+        cfg, A = self.cfg, self.aud
+        C, nm, Lm = mel.shape
+        Da, nh = cfg.aud_d_model, cfg.aud_num_heads
+        hd = Da // nh
+        N = Lm // 2
+        Npad = _round_up(N, 64)
+        out = torch.empty((C * N, Da), dtype=self.dtype, device=self.dev)
+        cb = max(1, cfg.aud_chunks_per_batch)
+        nb = min(C, cb)
+        # rows 0 and L+1 of every chunk are the conv padding; 4 spare zero rows at the very end absorb the
+        # (zero-weighted) K padding overrun of the last row view
+        melT = self._buf("aud_melT", (nb * (Lm + 2) + 4, nm), zero=True)[: nb * (Lm + 2)].view(nb, Lm + 2, nm)
+        y1 = self._buf("aud_y1", (nb, Lm + 1, Da), zero=True)              # row 0 = left zero pad of conv2
+        y1[:, 0].zero_()
+        h = self._buf("aud_h", (nb * N, Da))
+        yqk = self._buf("aud_qk", (nb * N, 2 * Da))
+        vt = self._buf("aud_vt", (nb, nh, hd, Npad), zero=True)
+        ao = self._buf("aud_ao", (nb * N, Da))
+        f1 = self._buf("aud_f1", (nb * N, cfg.aud_ffn_dim))
+        mel = mel.to(self.dtype).contiguous()
+        for c0 in range(0, C, cb):
+            c1 = min(C, c0 + cb)
+            Cc, M = c1 - c0, (c1 - c0) * N
+            x = out[c0 * N: c1 * N]
+            hip.mel_transpose_pad(mel[c0:c1], melT[:Cc])
+            # conv1 (k3,p1) as a GEMM over overlapping rows of melT; GELU(erf)
+            hip.gemm(melT[0], A["conv1_w"], A["conv1_b"], y1[:Cc, 1:], act=hip.ACT_GELU_ERF, M=Lm, K=A["k1"], ldx=nm,
+                     batch=Cc, bsX=(Lm + 2) * nm, bsY=(Lm + 1) * Da)
+            # conv2 (k3,s2,p1): row t reads y1 rows 2t..2t+2; GELU(erf); + embed_positions
+            hip.gemm(y1[0], A["conv2_w"], A["conv2_b"], x.view(Cc, N, Da), act=hip.ACT_GELU_ERF, residual=A["pos"], rmod=N,
+                     M=N, K=3 * Da, ldx=2 * Da, batch=Cc, bsX=(Lm + 1) * Da, bsY=N * Da, bsR=0)
+            for L in A["layers"]:
+                hip.norm(hip.NORM_LAYER, x, L["ln1w"], eps=cfg.aud_ln_eps, bias=L["ln1b"], out=h[:M])
+                hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+                hip.attn_self(yqk[:M], vt, ao[:M], B=Cc, N=N, Npad=Npad, H=nh, D=hd, koff=Da, scale=hd ** -0.5)
+                hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
+                hip.norm(hip.NORM_LAYER, x, L["ln2w"], eps=cfg.aud_ln_eps, bias=L["ln2b"], out=h[:M])
+                hip.gemm(h[:M], L["fc1"], L["b1"], f1[:M], act=hip.ACT_GELU_ERF)
+                hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
+                if self.dtype == torch.float16:                     # TP whisper:409-411 overflow guard
+                    cv = torch.finfo(torch.float16).max - 1000
+                    x.clamp_(min=-cv, max=cv)
+            hip.norm(hip.NORM_LAYER, x, A["lnw"], eps=cfg.aud_ln_eps, bias=A["lnb"], out=x)
+        return out.view(C, N, Da)
+
+    # -----------------------------------------------------------------------------------------
+    # encode_video_audios — multimodal.py:210-252 (one sample)
+    # -----------------------------------------------------------------------------------------
+    def encode_video_audios(self, mel: torch.Tensor, audio_size: int, normalizer: Optional[float] = None,
+                            aud_features: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        cfg = self.cfg
+        H, Da, pool = cfg.hidden_size, cfg.aud_d_model, cfg.mm_audio_pool_size
+        f = self.whisper_forward(mel) if aud_features is None else aud_features              # [C, 1500, Da]
+        s1, s2 = audio_token_counts(audio_size, cfg)
+        flat = f.reshape(-1, Da)
+        if s2 < 1:
+            raise ValueError("audio shorter than one pooled token")
+        # Conv1d(k=pool, s=pool, no bias) over the first s1 rows == GEMM on a [s2, pool*Da] view
+        pooled = hip.gemm(flat, self.mm["aud_pool"], None, M=s2, K=pool * Da, ldx=pool * Da)
+        p1 = hip.gemm(pooled, self.mm["aud_w0"], self.mm["aud_b0"], act=hip.ACT_GELU_ERF)
+        p2 = hip.gemm(p1, self.mm["aud_w2"], self.mm["aud_b2"])
+        x = hip.norm(hip.NORM_MM, p2, self.mm["aud_norm"], eps=1e-5)
+        if s2 > 1:
+            pt = self.pos_table("t", s2, cfg.mm_time_interval)
+            hip.add_pos(x, None, None, pt, T=s2, oh=1, ow=1, H=H)
+        else:
+            raise ValueError("LearnablePosEmbd requires more than one audio token (pos.py:42)")
+        flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        hip.any_nonzero(mel.to(self.dtype).contiguous().view(-1), flag)
+        mask = torch.empty((s2,), dtype=torch.uint8, device=self.dev)
+        feats = hip.norm(hip.NORM_LLM, x, self.mm["llm_norm"], eps=1e-5, mask_out=mask, sample_flag=flag,
+                         normalizer=1.0 if normalizer is None else normalizer)
+        return feats, mask
+
+    # -----------------------------------------------------------------------------------------
+    # multimodal stream through all layers (diagonal V2V/A2A + cache fill)
+    # -----------------------------------------------------------------------------------------
+    def mm_stream_prefill(self, img: Optional[torch.Tensor], img_mask: Optional[torch.Tensor],
+                          aud: Optional[torch.Tensor], aud_mask: Optional[torch.Tensor],
+                          pre_normalized: bool = True, check_masks: bool = True) -> MMState:
+        """img/aud: [N, H] features (already multiplied by the normalizer when pre_normalized)."""
+        cfg = self.cfg
+        H, nkv, hd, G = cfg.hidden_size, cfg.num_key_value_heads, cfg.head_dim, cfg.num_attention_heads // cfg.num_key_value_heads
+        kvd = nkv * hd
+        n_img = 0 if img is None else img.shape[0]
+        n_aud = 0 if aud is None else aud.shape[0]
+        aud_start = _round_up(n_img, 64)
+        ntot = aud_start + _round_up(n_aud, 64)
+        ntile = ntot // 64
+        st = MMState(n_img=n_img, n_aud=n_aud, img_start=0, aud_start=aud_start, ntile64=ntile)
+        if ntot == 0:
+            return st
+        Lr = cfg.num_hidden_layers
+        X = torch.zeros((ntot, H), dtype=self.dtype, device=self.dev)
+        for src, off, n in ((img, 0, n_img), (aud, aud_start, n_aud)):
+            if n:
+                if pre_normalized:
+                    X[off: off + n].copy_(src)
+                else:
+                    hip.scale(src.contiguous(), X[off: off + n], self.normalizer)
+        st.kc = torch.empty((Lr, nkv, ntile, 64, hd), dtype=self.dtype, device=self.dev)
+        st.vtc = torch.empty((Lr, nkv, ntile, hd, 64), dtype=self.dtype, device=self.dev)
+        hbuf = self._buf("mm_h", (ntot, H))
+        vrow = self._buf("mm_vrow", (ntot, kvd))
+        u = self._buf("mm_u", (ntot, H))
+        gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
+        eps = cfg.rms_norm_eps
+        for li, L in enumerate(self.layers):
+            hip.norm(hip.NORM_GEMMA, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184
+            hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
+            if li == Lr - 1:
+                break                                                                                # dead update on the last layer
+            hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)                               # :196-197 o_proj(repeat_kv(V))
+            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_attn"], eps=eps, residual=X, out=X)           # :198-201
+            hip.norm(hip.NORM_GEMMA, X, L["ln_pre_ffn"], eps=eps, out=hbuf)                          # :118
+            hip.gemm_geglu(hbuf, L["wgu"], gt)                                                       # :119 gate/up + GeGLU
+            hip.gemm(gt, L["wdown"], None, u)                                                        # :119 down_proj
+            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_ffn"], eps=eps, residual=X, out=X)            # :120-121
+        if check_masks:
+            # one host sync per VIDEO (the reference syncs per layer per step: xattn.py:214-215)
+            for name, m in (("img", img_mask), ("aud", aud_mask)):
+                if m is None:
+                    continue
+                nv = int(m.sum().item())
+                setattr(st, f"{name}_any_valid", nv > 0)
+                if 0 < nv < m.numel():
+                    pad = torch.zeros(_round_up(m.numel(), 64), dtype=torch.uint8, device=self.dev)
+                    pad[: m.numel()] = m
+                    setattr(st, f"{name}_mask", pad)
+        return st
+
+    # -----------------------------------------------------------------------------------------
+    # text stream
+    # -----------------------------------------------------------------------------------------
+    def new_text_state(self, B: int, Lmax: int) -> TextState:
+        cfg = self.cfg
+        kvd = cfg.num_key_value_heads * cfg.head_dim
+        Lr = cfg.num_hidden_layers
+        return TextState(B=B, Lmax=Lmax,
+                         kc=torch.zeros((Lr, B, Lmax, kvd), dtype=self.dtype, device=self.dev),
+                         vc=torch.zeros((Lr, B, Lmax, kvd), dtype=self.dtype, device=self.dev),
+                         kmask=torch.zeros((B, Lmax), dtype=torch.uint8, device=self.dev))
+
+    def _rope_tables(self, max_pos: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """cos/sin rows per position, fp32 math then cast (TP gemma2:118-136); host-precomputed table."""
+        if self._rope_cache is None or self._rope_cache[0].shape[0] < max_pos:
+            hd = self.cfg.head_dim
+            n = max(max_pos, 2048)
+            inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+            fr = torch.arange(n, dtype=torch.float)[:, None] * inv[None, :]
+            emb = torch.cat((fr, fr), dim=-1)
+            self._rope_cache = (emb.cos().to(self.dtype).to(self.dev), emb.sin().to(self.dtype).to(self.dev))
+        return self._rope_cache
+
+    def _cross(self, q: torch.Tensor, li: int, mm: MMState, which: str, out: torch.Tensor, R: int):
+        cfg = self.cfg
+        nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+        G = cfg.num_attention_heads // nkv
+        n = mm.n_img if which == "img" else mm.n_aud
+        start = mm.img_start if which == "img" else mm.aud_start
+        mask = mm.img_mask if which == "img" else mm.aud_mask
+        any_valid = mm.img_any_valid if which == "img" else mm.aud_any_valid
+        Rpad = _round_up(R, 32)
+        nsub = (n + 31) // 32
+        row_tiles = Rpad // 32
+        zsplit = max(1, min(256 // max(1, nkv * row_tiles), (nsub + 7) // 8))
+        key = f"xattn_ws_{zsplit}_{Rpad}"
+        if key not in self._ws:
+            self._ws[key] = hip.attn_cross_workspace(zsplit, nkv, Rpad, hd, self.dev)
+        opart, ml = self._ws[key]
+        hip.attn_cross(q, mm.kc[li], mm.vtc[li], mask, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
+                       key_start=start, n_keys=n, scale=cfg.query_pre_attn_scalar ** -0.5,
+                       softcap=cfg.attn_logit_softcapping, zsplit=zsplit)
+        hip.attn_merge(opart, ml, out, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+
+    def text_forward(self, hidden: torch.Tensor, positions: torch.Tensor, ts: TextState, mm: Optional[MMState],
+                     Lq: int, new_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """hidden: [B*Lq, H] embeds already multiplied by the normalizer; positions: int64 [B*Lq].
+        Appends Lq positions to the text cache.  Returns the final-norm hidden states [B*Lq, H]."""
+        cfg = self.cfg
+        B = ts.B
+        H, nq, nkv, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        nqd, kvd = nq * hd, nkv * hd
+        M = B * Lq
+        eps = cfg.rms_norm_eps
+        p0 = ts.past_len
+        if p0 + Lq > ts.Lmax:
+            raise RuntimeError("text KV cache exhausted")
+        cos_t, sin_t = self._rope_tables(int(ts.Lmax) + 1)
+        cos = cos_t.index_select(0, positions).contiguous()
+        sin = sin_t.index_select(0, positions).contiguous()
+        if new_mask is None:
+            ts.kmask[:, p0: p0 + Lq] = 1
+        else:
+            ts.kmask[:, p0: p0 + Lq] = new_mask.to(torch.uint8)
+        has_img = mm is not None and mm.n_img > 0
+        has_aud = mm is not None and mm.n_aud > 0
+        nstream = 1 + int(has_img) + int(has_aud)
+        hn = self._buf("t_h", (M, H))
+        qkv = self._buf("t_qkv", (M, nqd + 2 * kvd))
+        qr = self._buf("t_qr", (M, nqd))
+        att = self._buf("t_att", (3 * M, nqd))
+        oall = self._buf("t_o", (3 * M, H))
+        ssum = self._buf("t_s", (M, H))
+        yp = self._buf("t_yp", (M, 2 * cfg.intermediate_size))
+        gt = self._buf("t_g", (M, cfg.intermediate_size))
+        dn = self._buf("t_d", (M, H))
+        sc = cfg.query_pre_attn_scalar ** -0.5
+        for li, L in enumerate(self.layers):
+            hip.norm(hip.NORM_GEMMA, hidden, L["ln_in"], eps=eps, out=hn)                           # gemma.py:162
+            self.proj(hn, L["wqkv"], qkv)
+            qr.copy_(qkv[:, :nqd])                                                                   # RoPE'd copy for T2T; raw q for x-attn (:58)
+            kslice = qkv[:, nqd: nqd + kvd]
+            kro = self._buf("t_k", (M, kvd))
+            kro.copy_(kslice)
+            hip.rope(qr, kro, cos, sin, rows=M, nq=nq, nkv=nkv, HD=hd)
+            ts.kc[li][:, p0: p0 + Lq].copy_(kro.view(B, Lq, kvd))
+            ts.vc[li][:, p0: p0 + Lq].copy_(qkv[:, nqd + kvd:].reshape(B, Lq, kvd))
+            window = cfg.sliding_window if (li % 2 == 0) else 0                                       # gemma.py:104
+            hip.attn_text(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
+                          past_len=p0, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
+            k = 1
+            qraw = qkv[:, :nqd]
+            G = nq // nkv
+            if has_img:
+                self._cross(qraw, li, mm, "img", att[k * M: (k + 1) * M], R=M * G); k += 1
+            if has_aud:
+                self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G); k += 1
+            # one o_proj pass over the stacked [text; image; audio] attention outputs (gemma.py:94 x3)
+            self.proj(att[: nstream * M], L["wo"], oall[: nstream * M])
+            if nstream == 1:
+                src = oall[:M]
+            else:
+                hip.add3(oall[:M], oall[M: 2 * M], oall[2 * M: 3 * M] if nstream == 3 else None, ssum)   # :236
+                src = ssum
+            hip.norm(hip.NORM_GEMMA_ADD, src, L["ln_post_attn"], eps=eps, residual=hidden, out=hidden)  # :237
+            hip.norm(hip.NORM_GEMMA, hidden, L["ln_pre_ffn"], eps=eps, out=hn)                          # :118
+            if M <= 8:
+                hip.gemv(hn, L["wgu"], yp)
+                hip.geglu_unpack(yp, gt)
+            else:
+                hip.gemm_geglu(hn, L["wgu"], gt)
+            self.proj(gt, L["wdown"], dn)
+            hip.norm(hip.NORM_GEMMA_ADD, dn, L["ln_post_ffn"], eps=eps, residual=hidden, out=hidden)    # :120-121
+        ts.past_len = p0 + Lq
+        return hip.norm(hip.NORM_GEMMA, hidden, self.final_norm, eps=eps)                               # gemma.py:411
+
+    def logits_argmax(self, hn_last: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """lm_head + final softcap (gemma.py:565-569) + greedy argmax.  hn_last: [B, H]."""
+        B = hn_last.shape[0]
+        logits = self.proj(hn_last.contiguous(), self.lm_head)
+        idx = torch.empty((B,), dtype=torch.int64, device=self.dev)
+        hip.softcap_argmax(logits, idx, self.cfg.final_logit_softcapping)
+        return logits, idx
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        """embed_tokens(ids) * normalizer; ids < 0 give zero rows (padding)."""
+        ids = ids.reshape(-1).to(torch.int64).contiguous()
+        out = torch.empty((ids.numel(), self.cfg.hidden_size), dtype=self.dtype, device=self.dev)
+        return hip.embed(ids, self.embed, out, normalizer=self.normalizer)

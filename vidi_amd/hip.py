@@ -1,0 +1,309 @@
+"""ctypes binding of libvidi_hip.so (include/vidi_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every function here takes torch
+tensors, checks device/dtype/contiguity, and passes `data_ptr()` + sizes + the current HIP stream
+through the C ABI.  There is NO fallback: if the library is missing or a kernel returns an error
+the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvidi_hip.so")
+
+DT_BF16, DT_F16 = 0, 1
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
+NORM_GEMMA, NORM_GEMMA_ADD, NORM_MM, NORM_MM_NOW, NORM_LLM, NORM_LAYER = range(6)
+
+_c_int, _c_ll, _c_f, _c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (mirrors include/vidi_hip.h; tests/test_abi.py checks every symbol exists)
+SIGNATURES = {
+    "vidi_gemm": [_c_vp] * 5 + [_c_int] * 8 + [_c_ll] * 3 + [_c_int] * 6 + [_c_vp],
+    "vidi_gemm_geglu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
+    "vidi_gemm_qkv_vt": [_c_vp] * 5 + [_c_int] * 13 + [_c_vp],
+    "vidi_gemm_kv_cache": [_c_vp] * 5 + [_c_int] * 10 + [_c_vp],
+    "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
+    "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
+    "vidi_attn_self": [_c_vp] * 3 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
+    "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
+    "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
+    "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
+    "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
+    "vidi_norm": [_c_int] + [_c_vp] * 7 + [_c_int] * 2 + [_c_ll] * 3 + [_c_f, _c_f, _c_vp, _c_int, _c_vp],
+    "vidi_scale": [_c_vp] * 2 + [_c_ll, _c_f, _c_int, _c_vp],
+    "vidi_any_nonzero": [_c_vp, _c_ll, _c_vp, _c_int, _c_vp],
+    "vidi_im2col_patch": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
+    "vidi_pool_s2d": [_c_vp] * 2 + [_c_int] * 8 + [_c_vp],
+    "vidi_add_pos": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
+    "vidi_add3": [_c_vp] * 4 + [_c_ll, _c_int, _c_vp],
+    "vidi_embed": [_c_vp] * 3 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp],
+    "vidi_geglu_unpack": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp],
+    "vidi_softcap_argmax": [_c_vp] * 2 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp],
+    "vidi_mel_transpose_pad": [_c_vp] * 2 + [_c_int] * 4 + [_c_vp],
+    "vidi_sinusoid": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the C-ABI library and declare prototypes.  Raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: build it with `python -m vidi_amd.build` (hipcc --offload-arch=gfx950). "
+            "vidi_amd has no CPU or PyTorch fallback for its kernels.")
+    lib = ctypes.CDLL(p)
+    lib.vidi_abi_version.restype = _c_int
+    lib.vidi_build_info.restype = ctypes.c_char_p
+    lib.vidi_attn_cross_workspace_bytes.restype = ctypes.c_size_t
+    lib.vidi_attn_cross_workspace_bytes.argtypes = [_c_int] * 4
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class VidiHipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "bad argument"}
+
+
+def _check(rc: int, op: str):
+    if rc != 0:
+        raise VidiHipError(f"{op} failed: {_ERR.get(rc, f'hipError {rc}')}")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float16:
+        return DT_F16
+    raise VidiHipError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VidiHipError("vidi_amd kernels need device tensors (no CPU path)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rowmajor(t: torch.Tensor, name: str):
+    if t.stride(-1) != 1:
+        raise VidiHipError(f"{name}: last dimension must be contiguous")
+
+
+# ---------------------------------------------------------------------------------------------
+# projections
+# ---------------------------------------------------------------------------------------------
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, *,
+         act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, rmod: int = 0,
+         repkv: Optional[tuple] = None, tile_cfg: int = -1, K: Optional[int] = None,
+         M: Optional[int] = None, ldx: Optional[int] = None,
+         batch: int = 1, bsX: int = 0, bsY: int = 0, bsR: int = 0) -> torch.Tensor:
+    """out[m,n] = epi(x[m,:] . w[n,:] + bias[n]) — 2-D row-major views (arbitrary leading stride).
+    `K`, `M`, `ldx` override the logical shape for overlapping-row (conv-as-GEMM) views."""
+    lib = load_library()
+    _rowmajor(x, "x"); _rowmajor(w, "w")
+    Mv = M if M is not None else x.shape[0]
+    N = w.shape[0]
+    Kv = K if K is not None else (w.shape[1] if repkv is None else w.shape[1])
+    ldxv = ldx if ldx is not None else x.stride(0)
+    if out is None:
+        out = torch.empty((Mv, N), dtype=x.dtype, device=x.device) if batch == 1 else None
+    if out is None:
+        raise VidiHipError("batched gemm needs an explicit out")
+    ldy = out.stride(-2)
+    ldr = residual.stride(-2) if residual is not None else 0
+    rc = lib.vidi_gemm(_p(x), _p(w), _p(bias), _p(out), _p(residual), Mv, N, Kv, ldxv, w.stride(0), ldy, ldr, rmod,
+                       bsX, bsY, bsR, batch, act, repkv[0] if repkv else 0, repkv[1] if repkv else 0,
+                       tile_cfg, _dt(x), _stream())
+    _check(rc, "vidi_gemm")
+    return out
+
+
+def gemm_geglu(x: torch.Tensor, wgu: torch.Tensor, out: Optional[torch.Tensor] = None, tile_cfg: int = -1) -> torch.Tensor:
+    lib = load_library()
+    M, K = x.shape
+    I = wgu.shape[0] // 2
+    if out is None:
+        out = torch.empty((M, I), dtype=x.dtype, device=x.device)
+    _check(lib.vidi_gemm_geglu(_p(x), _p(wgu), _p(out), M, I, K, x.stride(0), wgu.stride(0), out.stride(0),
+                               tile_cfg, _dt(x), _stream()), "vidi_gemm_geglu")
+    return out
+
+
+def gemm_qkv_vt(x, w, bias, yqk, vt, *, vstart, hd, seq, seqpad, nheads, tile_cfg=-1):
+    lib = load_library()
+    M, K = x.shape
+    _check(lib.vidi_gemm_qkv_vt(_p(x), _p(w), _p(bias), _p(yqk), _p(vt), M, w.shape[0], K, x.stride(0), w.stride(0),
+                                yqk.stride(0), vstart, hd, seq, seqpad, nheads, tile_cfg, _dt(x), _stream()), "vidi_gemm_qkv_vt")
+
+
+def gemm_kv_cache(x, wkv, kc, vtc, vrow, *, kvd, hd, ntile64, tok0, tile_cfg=-1):
+    lib = load_library()
+    M, K = x.shape
+    _check(lib.vidi_gemm_kv_cache(_p(x), _p(wkv), _p(kc), _p(vtc), _p(vrow), M, kvd, K, x.stride(0), wkv.stride(0),
+                                  hd, ntile64, tok0, tile_cfg, _dt(x), _stream()), "vidi_gemm_kv_cache")
+
+
+def gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _check(lib.vidi_gemv(_p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _dt(x), _stream()), "vidi_gemv")
+    return out
+
+
+def gemm_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
+    lib = load_library()
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _check(lib.vidi_gemm_f32(_p(x), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), act, _stream()),
+           "vidi_gemm_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def attn_self(qk, vt, out, *, B, N, Npad, H, D, koff, scale):
+    lib = load_library()
+    _check(lib.vidi_attn_self(_p(qk), _p(vt), _p(out), B, N, Npad, H, D, qk.stride(0), koff, out.stride(0), float(scale),
+                              _dt(qk), _stream()), "vidi_attn_self")
+
+
+def attn_cross_workspace(zsplit: int, nkv: int, Rpad: int, HD: int, device) -> tuple:
+    W = 4 * zsplit
+    opart = torch.empty((W, nkv, Rpad, HD), dtype=torch.float32, device=device)
+    ml = torch.empty((W, nkv, Rpad, 2), dtype=torch.float32, device=device)
+    return opart, ml
+
+
+def attn_cross(q, kc, vtc, mask, opart, ml, *, R, Rpad, G, nkv, HD, ntile64, key_start, n_keys, scale, softcap, zsplit):
+    lib = load_library()
+    _check(lib.vidi_attn_cross(_p(q), _p(kc), _p(vtc), _p(mask), _p(opart), _p(ml), R, Rpad, G, nkv, HD, q.stride(0),
+                               ntile64, key_start, n_keys, float(scale), float(softcap or 0.0), zsplit, _dt(q), _stream()),
+           "vidi_attn_cross")
+
+
+def attn_merge(opart, ml, out, *, W, nkv, R, Rpad, G, HD, zero_out=False, out_f32=None, out_ml=None, dtype=None):
+    lib = load_library()
+    ldo = out.stride(0) if out is not None else out_f32.stride(0)
+    dt = _dt(out) if out is not None else dtype
+    _check(lib.vidi_attn_merge(_p(opart), _p(ml), _p(out), _p(out_f32), _p(out_ml), W, nkv, R, Rpad, G, HD, ldo,
+                               1 if zero_out else 0, dt, _stream()), "vidi_attn_merge")
+
+
+def attn_text(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len, window, scale, softcap):
+    lib = load_library()
+    _check(lib.vidi_attn_text(_p(q), _p(kc), _p(vc), _p(kmask), _p(out), B, Lq, Lmax, nq, nkv, HD, past_len, window,
+                              float(scale), float(softcap or 0.0), _dt(q), _stream()), "vidi_attn_text")
+
+
+def rope(q, k, cos, sin, *, rows, nq, nkv, HD):
+    lib = load_library()
+    _check(lib.vidi_rope(_p(q), _p(k), _p(cos), _p(sin), rows, nq, nkv, HD, _dt(q), _stream()), "vidi_rope")
+
+
+# ---------------------------------------------------------------------------------------------
+# norms / elementwise
+# ---------------------------------------------------------------------------------------------
+def norm(mode: int, x: Optional[torch.Tensor], weight: Optional[torch.Tensor], *, eps: float, out: Optional[torch.Tensor] = None,
+         bias=None, residual=None, mask_out=None, x_f32=None, normalizer: float = 1.0, sample_flag: Optional[torch.Tensor] = None,
+         dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    lib = load_library()
+    src = x if x is not None else x_f32
+    H = src.shape[-1]
+    rows = src.numel() // H
+    if out is None:
+        out = torch.empty(src.shape, dtype=(x.dtype if x is not None else dtype), device=src.device)
+    ldx = src.stride(-2) if src.dim() > 1 else H
+    ldy = out.stride(-2) if out.dim() > 1 else H
+    ldr = (residual.stride(-2) if residual.dim() > 1 else H) if residual is not None else 0
+    _check(lib.vidi_norm(mode, _p(x), _p(x_f32), _p(weight), _p(bias), _p(residual), _p(out), _p(mask_out), rows, H,
+                         ldx, ldy, ldr, float(eps), float(normalizer), _p(sample_flag), _dt(out), _stream()), "vidi_norm")
+    return out
+
+
+def im2col_patch(px, out, *, T, S, P, Kpad):
+    _check(load_library().vidi_im2col_patch(_p(px), _p(out), T, S, P, Kpad, _dt(px), _stream()), "vidi_im2col_patch")
+
+
+def pool_s2d(f, out, *, T, side, C, h, w, m, resize):
+    _check(load_library().vidi_pool_s2d(_p(f), _p(out), T, side, C, h, w, m, 1 if resize else 0, _dt(f), _stream()), "vidi_pool_s2d")
+
+
+def add_pos(f, ph, pw, pt, *, T, oh, ow, H):
+    _check(load_library().vidi_add_pos(_p(f), _p(ph), _p(pw), _p(pt), T, oh, ow, H, _dt(f), _stream()), "vidi_add_pos")
+
+
+def add3(a, b, c, out):
+    _check(load_library().vidi_add3(_p(a), _p(b), _p(c), _p(out), a.numel(), _dt(a), _stream()), "vidi_add3")
+    return out
+
+
+def embed(ids, E, out, *, normalizer):
+    n = ids.numel()
+    _check(load_library().vidi_embed(_p(ids), _p(E), _p(out), n, E.shape[1], E.shape[0], float(normalizer), _dt(E), _stream()),
+           "vidi_embed")
+    return out
+
+
+def geglu_unpack(yp, out):
+    M, I2 = yp.shape
+    _check(load_library().vidi_geglu_unpack(_p(yp), _p(out), M, I2 // 2, _dt(yp), _stream()), "vidi_geglu_unpack")
+    return out
+
+
+def softcap_argmax(logits, idx, cap):
+    B, V = logits.shape
+    _check(load_library().vidi_softcap_argmax(_p(logits), _p(idx), B, V, logits.stride(0), float(cap or 0.0), _dt(logits), _stream()),
+           "vidi_softcap_argmax")
+    return idx
+
+
+def mel_transpose_pad(mel, out):
+    C, nmel, L = mel.shape
+    _check(load_library().vidi_mel_transpose_pad(_p(mel), _p(out), C, nmel, L, _dt(mel), _stream()), "vidi_mel_transpose_pad")
+    return out
+
+
+def scale(x, out, s: float):
+    _check(load_library().vidi_scale(_p(x), _p(out), x.numel(), float(s), _dt(x), _stream()), "vidi_scale")
+    return out
+
+
+def any_nonzero(x, flag):
+    """flag (int32[1], zeroed by the caller) |= any(x != 0)"""
+    _check(load_library().vidi_any_nonzero(_p(x), x.numel(), _p(flag), _dt(x), _stream()), "vidi_any_nonzero")
+    return flag
+
+
+def sinusoid(pe, div, *, rows, i0, l, N, d):
+    _check(load_library().vidi_sinusoid(_p(pe), _p(div), rows, i0, l, N, d, _stream()), "vidi_sinusoid")
+    return pe

@@ -1,0 +1,264 @@
+"""Reference-compatible model object for the MI355X path.
+
+Mirrors the surface `eval/inference.py` and `model/builder.py` use on the reference's
+`DattnGemma2ForCausalLM` (Vidi1.5_9B/vidi/model/lmm/dattn/gemma.py:467-687):
+
+    model.config (mm_splits writable), model.get_model().{text_tokenizer,image_processor,audio_processor},
+    model.generation_config.eos_token_id, model.generate(inputs, images=, audios=, audio_sizes=, **kw)
+    -> LongTensor[B, n_new] (new tokens only), model.forward(...) -> DattnCausalLMOutputWithPast,
+    model.encode_videos(images, audios, audio_sizes), model.prepare_inputs_labels_for_multimodal(...).
+
+The greedy loop is our own: HF GenerationMixin is not involved, so there is no
+coupling to a transformers version.  Everything numeric runs in `VidiEngine` (HIP kernels)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .config import VidiConfig
+from .engine import MMState, TextState, VidiEngine
+
+IGNORE_INDEX = -100
+IMAGE_TOKEN_INDEX = -200
+DEFAULT_IMAGE_TOKEN = "<image>"
+
+
+@dataclass
+class DattnCausalLMOutputWithPast:
+    """lmm/dattn/outputs.py:12-20"""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Any = None
+    past_image_key_values: Any = None
+    past_audio_key_values: Any = None
+    hidden_states: Any = None
+    attentions: Any = None
+
+
+def strip_image_token(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                      padding_side: str = "right") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Integer half of prepare_inputs_labels_for_multimodal (multimodal.py:352-430): drop pads, delete
+    the single <image> placeholder (-200), re-pad.  Returns (ids[B,L] with -1 at pads, mask[B,L] bool,
+    position_ids[B,L]).  Host-side, bit-exact."""
+    ids_cpu = input_ids.detach().cpu()
+    am = torch.ones_like(ids_cpu, dtype=torch.bool) if attention_mask is None else attention_mask.detach().cpu().bool()
+    rows = []
+    for row, m in zip(ids_cpu, am):
+        cur = row[m]
+        n_img = int((cur == IMAGE_TOKEN_INDEX).sum())
+        assert n_img <= 1, "only support at most one image for now."          # multimodal.py:369
+        rows.append(cur[cur != IMAGE_TOKEN_INDEX])
+    L = max(int(r.shape[0]) for r in rows)
+    B = len(rows)
+    out = torch.full((B, L), -1, dtype=torch.int64)
+    mask = torch.zeros((B, L), dtype=torch.bool)
+    pos = torch.zeros((B, L), dtype=torch.int64)
+    for i, r in enumerate(rows):
+        n = int(r.shape[0])
+        if n == 0:
+            continue
+        if padding_side == "left":
+            out[i, -n:] = r; mask[i, -n:] = True; pos[i, -n:] = torch.arange(n)
+        else:
+            out[i, :n] = r; mask[i, :n] = True; pos[i, :n] = torch.arange(n)
+    return out, mask, pos
+
+
+class _Inner:
+    """what `model.get_model()` returns in the reference (DattnGemma2MMModel)"""
+
+    def __init__(self, owner: "VidiForCausalLM"):
+        self._owner = owner
+        self.text_tokenizer = None
+        self.image_processor = None
+        self.audio_processor = None
+
+
+class VidiForCausalLM:
+    config_class = VidiConfig
+
+    def __init__(self, config: VidiConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float16,
+                 device: str = "cuda"):
+        self.config = config
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.engine = VidiEngine(config, weights, dtype=dtype, device=device)
+        self.generation_config = SimpleNamespace(eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id)
+        self.model = _Inner(self)
+        self._mm_cache: Optional[Tuple[Any, MMState]] = None
+
+    # ---- reference accessors ----
+    def get_model(self):
+        return self.model
+
+    def eval(self):
+        return self
+
+    def half(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    # ---- multimodal encode (multimodal.py:254-265) ----
+    def _single(self, xs, name):
+        if xs is None:
+            return None
+        if isinstance(xs, (list, tuple)) or xs.dim() == 5 or (name == "audios" and xs.dim() == 4):
+            if len(xs) != 1:
+                # TODO(next): per-sample videos in one batch (the CLI and the BASELINE configs use one video)
+                raise NotImplementedError("one video per call; a batch of queries may share it")
+            return xs[0]
+        return xs
+
+    def encode_videos(self, images, audios, audio_sizes):
+        """-> (image_features[1,Nv,H], image_mask[1,Nv] bool, audio_features[1,Na,H], audio_mask[1,Na] bool),
+        un-normalised like the reference (the normaliser is applied inside the decoder, gemma.py:353-356)."""
+        eng = self.engine
+        img = self._single(images, "images")
+        aud = self._single(audios, "audios")
+        fi = mi = fa = ma = None
+        if img is not None:
+            fi, mi = eng.encode_video_images(img.to(eng.dev))
+            fi, mi = fi[None], mi[None].bool()
+        if aud is not None:
+            fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]))
+            fa, ma = fa[None], ma[None].bool()
+        return fi, mi, fa, ma
+
+    def encode_mm_state(self, images, audios, audio_sizes) -> MMState:
+        """encode + run the query-independent multimodal stream through all layers (caches)."""
+        eng = self.engine
+        img = self._single(images, "images")
+        aud = self._single(audios, "audios")
+        fi = mi = fa = ma = None
+        nz = eng.normalizer
+        if img is not None:
+            fi, mi = eng.encode_video_images(img.to(eng.dev), normalizer=nz)
+        if aud is not None:
+            fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]), normalizer=nz)
+        st = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
+        st.image_attention_mask, st.audio_attention_mask = mi, ma
+        return st
+
+    # ---- text prefill + greedy decode ----
+    def _prefill(self, ids: torch.Tensor, mask: torch.Tensor, pos: torch.Tensor, mm: Optional[MMState], max_new: int):
+        eng = self.engine
+        B, L = ids.shape
+        ts = eng.new_text_state(B, L + max_new + 1)
+        emb = eng.embed_tokens(ids.to(eng.dev))                         # pads (-1) -> zero rows (multimodal.py:423-426)
+        hn = eng.text_forward(emb, pos.reshape(-1).to(eng.dev), ts, mm, Lq=L, new_mask=mask.to(eng.dev))
+        lens = mask.sum(-1).to(eng.dev)
+        ts.n_valid = lens.clone()
+        # logits of each row's LAST VALID token.  (HF + right padding would read position -1, i.e. a
+        # pad slot for shorter rows; the reference CLI never batches, see DESIGN.md "batch semantics".)
+        last = hn.view(B, L, -1)[torch.arange(B, device=eng.dev), lens - 1]
+        return ts, last
+
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, images=None, image_sizes=None, audios=None,
+                 audio_sizes: Optional[Sequence[int]] = None, mm_state: Optional[MMState] = None, **kwargs) -> torch.Tensor:
+        """gemma.py:603-655.  Accepts do_sample/max_new_tokens/use_cache/disable_compile/pad_token_id/
+        attention_mask/position_ids; greedy only (the reference CLI uses do_sample=False)."""
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")            # gemma.py:615-616
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("sampling is not implemented (reference CLI is greedy)")
+        max_new = int(kwargs.get("max_new_tokens", 20))
+        eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
+        pad = kwargs.get("pad_token_id", None)
+        pad = eos if pad is None else pad
+        attention_mask = kwargs.get("attention_mask", None)
+        eng = self.engine
+        ids, mask, pos = strip_image_token(inputs, attention_mask)
+        if mm_state is None and (images is not None or audios is not None):
+            mm_state = self.encode_mm_state(images, audios, audio_sizes)
+        ts, last = self._prefill(ids, mask, pos, mm_state, max_new)
+        B = ids.shape[0]
+        out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
+        finished = torch.zeros(B, dtype=torch.bool, device=eng.dev)
+        _, nxt = eng.logits_argmax(last)
+        n_done = 0
+        for step in range(max_new):
+            nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
+            out[:, step] = nxt
+            n_done = step + 1
+            finished = finished | (nxt == eos)
+            if bool(finished.all()) or step == max_new - 1:          # one D2H sync per token, like HF's stopping criteria
+                break
+            emb = eng.embed_tokens(nxt)
+            posn = ts.n_valid.clone()                                  # HF: position = cumsum(mask) - 1 of the new token
+            ts.n_valid += 1
+            hn = eng.text_forward(emb, posn, ts, mm_state, Lq=1)
+            _, nxt = eng.logits_argmax(hn)
+        return out[:, :n_done]
+
+    # ---- forward (gemma.py:484-601): prefill-style call returning logits ----
+    @torch.no_grad()
+    def forward(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                images=None, audios=None, audio_sizes=None, mm_state: Optional[MMState] = None,
+                logits_to_keep: int = 0, **kwargs) -> DattnCausalLMOutputWithPast:
+        eng = self.engine
+        ids, mask, pos = strip_image_token(input_ids, attention_mask)
+        if mm_state is None and (images is not None or audios is not None):
+            mm_state = self.encode_mm_state(images, audios, audio_sizes)
+        B, L = ids.shape
+        ts = eng.new_text_state(B, L + 1)
+        emb = eng.embed_tokens(ids.to(eng.dev))
+        hn = eng.text_forward(emb, pos.reshape(-1).to(eng.dev), ts, mm_state, Lq=L, new_mask=mask.to(eng.dev))
+        hn = hn.view(B, L, -1)
+        keep = hn if logits_to_keep == 0 else hn[:, -logits_to_keep:]
+        Bk, Lk, H = keep.shape
+        from . import hip
+        flat = keep.reshape(Bk * Lk, H).contiguous()
+        logits = hip.gemm(flat, eng.lm_head, None) if flat.shape[0] > 8 else hip.gemv(flat, eng.lm_head)
+        idx = torch.empty((Bk * Lk,), dtype=torch.int64, device=eng.dev)
+        hip.softcap_argmax(logits, idx, self.config.final_logit_softcapping)
+        return DattnCausalLMOutputWithPast(logits=logits.view(Bk, Lk, -1), past_key_values=ts,
+                                           past_image_key_values=mm_state, past_audio_key_values=mm_state)
+
+    __call__ = forward
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             images, image_sizes, audios, audio_sizes):
+        """multimodal.py:339-451 signature; returns the same 10-tuple (labels untouched: inference only)."""
+        if input_ids.shape[1] == 1:
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels, None, None
+        ids, mask, pos = strip_image_token(input_ids, attention_mask)
+        eng = self.engine
+        emb = eng.embed_tokens(ids.to(eng.dev)).view(ids.shape[0], ids.shape[1], -1)
+        fi, mi, fa, ma = self.encode_videos(images, audios, audio_sizes)
+        return (None, pos if position_ids is not None else None, mask if attention_mask is not None else None,
+                past_key_values, emb, labels, fi, mi, fa, ma)
+
+
+def load_pretrained_model(model_name_or_path: str, load_8bit: bool = False, load_4bit: bool = False, device_map: str = "auto",
+                          device: str = "cuda", use_flash_attn: bool = True, **kwargs):
+    """model/builder.py:24-64 signature.  Loads config.json + *.safetensors from a local directory
+    (fp16 like the reference: builder.py:41), or builds a synthetic model when `kwargs['synthetic']`
+    names a preset.  Returns (model, tokenizer, image_processor, audio_processor)."""
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes quantised loading is out of scope")
+    from .weights import init_random_weights, load_safetensors_dir
+    dtype = kwargs.pop("torch_dtype", torch.float16)
+    synthetic = kwargs.pop("synthetic", None)
+    if synthetic is not None:
+        from . import config as C
+        cfg = getattr(C, synthetic)() if isinstance(synthetic, str) else synthetic
+        weights = init_random_weights(cfg, seed=int(kwargs.pop("seed", 3)), dtype=dtype, device=device)
+    else:
+        cfg = VidiConfig.from_pretrained(model_name_or_path)
+        weights = load_safetensors_dir(model_name_or_path, device="cpu")
+    model = VidiForCausalLM(cfg, weights, dtype=dtype, device=device)
+    tok = img_proc = aud_proc = None
+    try:
+        from .processors import build_processors
+        tok, img_proc, aud_proc = build_processors(model_name_or_path, cfg)
+    except Exception:                       # tokenizer files absent (synthetic runs): processors stay None
+        pass
+    model.get_model().text_tokenizer, model.get_model().image_processor, model.get_model().audio_processor = tok, img_proc, aud_proc
+    model.generation_config.eos_token_id = cfg.eos_token_id
+    return model, tok, img_proc, aud_proc

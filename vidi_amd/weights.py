@@ -1,0 +1,125 @@
+"""Weight containers for the Vidi path: HF-style state-dict names (what a real checkpoint's
+safetensors hold), random initialisation for synthetic runs, and safetensors loading.
+
+Names follow the reference modules: `model.layers.N.*` (Gemma2), `model.mm_vis.vision_model.*`
+(SiglipVisionModel), `model.mm_aud.encoder.*` (WhisperEncoder) and the `model.mm_rand_*` glue of
+Vidi1.5_9B/vidi/model/lmm/dattn/multimodal.py:63-94."""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Dict
+
+import torch
+
+from .config import VidiConfig
+
+
+def weight_shapes(cfg: VidiConfig) -> Dict[str, tuple]:
+    H, I, nq, nkv, hd = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    s: Dict[str, tuple] = {"model.embed_tokens.weight": (cfg.vocab_size, H), "model.norm.weight": (H,)}
+    if not cfg.tie_word_embeddings:
+        s["lm_head.weight"] = (cfg.vocab_size, H)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        s[p + "self_attn.q_proj.weight"] = (nq * hd, H)
+        s[p + "self_attn.k_proj.weight"] = (nkv * hd, H)
+        s[p + "self_attn.v_proj.weight"] = (nkv * hd, H)
+        s[p + "self_attn.o_proj.weight"] = (H, nq * hd)
+        s[p + "mlp.gate_proj.weight"] = (I, H)
+        s[p + "mlp.up_proj.weight"] = (I, H)
+        s[p + "mlp.down_proj.weight"] = (H, I)
+        for n in ("input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm"):
+            s[p + n + ".weight"] = (H,)
+    # SigLIP
+    Hv, Iv, P = cfg.vis_hidden_size, cfg.vis_intermediate_size, cfg.vis_patch_size
+    v = "model.mm_vis.vision_model."
+    s[v + "embeddings.patch_embedding.weight"] = (Hv, 3, P, P)
+    s[v + "embeddings.patch_embedding.bias"] = (Hv,)
+    s[v + "embeddings.position_embedding.weight"] = (cfg.vis_side ** 2, Hv)
+    for i in range(cfg.vis_select_layers):
+        p = f"{v}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (Hv, Hv)
+            s[p + f"self_attn.{n}.bias"] = (Hv,)
+        s[p + "mlp.fc1.weight"] = (Iv, Hv); s[p + "mlp.fc1.bias"] = (Iv,)
+        s[p + "mlp.fc2.weight"] = (Hv, Iv); s[p + "mlp.fc2.bias"] = (Hv,)
+        for n in ("layer_norm1", "layer_norm2"):
+            s[p + n + ".weight"] = (Hv,); s[p + n + ".bias"] = (Hv,)
+    # Whisper encoder
+    Da, Fa = cfg.aud_d_model, cfg.aud_ffn_dim
+    a = "model.mm_aud.encoder."
+    s[a + "conv1.weight"] = (Da, cfg.aud_num_mel_bins, 3); s[a + "conv1.bias"] = (Da,)
+    s[a + "conv2.weight"] = (Da, Da, 3); s[a + "conv2.bias"] = (Da,)
+    s[a + "embed_positions.weight"] = (cfg.aud_max_source_positions, Da)
+    s[a + "layer_norm.weight"] = (Da,); s[a + "layer_norm.bias"] = (Da,)
+    for i in range(cfg.aud_num_layers):
+        p = f"{a}layers.{i}."
+        for n in ("q_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (Da, Da); s[p + f"self_attn.{n}.bias"] = (Da,)
+        s[p + "self_attn.k_proj.weight"] = (Da, Da)
+        s[p + "fc1.weight"] = (Fa, Da); s[p + "fc1.bias"] = (Fa,)
+        s[p + "fc2.weight"] = (Da, Fa); s[p + "fc2.bias"] = (Da,)
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            s[p + n + ".weight"] = (Da,); s[p + n + ".bias"] = (Da,)
+    # mm glue
+    m = "model."
+    pool = cfg.mm_image_pool_size
+    s[m + "mm_rand_img_projector.model.0.weight"] = (H, Hv * pool * pool); s[m + "mm_rand_img_projector.model.0.bias"] = (H,)
+    s[m + "mm_rand_img_projector.model.2.weight"] = (H, H); s[m + "mm_rand_img_projector.model.2.bias"] = (H,)
+    s[m + "mm_rand_aud_pool.weight"] = (H, Da, cfg.mm_audio_pool_size)
+    s[m + "mm_rand_aud_projector.model.0.weight"] = (H, H); s[m + "mm_rand_aud_projector.model.0.bias"] = (H,)
+    s[m + "mm_rand_aud_projector.model.2.weight"] = (H, H); s[m + "mm_rand_aud_projector.model.2.bias"] = (H,)
+    for n in ("mm_rand_img_norm", "mm_rand_aud_norm", "mm_rand_llm_norm"):
+        s[m + n + ".weight"] = (H,)
+    for n in ("mm_rand_pos_h", "mm_rand_pos_w", "mm_rand_pos_t"):
+        s[m + n + ".mlp.0.weight"] = (H, H); s[m + n + ".mlp.0.bias"] = (H,)
+        s[m + n + ".mlp.2.weight"] = (H, H); s[m + n + ".mlp.2.bias"] = (H,)
+    return s
+
+
+def is_fp32_param(name: str) -> bool:
+    """LearnablePosEmbd's MLP is built with dtype=float32 and computes in fp32 (mm_vision/pos.py:36-39)."""
+    return ".mm_rand_pos_" in name
+
+
+def init_random_weights(cfg: VidiConfig, seed: int = 3, dtype: torch.dtype = torch.bfloat16, device="cpu") -> Dict[str, torch.Tensor]:
+    """SURVEY.md §8(d) synthetic weights: Linear ~ N(0,0.02), biases small, norm weights near their
+    identity value with a perturbation so the weight paths are exercised, llm_norm = mm_std."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in weight_shapes(cfg).items():
+        dt = torch.float32 if is_fp32_param(name) else dtype
+        if name.endswith("mm_rand_llm_norm.weight"):
+            t = torch.full(shape, cfg.mm_std, dtype=torch.float32, device=dev)
+        elif "layernorm.weight" in name or name == "model.norm.weight":        # Gemma (1+w) form
+            t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.1
+        elif name.endswith("norm.weight") or "layer_norm" in name and name.endswith(".weight"):
+            t = 1.0 + torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.1
+        elif name.endswith(".bias"):
+            t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.02
+        elif name.endswith("position_embedding.weight") or name.endswith("embed_positions.weight"):
+            t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.02
+        elif name == "model.embed_tokens.weight":
+            t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.02
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * min(0.02 * (3584 / max(fan_in, 1)) ** 0.5, 0.08)
+        out[name] = t.to(dt)
+    return out
+
+
+def load_safetensors_dir(path: str, device="cpu") -> Dict[str, torch.Tensor]:
+    """Load every *.safetensors shard under `path` into one state dict (real checkpoints)."""
+    from safetensors.torch import load_file
+    out: Dict[str, torch.Tensor] = {}
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    for f in files:
+        out.update(load_file(f, device=str(device)))
+    return out
