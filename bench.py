@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: video-tokens/s of the Vidi1.5-9B prefill on a synthetic
+1-hour video at 1 fps (3600 frames, 120 audio windows, 39-token temporal-retrieval prompt), plus s/query.
+
+A "step" = one full prefill of the hot path with inputs already resident in HBM:
+    SigLIP tower -> pool/projector/pos/norm -> Whisper tower -> audio pool/projector ->
+    42-layer multimodal (diagonal) stream + cross-attention cache fill ->
+    text prefill (T2T + T2V + T2A) -> first-token logits + argmax.
+video-tokens/s = Nv * K / t   (Nv = 90 000 visual tokens at 3600 frames: the reference's token-budget rule).
+
+N > 1 (torchrun, one rank per GPU): the SAME video is sharded along the frame axis (and 30-s audio
+windows); every rank runs towers + stream on its shard, keeps its K/V shard resident and the per-layer
+cross-attention partials are all-gathered (RCCL) and LSE-merged — strong scaling of one query.
+
+Prints ONE JSON line (rank 0).  Extra objects: roofline (dominant kernel family = MFMA GEMM, timed with
+HIP events on the launch stream), cpu_baseline (the CPU oracle timed on a bounded slice of this workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/fp16, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=3600, help="video frames (1 fps); 3600 = BASELINE 60-min config")
+    ap.add_argument("--prompt-len", type=int, default=39)
+    ap.add_argument("--decode-steps", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--preset", default="vidi15_9b")
+    return ap.parse_args()
+
+
+def shard(n, world, rank):
+    base, extra = divmod(n, world)
+    s = rank * base + min(rank, extra)
+    return s, s + base + (1 if rank < extra else 0)
+
+
+def cpu_baseline(cfg, T, Nv, Na, prompt_len):
+    """The CPU oracle (oracle/vidi_oracle.py, fp32 eager PyTorch) timed on a bounded slice of the same
+    workload and extrapolated linearly in (frames x layers), (tokens x layers), (windows x layers)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dataclasses
+    import vidi_oracle as O
+    from vidi_amd.weights import init_random_weights
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    small = dataclasses.replace(cfg, num_hidden_layers=1, vis_num_layers=3, aud_num_layers=1, vocab_size=1024)
+    w = init_random_weights(small, seed=3, dtype=torch.float32, device="cpu")
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    ocfg = O.OracleConfig(**{k: v for k, v in small.to_dict().items() if k in names}, vis_select_layer=small.mm_vision_select_layer)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        nf = 8
+        px = (torch.randn((nf, 3, cfg.vis_image_size, cfg.vis_image_size), generator=g) * 0.5).clamp(-1, 1)
+        O.siglip_forward(px[:1], w, ocfg)
+        t0 = time.time(); O.siglip_forward(px, w, ocfg); t_vis = (time.time() - t0) / (nf * 2)        # per frame-layer
+        ntok = 2048
+        x = torch.randn((1, ntok, cfg.hidden_size), generator=g) * 0.03 * cfg.hidden_size ** 0.5
+        t0 = time.time(); O.mm_stream_layer(x, w, "model.layers.0.", ocfg); t_llm = (time.time() - t0) / ntok   # per token-layer
+        mel = torch.randn((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g) * 0.3
+        t0 = time.time(); O.whisper_encoder_forward(mel, w, ocfg); t_aud = time.time() - t0            # per window-layer (+stem)
+        # cross attention of the text prefill over a slice of the keys, one layer-modality
+        nk = 8192
+        q = torch.randn((1, cfg.num_attention_heads, prompt_len, cfg.head_dim), generator=g)
+        k = torch.randn((1, cfg.num_attention_heads, nk, cfg.head_dim), generator=g)
+        t0 = time.time(); O.sdpa_reference(q, k, k, cfg.head_dim ** -0.5, 50.0); t_x = (time.time() - t0) / nk
+    C = math.ceil(T / 30)
+    t_total = (T * cfg.vis_select_layers * t_vis + (Nv + Na) * cfg.num_hidden_layers * t_llm +
+               C * cfg.aud_num_layers * t_aud + (Nv + Na) * cfg.num_hidden_layers * t_x)
+    return {"value": Nv / t_total, "unit": "video-tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 on {nf} frames x 2 SigLIP layers, {ntok} tokens x 1 LLM stream layer, 1 Whisper window x 1 layer, "
+                      f"x-attn Lq={prompt_len} over {nk} keys; extrapolated linearly to {T} frames / {Nv + Na} tokens / "
+                      f"{cfg.vis_select_layers}+{cfg.num_hidden_layers}+{cfg.aud_num_layers} layers",
+            "t_prefill_extrapolated_s": t_total,
+            "breakdown_s": {"siglip": T * cfg.vis_select_layers * t_vis, "llm_stream": (Nv + Na) * cfg.num_hidden_layers * t_llm,
+                            "whisper": C * cfg.aud_num_layers * t_aud, "xattn": (Nv + Na) * cfg.num_hidden_layers * t_x}}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend=os.environ.get("VIDI_DIST_BACKEND", "nccl"))
+    dev = f"cuda:{local if world > 1 else 0}"
+    torch.cuda.set_device(dev)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+
+    from vidi_amd import config as C, hip
+    from vidi_amd.engine import token_budget_hw, audio_token_counts
+    from vidi_amd.model import VidiForCausalLM
+    from vidi_amd.weights import init_random_weights
+    cfg = getattr(C, a.preset)()
+    weights = init_random_weights(cfg, seed=3, dtype=dtype, device=dev)          # replicated on every rank (same seed)
+    model = VidiForCausalLM(cfg, weights, dtype=dtype, device=dev)
+    del weights
+    eng = model.engine
+    if world > 1:
+        eng.set_dist(None)
+
+    # ---- synthetic workload: resident in HBM before the timed region ----
+    T = a.frames
+    Cw = math.ceil(T / 30)                                   # 30-s Whisper windows
+    audio_size = T * 100                                      # mel frames (100 per second)
+    f0, f1 = shard(T, world, rank)
+    c0, c1 = shard(Cw, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    S = cfg.vis_image_size
+    pixel = (torch.randn((f1 - f0, 3, S, S), generator=g, device=dev) * 0.5).clamp_(-1, 1).to(dtype)
+    mel = (torch.randn((c1 - c0, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g, device=dev) * 0.3).to(dtype)
+    gi = torch.Generator().manual_seed(2)
+    ids = torch.randint(1000, min(200000, cfg.vocab_size), (1, a.prompt_len + 1), generator=gi)
+    ids[0, 0] = cfg.bos_token_id
+    ids[0, 4] = -200
+    hw = token_budget_hw(T, cfg.vis_side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)
+    h, w = hw if hw[0] != 28 else (cfg.vis_side + 1, cfg.vis_side + 1)
+    Nv = T * (h // cfg.mm_image_pool_size) * (w // cfg.mm_image_pool_size)
+    Na = audio_token_counts(audio_size, cfg)[1]
+    one = torch.ones(1, dtype=torch.int32, device=dev)         # sample-level "any non-zero input" flag (synthetic: true)
+
+    from vidi_amd.model import strip_image_token
+    idt, mask, pos = strip_image_token(ids)
+    stage_ms = {}
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def step(record=False):
+        e0 = ev()
+        fi, mi = eng.encode_video_images(pixel, frame_offset=f0, total_frames=T, normalizer=eng.normalizer, sample_flag=one)
+        e1 = ev()
+        fa, ma = eng.encode_video_audios(mel, audio_size, normalizer=eng.normalizer, chunk_offset=c0, sample_flag=one)
+        e2 = ev()
+        mm = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
+        e3 = ev()
+        ts, last = model._prefill(idt, mask, pos, mm, a.decode_steps + 1)
+        _, nxt = eng.logits_argmax(last)
+        e4 = ev()
+        if record:
+            torch.cuda.synchronize()
+            for k, (x, y) in {"vision_encode": (e0, e1), "audio_encode": (e1, e2), "mm_stream": (e2, e3), "text_prefill": (e3, e4)}.items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + x.elapsed_time(y)
+        return mm, ts, nxt
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    timer = None if a.no_kernel_timer else hip.KernelTimer()
+    barrier(); torch.cuda.synchronize()
+    hip.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        mm, ts, nxt = step(record=True)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    hip.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = Nv * a.steps / dt
+
+    # ---- decode leg (s/query = prefill + n_new decode steps on the resident caches) ----
+    torch.cuda.synchronize()
+    td0 = time.perf_counter()
+    for _ in range(a.decode_steps):
+        emb = eng.embed_tokens(nxt)
+        posn = ts.n_valid.clone(); ts.n_valid += 1
+        hn = eng.text_forward(emb, posn, ts, mm, Lq=1)
+        _, nxt = eng.logits_argmax(hn)
+        int(nxt[0])                                           # per-token D2H sync, as a stopping criterion needs
+    torch.cuda.synchronize()
+    t_decode = (time.perf_counter() - td0) / max(1, a.decode_steps)
+
+    fam = timer.summary() if timer is not None else {}
+    roof = None
+    if "gemm" in fam:
+        gm = fam["gemm"]
+        ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12
+        roof = {"kernel": "gemm_kernel (MFMA 32x32x16, all GEMM launches of the timed steps)", "bound": "mfma",
+                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": gm["launches"], "avg_launch_ms": gm["ms"] / gm["launches"],
+                "algorithmic_flop_per_launch_avg": gm["work"] / gm["launches"]}
+    fams = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
+                ("TFLOP/s" if v["unit"] == "flop" else "GB/s"): (v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9)) if v["ms"] > 0 else 0.0}
+            for k, v in fam.items()}
+
+    res = {
+        "metric": "video-tokens/sec (prefill), Vidi1.5-9B 1h@1fps", "value": value, "unit": "video-tokens/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (random frames/mel/prompt, random-init weights)",
+        "config": {"workload": f"Vidi1.5-9B prefill, {T} frames@1fps 384px (+{Cw} audio windows, {a.prompt_len}-token prompt)",
+                   "frames": T, "video_tokens": Nv, "audio_tokens": Na, "prompt_tokens": a.prompt_len,
+                   "parallelism": f"frame-shard x{world} (K/V shards resident, LSE-merged cross-attention)" if world > 1 else "single GPU"},
+        "sec_per_query": ms_per_step / 1e3 + a.decode_steps * t_decode, "decode_ms_per_token": t_decode * 1e3,
+        "decode_tokens": a.decode_steps, "frames_per_s": T * a.steps / dt,
+        "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
+        "kernel_families": fams,
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(cfg, T, Nv, Na, a.prompt_len)
+            res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
+        except Exception as e:      # never lose the GPU line to a host-side problem
+            res["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,8 +107,9 @@ size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD);
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
                     float scale, float softcap, int zsplit, int dtype, void* stream);
-/* Merge partials -> Out:[tokens, ldo] (head (kvh*G+g) at column (kvh*G+g)*HD); optional OutF32 /
- * OutML ([tokens][heads][2]) expose the un-rounded result + (m,l) for the cross-GPU LSE merge.
+/* Merge partials -> Out:[tokens, ldo] (head (kvh*G+g) at column (kvh*G+g)*HD).  Optional OutF32
+ * [nkv][Rpad][HD] / OutML [nkv][Rpad][2] receive the merged result in PARTIAL form (numerator, m, l)
+ * — one slice of the Opart/ML layout — so per-GPU results can be all-gathered and merged again.
  * zero_out=1 reproduces gemma.py:180-192 for a sample with no valid key. */
 int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF32, float* OutML,
                     int W, int nkv, int R, int Rpad, int G, int HD, int ldo, int zero_out, int dtype, void* stream);

@@ -626,7 +626,8 @@ def model_forward(inputs_embeds: Tensor, position_ids: Tensor, text_mask: Tensor
 
 def lm_logits(hidden: Tensor, w: W, cfg: OracleConfig) -> Tensor:
     """lm_head + final-logit softcap — gemma.py:565-569."""
-    logits = linear(hidden, w["lm_head.weight"])
+    # gemma-2 ties lm_head to embed_tokens (tie_word_embeddings=True): checkpoints carry no lm_head.weight
+    logits = linear(hidden, w.get("lm_head.weight", w["model.embed_tokens.weight"]))
     if cfg.final_logit_softcapping is not None:
         logits = torch.tanh(logits / cfg.final_logit_softcapping) * cfg.final_logit_softcapping
     return logits

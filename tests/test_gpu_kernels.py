@@ -242,9 +242,16 @@ def test_attn_cross_split_invariance(hip):
         opart, ml = hip.attn_cross_workspace(zs, nkv, 32, HD, "cuda")
         hip.attn_cross(q, kc, vtc, None, opart, ml, R=Lq * G, Rpad=32, G=G, nkv=nkv, HD=HD, ntile64=ntile, key_start=0,
                        n_keys=N, scale=HD ** -0.5, softcap=50.0, zsplit=zs)
-        o = torch.zeros((Lq, nq * HD), dtype=torch.float32, device="cuda")
-        hip.attn_merge(opart, ml, None, W=4 * zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD, out_f32=o, dtype=0)
-        outs.append(o)
+        po = torch.zeros((nkv, 32, HD), dtype=torch.float32, device="cuda")
+        pml = torch.zeros((nkv, 32, 2), dtype=torch.float32, device="cuda")
+        hip.attn_merge(opart, ml, None, W=4 * zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD, out_f32=po, out_ml=pml, dtype=0)
+        # second-level merge of the partial form (what the multi-GPU path does with all-gathered partials)
+        o = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda")
+        hip.attn_merge(po[None].contiguous(), pml[None].contiguous(), o, W=1, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD)
+        outs.append((po[:, : Lq * G] / pml[:, : Lq * G, 1:2]).clone())
+        o1 = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda")
+        hip.attn_merge(opart, ml, o1, W=4 * zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD)
+        assert torch.equal(o.cpu(), o1.cpu()), "two-level merge must equal the direct merge"
     report("split invariance", outs[0], outs[1], 2e-4, 1e-3)
 
 

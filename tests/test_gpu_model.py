@@ -38,7 +38,8 @@ def tiny_setup(request):
 
 
 def tol(dt, k=1.0):
-    return (3e-2 * k, 3e-2) if dt == torch.bfloat16 else (6e-3 * k, 6e-3)
+    """activations after several bf16 layers: |err| <= 5% of the tensor's rms + 3% relative (fp16: 1% / 0.6%)"""
+    return (5e-2 * k, 3e-2) if dt == torch.bfloat16 else (1e-2 * k, 6e-3)
 
 
 def test_siglip_tower(tiny_setup):

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 }
 
 // Combine W partials per (row, kv head): O = sum_w 2^(m_w-m) O_w / sum_w 2^(m_w-m) l_w.
-// Optionally also emits (m, l) so that a further cross-GPU merge can be applied to the result.
+// Optionally emits the merged result in PARTIAL form (numerator, m, l) for a further cross-GPU merge.
 
 template <typename T, int HD>
 __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
@@ -260,10 +260,12 @@ __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
     const size_t oidx = (size_t)tq * p.ldo + (kvh * p.G + g) * HD + d;
     float out = (den > 0.f && !p.zero_out) ? num / den : 0.f;
     if (p.Out) p.Out[oidx] = T::from_f32(out);
-    if (p.OutF32) p.OutF32[oidx] = (den > 0.f) ? num / den : 0.f;
+    // partial form (same layout as one slice of Opart/ML): lets a second merge combine per-GPU results
+    const size_t pbase = (size_t)kvh * p.Rpad + r;
+    if (p.OutF32) p.OutF32[pbase * HD + d] = num;
     if (p.OutML && d == 0) {
-        p.OutML[((size_t)tq * p.nkv * p.G + kvh * p.G + g) * 2] = m;
-        p.OutML[((size_t)tq * p.nkv * p.G + kvh * p.G + g) * 2 + 1] = den;
+        p.OutML[pbase * 2] = m;
+        p.OutML[pbase * 2 + 1] = den;
     }
 }
 

@@ -68,6 +68,8 @@ class MMState:
     aud_mask: Optional[torch.Tensor] = None
     img_any_valid: bool = True
     aud_any_valid: bool = True
+    g_img: int = 0                           # global (all ranks) key counts; == n_img/n_aud on one GPU
+    g_aud: int = 0
     # reference-facing views (encode_videos outputs)
     image_features: Optional[torch.Tensor] = None
     image_attention_mask: Optional[torch.Tensor] = None
@@ -100,6 +102,7 @@ class VidiEngine:
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._ws: Dict[str, torch.Tensor] = {}
+        self.pg, self.world, self.rank = None, 1, 0
 
     # -----------------------------------------------------------------------------------------
     # weight packing (one-time repack into kernel-preferred layouts; owned by this module)
@@ -358,26 +361,35 @@ class VidiEngine:
     # encode_video_audios — multimodal.py:210-252 (one sample)
     # -----------------------------------------------------------------------------------------
     def encode_video_audios(self, mel: torch.Tensor, audio_size: int, normalizer: Optional[float] = None,
-                            aud_features: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                            aud_features: Optional[torch.Tensor] = None, chunk_offset: int = 0,
+                            sample_flag: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`mel` may be a shard of the sample's 30-s windows starting at window `chunk_offset`;
+        `audio_size` is always the GLOBAL mel-frame count (the floors of multimodal.py:226-235 are global)."""
         cfg = self.cfg
         H, Da, pool = cfg.hidden_size, cfg.aud_d_model, cfg.mm_audio_pool_size
         f = self.whisper_forward(mel) if aud_features is None else aud_features              # [C, 1500, Da]
-        s1, s2 = audio_token_counts(audio_size, cfg)
+        s1, s2_total = audio_token_counts(audio_size, cfg)
         flat = f.reshape(-1, Da)
-        if s2 < 1:
-            raise ValueError("audio shorter than one pooled token")
+        if s2_total < 2:
+            raise ValueError("LearnablePosEmbd requires more than one audio token (pos.py:42)")
+        N = f.shape[1]
+        if N % pool:
+            raise ValueError("encoder rows per window must be a multiple of the audio pool size to shard by window")
+        tok0 = chunk_offset * (N // pool)                          # first global token of this shard
+        s2 = max(0, min(s2_total - tok0, f.shape[0] * (N // pool)))
+        if s2 == 0:
+            return (torch.empty((0, H), dtype=self.dtype, device=self.dev), torch.empty((0,), dtype=torch.uint8, device=self.dev))
         # Conv1d(k=pool, s=pool, no bias) over the first s1 rows == GEMM on a [s2, pool*Da] view
         pooled = hip.gemm(flat, self.mm["aud_pool"], None, M=s2, K=pool * Da, ldx=pool * Da)
         p1 = hip.gemm(pooled, self.mm["aud_w0"], self.mm["aud_b0"], act=hip.ACT_GELU_ERF)
         p2 = hip.gemm(p1, self.mm["aud_w2"], self.mm["aud_b2"])
         x = hip.norm(hip.NORM_MM, p2, self.mm["aud_norm"], eps=1e-5)
-        if s2 > 1:
-            pt = self.pos_table("t", s2, cfg.mm_time_interval)
-            hip.add_pos(x, None, None, pt, T=s2, oh=1, ow=1, H=H)
-        else:
-            raise ValueError("LearnablePosEmbd requires more than one audio token (pos.py:42)")
-        flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        hip.any_nonzero(mel.to(self.dtype).contiguous().view(-1), flag)
+        pt = self.pos_table("t", s2_total, cfg.mm_time_interval, i0=tok0, rows=s2)
+        hip.add_pos(x, None, None, pt, T=s2, oh=1, ow=1, H=H)
+        flag = sample_flag
+        if flag is None:
+            flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            hip.any_nonzero(mel.to(self.dtype).contiguous().view(-1), flag)
         mask = torch.empty((s2,), dtype=torch.uint8, device=self.dev)
         feats = hip.norm(hip.NORM_LLM, x, self.mm["llm_norm"], eps=1e-5, mask_out=mask, sample_flag=flag,
                          normalizer=1.0 if normalizer is None else normalizer)
@@ -399,7 +411,13 @@ class VidiEngine:
         ntot = aud_start + _round_up(n_aud, 64)
         ntile = ntot // 64
         st = MMState(n_img=n_img, n_aud=n_aud, img_start=0, aud_start=aud_start, ntile64=ntile)
-        if ntot == 0:
+        st.g_img, st.g_aud = n_img, n_aud
+        if self.world > 1:                              # modality presence is a global property
+            import torch.distributed as dist
+            t = torch.tensor([n_img, n_aud], dtype=torch.int64, device=self.dev if dist.get_backend(self.pg) != "gloo" else "cpu")
+            dist.all_reduce(t, group=self.pg)
+            st.g_img, st.g_aud = int(t[0]), int(t[1])
+        if ntot == 0 and self.world == 1:
             return st
         Lr = cfg.num_hidden_layers
         X = torch.zeros((ntot, H), dtype=self.dtype, device=self.dev)
@@ -416,7 +434,7 @@ class VidiEngine:
         u = self._buf("mm_u", (ntot, H))
         gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
         eps = cfg.rms_norm_eps
-        for li, L in enumerate(self.layers):
+        for li, L in enumerate(self.layers if ntot > 0 else []):
             hip.norm(hip.NORM_GEMMA, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184
             hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
             if li == Lr - 1:
@@ -430,11 +448,17 @@ class VidiEngine:
         if check_masks:
             # one host sync per VIDEO (the reference syncs per layer per step: xattn.py:214-215)
             for name, m in (("img", img_mask), ("aud", aud_mask)):
-                if m is None:
+                if m is None and self.world == 1:
                     continue
-                nv = int(m.sum().item())
-                setattr(st, f"{name}_any_valid", nv > 0)
-                if 0 < nv < m.numel():
+                nv = int(m.sum().item()) if m is not None and m.numel() else 0
+                nv_global = nv
+                if self.world > 1:                     # "sample has any valid key" is a global property
+                    import torch.distributed as dist
+                    t = torch.tensor([nv], dtype=torch.int64, device=self.dev if dist.get_backend(self.pg) != "gloo" else "cpu")
+                    dist.all_reduce(t, group=self.pg)
+                    nv_global = int(t.item())
+                setattr(st, f"{name}_any_valid", nv_global > 0)
+                if m is not None and 0 < nv < m.numel() or (m is not None and nv == 0 and m.numel() > 0 and nv_global > 0):
                     pad = torch.zeros(_round_up(m.numel(), 64), dtype=torch.uint8, device=self.dev)
                     pad[: m.numel()] = m
                     setattr(st, f"{name}_mask", pad)
@@ -479,10 +503,50 @@ class VidiEngine:
         if key not in self._ws:
             self._ws[key] = hip.attn_cross_workspace(zsplit, nkv, Rpad, hd, self.dev)
         opart, ml = self._ws[key]
-        hip.attn_cross(q, mm.kc[li], mm.vtc[li], mask, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
-                       key_start=start, n_keys=n, scale=cfg.query_pre_attn_scalar ** -0.5,
-                       softcap=cfg.attn_logit_softcapping, zsplit=zsplit)
-        hip.attn_merge(opart, ml, out, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+        if n > 0:
+            hip.attn_cross(q, mm.kc[li], mm.vtc[li], mask, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
+                           key_start=start, n_keys=n, scale=cfg.query_pre_attn_scalar ** -0.5,
+                           softcap=cfg.attn_logit_softcapping, zsplit=zsplit)
+        if self.world == 1:
+            hip.attn_merge(opart, ml, out, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+            return
+        # ---- keys are sharded over ranks: local merge -> partial form -> all-gather -> exact LSE merge ----
+        import torch.distributed as dist
+        pk = f"xattn_part_{Rpad}"
+        if pk not in self._ws:
+            self._ws[pk] = (torch.zeros((nkv, Rpad, hd), dtype=torch.float32, device=self.dev),
+                            torch.zeros((nkv, Rpad, 2), dtype=torch.float32, device=self.dev),
+                            torch.zeros((self.world, nkv, Rpad, hd), dtype=torch.float32, device=self.dev),
+                            torch.zeros((self.world, nkv, Rpad, 2), dtype=torch.float32, device=self.dev))
+        po, pml, gpo, gpml = self._ws[pk]
+        if n > 0:
+            hip.attn_merge(opart, ml, None, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, out_f32=po, out_ml=pml,
+                           dtype=hip._dt(out))
+        else:                                   # this rank holds no key of the modality: neutral partial
+            po.zero_()
+            pml[..., 0] = float("-inf")
+            pml[..., 1] = 0.0
+        self._all_gather(gpo, po)
+        self._all_gather(gpml, pml)
+        hip.attn_merge(gpo, gpml, out, W=self.world, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+
+    # -----------------------------------------------------------------------------------------
+    # multi-GPU (one process per GPU, RCCL): frame/chunk-sharded keys, replicated text stream
+    # -----------------------------------------------------------------------------------------
+    def set_dist(self, group=None):
+        import torch.distributed as dist
+        self.pg = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        import torch.distributed as dist
+        if dist.get_backend(self.pg) == "gloo":              # CPU-transport test mode (2 ranks on one GPU)
+            o, i = out.cpu(), inp.cpu()
+            dist.all_gather_into_tensor(o, i, group=self.pg)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.pg)
 
     def text_forward(self, hidden: torch.Tensor, positions: torch.Tensor, ts: TextState, mm: Optional[MMState],
                      Lq: int, new_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -504,8 +568,8 @@ class VidiEngine:
             ts.kmask[:, p0: p0 + Lq] = 1
         else:
             ts.kmask[:, p0: p0 + Lq] = new_mask.to(torch.uint8)
-        has_img = mm is not None and mm.n_img > 0
-        has_aud = mm is not None and mm.n_aud > 0
+        has_img = mm is not None and mm.g_img > 0
+        has_aud = mm is not None and mm.g_aud > 0
         nstream = 1 + int(has_img) + int(has_aud)
         hn = self._buf("t_h", (M, H))
         qkv = self._buf("t_qkv", (M, nqd + 2 * kvd))

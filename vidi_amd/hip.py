@@ -71,9 +71,77 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _c_int
+        setattr(lib, name, _Timed(fn, name))
     if path is None:
         _lib = lib
     return lib
+
+
+# ---------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
+# ---------------------------------------------------------------------------------------------
+TIMER = None      # set to a KernelTimer to time every C-ABI launch
+
+
+def _work(name, a):
+    """(family, algorithmic work, unit) of one launch — DESIGN.md 'algorithmic work per launch'."""
+    if name == "vidi_gemm":
+        return "gemm", 2.0 * a[5] * a[6] * a[7] * a[16], "flop"
+    if name == "vidi_gemm_geglu":
+        return "gemm", 2.0 * a[3] * (2 * a[4]) * a[5], "flop"
+    if name == "vidi_gemm_qkv_vt":
+        return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
+    if name == "vidi_gemm_kv_cache":
+        return "gemm", 2.0 * a[5] * (2 * a[6]) * a[7], "flop"
+    if name == "vidi_attn_self":
+        return "attn_self", 4.0 * a[4] * a[4] * a[7] * a[6] * a[3], "flop"
+    if name == "vidi_attn_cross":
+        return "attn_cross", float(a[14]) * 2 * a[9] * a[10] * 2, "byte"
+    if name == "vidi_norm":
+        return "norm", float(a[8]) * a[9] * 2 * 2, "byte"
+    if name == "vidi_gemv":
+        return "gemv", float(a[4]) * a[5] * 2, "byte"
+    if name == "vidi_gemm_f32":
+        return "gemm_f32", 2.0 * a[4] * a[5] * a[6], "flop"
+    return "other", 0.0, "none"
+
+
+class _Timed:
+    def __init__(self, fn, name):
+        self.fn, self.name = fn, name
+
+    def __call__(self, *a):
+        t = TIMER
+        if t is None:
+            return self.fn(*a)
+        return t.run(self.name, a, self.fn)
+
+
+class KernelTimer:
+    """Brackets every launch with torch.cuda.Event pairs recorded on the current stream (the stream the
+    kernels are enqueued on).  summary() synchronises once and aggregates per kernel family."""
+
+    def __init__(self):
+        self.rec = []
+
+    def run(self, name, a, fn):
+        fam, work, unit = _work(name, a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*a)
+        e1.record()
+        self.rec.append((fam, work, unit, e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, work, unit, e0, e1 in self.rec:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
 
 
 class VidiHipError(RuntimeError):
@@ -213,8 +281,9 @@ def attn_cross(q, kc, vtc, mask, opart, ml, *, R, Rpad, G, nkv, HD, ntile64, key
 
 def attn_merge(opart, ml, out, *, W, nkv, R, Rpad, G, HD, zero_out=False, out_f32=None, out_ml=None, dtype=None):
     lib = load_library()
-    ldo = out.stride(0) if out is not None else out_f32.stride(0)
-    dt = _dt(out) if out is not None else dtype
+    # out_f32 [nkv,Rpad,HD] / out_ml [nkv,Rpad,2]: merged result in partial form (for the cross-GPU merge)
+    ldo = out.stride(0) if out is not None else 0
+    dt = _dt(out) if out is not None else (dtype if dtype is not None else DT_BF16)
     _check(lib.vidi_attn_merge(_p(opart), _p(ml), _p(out), _p(out_f32), _p(out_ml), W, nkv, R, Rpad, G, HD, ldo,
                                1 if zero_out else 0, dt, _stream()), "vidi_attn_merge")
 
