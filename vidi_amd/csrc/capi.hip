@@ -141,7 +141,8 @@ int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const v
 }
 
 int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, int dtype, void* stream) {
-    if (!px || !A || T <= 0 || S % P || Kpad < 3 * P * P) return VIDI_ERR_ARG;
+    // S need not be a multiple of P: Conv2d(padding="valid") drops the remainder (384 = 27*14 + 6)
+    if (!px || !A || T <= 0 || S < P || Kpad < 3 * P * P) return VIDI_ERR_ARG;
     void* a[2] = {(void*)px, A};
     const long long i[4] = {T, S, P, Kpad};
     return vidi_ew_dispatch(EW_IM2COL, a, i, nullptr, dtype, (hipStream_t)stream);

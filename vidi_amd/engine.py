@@ -541,12 +541,14 @@ class VidiEngine:
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         import torch.distributed as dist
+        # `out` is [world, *inp.shape]; pass it in the concatenated-along-dim-0 form both backends accept
+        cat_shape = (out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:])
         if dist.get_backend(self.pg) == "gloo":              # CPU-transport test mode (2 ranks on one GPU)
-            o, i = out.cpu(), inp.cpu()
+            o, i = out.cpu().view(cat_shape), inp.cpu().contiguous()
             dist.all_gather_into_tensor(o, i, group=self.pg)
-            out.copy_(o)
+            out.copy_(o.view(out.shape))
         else:
-            dist.all_gather_into_tensor(out, inp, group=self.pg)
+            dist.all_gather_into_tensor(out.view(cat_shape), inp, group=self.pg)
 
     def text_forward(self, hidden: torch.Tensor, positions: torch.Tensor, ts: TextState, mm: Optional[MMState],
                      Lq: int, new_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
