@@ -170,12 +170,12 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+        const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp2(m_run - m_use);
         m_run = m_new;
         float pv[16], psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            pv[r] = exp2f(s[r] - m_use);
+            pv[r] = fast_exp2(s[r] - m_use);
             psum += pv[r];
         }
         l_run = l_run * alpha + psum;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
             const size_t base = ((size_t)w * p.nkv + kvh) * p.Rpad + r;
             const float mw = p.ML[base * 2];
             if (mw == -INFINITY) continue;
-            const float sc = exp2f(mw - m);
+            const float sc = fast_exp2(mw - m);
             den += sc * p.ML[base * 2 + 1];
             num += sc * p.Opart[base * HD + d];
         }

@@ -23,11 +23,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ---- scalar conversions -------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ u16 f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
+__device__ __forceinline__ u16 f32_to_bf16(float f) {   // round-to-nearest-even: hardware v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(u16, (__bf16)f);
 }
 __device__ __forceinline__ float f16_to_f32(u16 v) {
     _Float16 h;
@@ -62,10 +59,17 @@ struct F16 {
 template <typename T>
 __device__ __forceinline__ float rnd(float f) { return T::to_f32(T::from_f32(f)); }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    return (unsigned)T::from_f32(lo) | ((unsigned)T::from_f32(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    if constexpr (T::id == VIDI_DT_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // one v_cvt_pk_bf16_f32
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
+// raw v_exp_f32 (no denormal fix-up sequence): softmax probabilities below 2^-126 flush to zero
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 template <typename T>
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll
