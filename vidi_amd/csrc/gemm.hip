@@ -14,14 +14,19 @@
 
 
 
-template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV>
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int BK = 64, int STAG = 0>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int NT = WN * WM * 64;
     constexpr int TN = BN / WN / 32, TM = BM / WM / 32;
-    constexpr int W_LOADS = BN * 8 / NT, X_LOADS = BM * 8 / NT;
+    constexpr int CPR = BK / 8;                       // 16-byte chunks per LDS row (8 for BK=64, 4 for BK=32)
+    constexpr int CSH = (CPR == 8) ? 3 : 2;
+    constexpr int ROWB = BK * 2;                      // LDS row bytes
+    constexpr int SWSH = (CPR == 8) ? 1 : 2;          // swizzle = (row >> SWSH) & (CPR-1): conflict-free ds_read_b128
+    constexpr int W_LOADS = BN * CPR / NT, X_LOADS = BM * CPR / NT;
     constexpr int LPT = W_LOADS + X_LOADS;
-    constexpr int STAGE_BYTES = (BN + BM) * 128;
-    static_assert(BN * 8 % NT == 0 && BM * 8 % NT == 0, "tile/threads mismatch");
+    constexpr int STAGE_BYTES = (BN + BM) * ROWB;
+    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(BN * CPR % NT == 0 && BM * CPR % NT == 0, "tile/threads mismatch");
     static_assert(MODE != MODE_GEGLU || (TN % 2 == 0), "GeGLU needs gate/up tile pairs per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -55,27 +60,29 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     int xcol[X_LOADS];
 #pragma unroll
     for (int j = 0; j < W_LOADS; ++j) {
-        const int pidx = j * NT + tid, row = pidx >> 3, cl = pidx & 7, cg = cl ^ ((row >> 1) & 7);
+        const int pidx = j * NT + tid, row = pidx >> CSH, cl = pidx & (CPR - 1), cg = cl ^ ((row >> SWSH) & (CPR - 1));
         const int n = min(n0 + row, p.N - 1);
         wsrc[j] = p.W + (size_t)n * p.ldw + cg * 8;
     }
 #pragma unroll
     for (int j = 0; j < X_LOADS; ++j) {
-        const int pidx = j * NT + tid, row = pidx >> 3, cl = pidx & 7, cg = cl ^ ((row >> 1) & 7);
+        const int pidx = j * NT + tid, row = pidx >> CSH, cl = pidx & (CPR - 1), cg = cl ^ ((row >> SWSH) & (CPR - 1));
         const int m = min(m0 + row, p.M - 1);
         xsrc[j] = Xb + (size_t)m * p.ldx;
         xcol[j] = cg * 8;
         if constexpr (!REPKV) xsrc[j] += cg * 8;
     }
 
-    auto load_stage = [&](int stage, int kt) {
+    // loads [jw0,jw1) of the W tile and [jx0,jx1) of the X tile of K-slice kt into ring slot `stage`
+    auto load_part = [&](int stage, int kt, int jw0, int jw1, int jx0, int jx1) {
         char* sW = smem + stage * STAGE_BYTES;
-        char* sX = sW + BN * 128;
-        const int k0 = kt * 64;
+        char* sX = sW + BN * ROWB;
+        const int k0 = kt * BK;
 #pragma unroll
-        for (int j = 0; j < W_LOADS; ++j) glds16(wsrc[j] + k0, sW + (j * NT + wave * 64) * 16);
+        for (int j = 0; j < W_LOADS; ++j) if (j >= jw0 && j < jw1) glds16(wsrc[j] + k0, sW + (j * NT + wave * 64) * 16);
 #pragma unroll
         for (int j = 0; j < X_LOADS; ++j) {
+            if (j < jx0 || j >= jx1) continue;
             if constexpr (REPKV) {
                 const int k = k0 + xcol[j];
                 const int phys = (k / (p.rep_g * p.rep_hd)) * p.rep_hd + (k % p.rep_hd);
@@ -85,6 +92,12 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
             }
         }
     };
+    auto load_stage = [&](int stage, int kt) { load_part(stage, kt, 0, W_LOADS, 0, X_LOADS); };
+    // STAG: the two waves that share a SIMD (w and w + NW/2) issue their DMA at different k16-steps, so one
+    // wave's load-issue time overlaps the other's MFMAs instead of both stalling the matrix pipe in lockstep.
+    constexpr int NS = BK / 16;
+    constexpr bool kStag = (STAG != 0) && (NS == 4) && (W_LOADS % 2 == 0) && (X_LOADS % 2 == 0) && (WN * WM == 8);
+    const int grp = (wave >= (WN * WM) / 2) ? 1 : 0;
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -95,68 +108,87 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     const int l31 = lane & 31, hi = lane >> 5;
-    const int sw = (l31 >> 1) & 7;                         // row swizzle (tile bases are multiples of 32)
-    const int w_row_off = (wn * TN * 32 + l31) * 128;
-    const int x_row_off = (wm * TM * 32 + l31) * 128;
+    const int sw = (l31 >> SWSH) & (CPR - 1);              // row swizzle (tile bases are multiples of 32)
+    const int w_row_off = (wn * TN * 32 + l31) * ROWB;
+    const int x_row_off = (wm * TM * 32 + l31) * ROWB;
 
-    const int nk = p.K / 64;
+    const int nk = p.K / BK;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) load_stage(s, s);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int rem = min(STAGES - 2, nk - 1 - kt);
+        // tile kt must have landed; up to `rem` younger tiles may stay in flight (loads return in order)
         if constexpr (STAGES == 2) {
             wait_vmcnt<0>();
         } else if constexpr (STAGES == 3) {
             if (rem >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        } else {
+        } else if constexpr (STAGES == 4) {
             if (rem >= 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        } else {
+            if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + STAGES - 1 < nk) load_stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+        const bool do_load = (kt + STAGES - 1 < nk);
+        const int lstage = (kt + STAGES - 1) % STAGES, lkt = kt + STAGES - 1;
+        if constexpr (!kStag) { if (do_load) load_stage(lstage, lkt); }
 
         const char* sW = smem + (kt % STAGES) * STAGE_BYTES;
-        const char* sX = sW + BN * 128;
+        const char* sX = sW + BN * ROWB;
         // fragments of k16-step s+1 are read before the MFMAs of step s (software pipeline in regs)
         u32x4 wf[2][TN], xf[2][TM];
         auto read_frags = [&](int buf, int s) {
             const int coff = ((2 * s + hi) ^ sw) << 4;
 #pragma unroll
-            for (int a = 0; a < TN; ++a) wf[buf][a] = *(const u32x4*)(sW + w_row_off + a * 32 * 128 + coff);
+            for (int a = 0; a < TN; ++a) wf[buf][a] = *(const u32x4*)(sW + w_row_off + a * 32 * ROWB + coff);
 #pragma unroll
-            for (int b = 0; b < TM; ++b) xf[buf][b] = *(const u32x4*)(sX + x_row_off + b * 32 * 128 + coff);
+            for (int b = 0; b < TM; ++b) xf[buf][b] = *(const u32x4*)(sX + x_row_off + b * 32 * ROWB + coff);
         };
         read_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 3) read_frags((s + 1) & 1, s + 1);
+        for (int s = 0; s < BK / 16; ++s) {
+            if (s < BK / 16 - 1) read_frags((s + 1) & 1, s + 1);
+            if constexpr (kStag) {
+                // group 0 issues its halves at steps 0,1 ; group 1 at steps 2,3
+                if (do_load && (s >> 1) == grp) {
+                    const int h = s & 1;
+                    load_part(lstage, lkt, h * (W_LOADS / 2), (h + 1) * (W_LOADS / 2), h * (X_LOADS / 2), (h + 1) * (X_LOADS / 2));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma32(wf[s & 1][a], xf[s & 1][b], acc[a][b]);
+            if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
+    // Row-major outputs are staged through LDS (the stage ring is free now) and leave as whole-row
+    // 16-byte stores: per-lane 8-byte stores straight from the MFMA layout touch 32 rows per
+    // instruction and were measured to cost ~20 K-iterations per 256x256 tile.  Transposed /
+    // scattered destinations (the Vt images) still go straight from registers.
     u16* Yb = p.Y + bz * p.bsY;
     const u16* Rb = p.R ? p.R + bz * p.bsR : nullptr;
     const bool act_tanh = (p.act == ACT_GELU_TANH), act_erf = (p.act == ACT_GELU_ERF);
+    constexpr int BNO = (MODE == MODE_GEGLU) ? BN / 2 : BN;       // output columns of this tile
+    constexpr int CROW = BNO * 2 + 16;                            // padded LDS row (bytes)
+    __syncthreads();                                              // every wave is done with the last K slice
+    char* sC = smem;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * TM * 32 + b * 32 + l31;
-        if (m >= p.M) continue;
-        const int mr = Rb ? (m % p.rmod) : 0;
+        const int ml = wm * TM * 32 + b * 32 + l31;               // row inside the tile
+        const int m = m0 + ml;
         if constexpr (MODE == MODE_GEGLU) {
 #pragma unroll
             for (int a = 0; a < TN; a += 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int nw = n0 + wn * TN * 32 + a * 32;          // W-row base of the gate tile
-                    if (nw >= p.N) continue;
-                    const int no = (nw >> 1) + 8 * j + 4 * hi;          // output feature
+                    const int nol = ((wn * TN * 32 + a * 32) >> 1) + 8 * j + 4 * hi;      // output column inside the tile
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -164,8 +196,8 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                         const float u = rnd<T>(acc[a + 1][b][4 * j + e]);
                         v[e] = rnd<T>(gelu_tanh_f(g)) * u;
                     }
-                    u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-                    *(u32x2*)(Yb + (size_t)m * p.ldy + no) = o;
+                    const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                    *(u32x2*)(sC + ml * CROW + nol * 2) = o;
                 }
             }
         } else {
@@ -173,7 +205,8 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
             for (int a = 0; a < TN; ++a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * TN * 32 + a * 32 + 8 * j + 4 * hi;
+                    const int nl = wn * TN * 32 + a * 32 + 8 * j + 4 * hi;
+                    const int n = n0 + nl;
                     if (n >= p.N) continue;
                     float v[4];
 #pragma unroll
@@ -191,41 +224,63 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(rnd<T>(v[e]));
                     }
-                    if (Rb) {
-                        const u32x2 rv = *(const u32x2*)(Rb + (size_t)mr * p.ldr + n);
-                        v[0] = rnd<T>(v[0]) + T::to_f32((u16)(rv[0] & 0xffff)); v[1] = rnd<T>(v[1]) + T::to_f32((u16)(rv[0] >> 16));
-                        v[2] = rnd<T>(v[2]) + T::to_f32((u16)(rv[1] & 0xffff)); v[3] = rnd<T>(v[3]) + T::to_f32((u16)(rv[1] >> 16));
-                    }
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-                    if constexpr (MODE == MODE_PLAIN) {
-                        *(u32x2*)(Yb + (size_t)m * p.ldy + n) = o;
-                    } else if constexpr (MODE == MODE_QKV_VT) {
-                        if (n < p.vstart) {
-                            *(u32x2*)(Yb + (size_t)m * p.ldy + n) = o;
-                        } else {
-                            const int c = n - p.vstart, h = c / p.hd, d = c % p.hd;
-                            const int bi = m / p.seq, tok = m % p.seq;
-                            const int pos = (tok & ~15) | perm16(tok & 15);
-                            u16* dst = p.Vt + (((size_t)bi * p.nheads + h) * p.hd + d) * p.seqpad + pos;
-                            dst[0] = (u16)(o[0] & 0xffff); dst[(size_t)p.seqpad] = (u16)(o[0] >> 16);
-                            dst[2 * (size_t)p.seqpad] = (u16)(o[1] & 0xffff); dst[3 * (size_t)p.seqpad] = (u16)(o[1] >> 16);
+                    bool staged = true;
+                    if constexpr (MODE == MODE_QKV_VT) {
+                        if (n >= p.vstart) {
+                            staged = false;
+                            if (m < p.M) {
+                                const int c = n - p.vstart, h = c / p.hd, d = c % p.hd;
+                                const int bi = m / p.seq, tok = m % p.seq;
+                                const int pos = (tok & ~15) | perm16(tok & 15);
+                                u16* dst = p.Vt + (((size_t)bi * p.nheads + h) * p.hd + d) * p.seqpad + pos;
+                                dst[0] = (u16)(o[0] & 0xffff); dst[(size_t)p.seqpad] = (u16)(o[0] >> 16);
+                                dst[2 * (size_t)p.seqpad] = (u16)(o[1] & 0xffff); dst[3 * (size_t)p.seqpad] = (u16)(o[1] >> 16);
+                            }
                         }
-                    } else {   // MODE_KV_CACHE
-                        const int tok = p.tok0 + m, tile = tok >> 6, tk = tok & 63;
-                        if (n < p.kvd) {
-                            const int kvh = n / p.hd, d = n % p.hd;
-                            *(u32x2*)(p.Kc + (((size_t)kvh * p.ntile64 + tile) * 64 + tk) * p.hd + d) = o;
-                        } else {
+                    } else if constexpr (MODE == MODE_KV_CACHE) {
+                        if (n >= p.kvd && m < p.M) {               // V: also the transposed, perm16 tile image
+                            const int tok = p.tok0 + m, tile = tok >> 6, tk = tok & 63;
                             const int c = n - p.kvd, kvh = c / p.hd, d = c % p.hd;
-                            *(u32x2*)(p.Vrow + (size_t)m * p.kvd + c) = o;
                             const int pos = (tk & ~15) | perm16(tk & 15);
                             u16* dst = p.Vtc + (((size_t)kvh * p.ntile64 + tile) * p.hd + d) * 64 + pos;
                             dst[0] = (u16)(o[0] & 0xffff); dst[64] = (u16)(o[0] >> 16);
                             dst[128] = (u16)(o[1] & 0xffff); dst[192] = (u16)(o[1] >> 16);
                         }
                     }
+                    if (staged) *(u32x2*)(sC + ml * CROW + nl * 2) = o;
                 }
             }
+        }
+    }
+    __syncthreads();
+    // ---- copy-out: 16-byte chunks, consecutive lanes = consecutive chunks of one row ------------
+    constexpr int CH = BNO / 8;
+    const int no0 = (MODE == MODE_GEGLU) ? (n0 >> 1) : n0;
+    const int Nout = (MODE == MODE_GEGLU) ? (p.N >> 1) : p.N;
+    for (int i = tid; i < BM * CH; i += NT) {
+        const int ml = i / CH, c = i % CH;
+        const int m = m0 + ml, n = no0 + c * 8;
+        if (m >= p.M || n >= Nout) continue;
+        if constexpr (MODE == MODE_QKV_VT) { if (n >= p.vstart) continue; }
+        u32x4 val = *(const u32x4*)(sC + ml * CROW + c * 16);
+        if constexpr (MODE == MODE_KV_CACHE) {
+            if (n < p.kvd) {
+                const int tok = p.tok0 + m, kvh = n / p.hd, d = n % p.hd;
+                *(u32x4*)(p.Kc + ((size_t)kvh * p.ntile64 * 64 + tok) * p.hd + d) = val;
+            } else {
+                *(u32x4*)(p.Vrow + (size_t)m * p.kvd + (n - p.kvd)) = val;
+            }
+        } else {
+            if (Rb) {
+                float x[8], r[8];
+                unpack8<T>(val, x);
+                unpack8<T>(*(const u32x4*)(Rb + (size_t)(m % p.rmod) * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
+                val = pack8<T>(x);
+            }
+            *(u32x4*)(Yb + (size_t)m * p.ldy + n) = val;
         }
     }
 }
@@ -396,10 +451,12 @@ static hipError_t set_lds(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV>
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int BK = 64, int STAG = 0>
 static int launch_cfg(const GemmParams& p, int batch, hipStream_t st) {
-    constexpr int LDS = STAGES * (BN + BM) * 128;
-    auto kern = gemm_kernel<T, BN, BM, WN, WM, STAGES, MODE, REPKV>;
+    constexpr int RING = STAGES * (BN + BM) * BK * 2;
+    constexpr int CTILE = BM * ((MODE == MODE_GEGLU ? BN / 2 : BN) * 2 + 16);
+    constexpr int LDS = RING > CTILE ? RING : CTILE;
+    auto kern = gemm_kernel<T, BN, BM, WN, WM, STAGES, MODE, REPKV, BK, STAG>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = set_lds(kern, LDS);
@@ -423,17 +480,17 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         }
     }
     if (tile_cfg < 0) {
-        // heuristic: big-tile deep pipeline when there is enough work to fill 256 CUs with it
+        // measured on MI355X (tools/bench_gemm.py): the 256x256 tile wins from ~1 wave of blocks up, also when
+        // N is not a multiple of 256 (edge tiles are masked); small problems take the 128x128 tile.
         const long long t256 = (long long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-        const long long t128x256 = (long long)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
-        if (p.N % 256 == 0 && t256 >= 512) tile_cfg = 2;
-        else if (t128x256 >= 512) tile_cfg = 1;
-        else tile_cfg = 0;
+        tile_cfg = (t256 >= 192) ? 2 : 0;
     }
     switch (tile_cfg) {
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
+        // (deeper BK=32 rings, staggered DMA issue and 2-blocks/CU 128x256 tiles were measured slower on MI355X —
+        //  DESIGN.md 'GEMM experiments' — the template parameters BK / STAG remain for future schedules)
         default: return VIDI_ERR_ARG;
     }
 }
@@ -454,8 +511,10 @@ int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int 
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return VIDI_ERR_SHAPE;
     if (p.K % 64 != 0 || p.N % 32 != 0) return VIDI_ERR_SHAPE;
     if (mode == MODE_GEGLU && p.N % 64 != 0) return VIDI_ERR_SHAPE;
-    if ((p.ldx % 8) || (p.ldw % 8) || (p.ldy % 4)) return VIDI_ERR_ALIGN;
-    if (((uintptr_t)p.X & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.Y & 7)) return VIDI_ERR_ALIGN;
+    if ((p.ldx % 8) || (p.ldw % 8) || (p.ldy % 8)) return VIDI_ERR_ALIGN;
+    if (((uintptr_t)p.X & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.Y & 15)) return VIDI_ERR_ALIGN;
+    if (p.R && ((p.ldr % 8) || ((uintptr_t)p.R & 15))) return VIDI_ERR_ALIGN;
+    if (mode == MODE_KV_CACHE && (((uintptr_t)p.Kc & 15) || ((uintptr_t)p.Vrow & 15) || (p.hd % 8))) return VIDI_ERR_ALIGN;
     if (dtype == VIDI_DT_BF16) return launch_dtype<BF16>(p, batch, mode, repkv, tile_cfg, st);
     if (dtype == VIDI_DT_F16) return launch_dtype<F16>(p, batch, mode, repkv, tile_cfg, st);
     return VIDI_ERR_DTYPE;
