@@ -65,8 +65,8 @@ class VidiConfig:
     aud_sampling_rate: int = 16000
     aud_hop_length: int = 160
     # ---- engine knobs (ours) ----
-    vis_frames_per_chunk: int = 96          # SigLIP activation chunk (frames)
-    aud_chunks_per_batch: int = 16          # Whisper activation chunk (30-s windows)
+    vis_frames_per_chunk: int = 360         # SigLIP activation chunk (frames): ~1000 M-tiles per GEMM => <2% tail waves
+    aud_chunks_per_batch: int = 60          # Whisper activation chunk (30-s windows)
 
     @property
     def vis_side(self) -> int:

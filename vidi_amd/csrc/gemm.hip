@@ -129,8 +129,8 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
         } else {
             if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();
-        const bool do_load = (kt + STAGES - 1 < nk);
+        if constexpr (STAG != 4) __builtin_amdgcn_s_barrier();
+        const bool do_load = (STAG < 3) && (kt + STAGES - 1 < nk);
         const int lstage = (kt + STAGES - 1) % STAGES, lkt = kt + STAGES - 1;
         if constexpr (!kStag) { if (do_load) load_stage(lstage, lkt); }
 
@@ -489,6 +489,8 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
+        case 13: if constexpr (MODE == MODE_PLAIN && !REPKV) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 3>(p, batch, st); else return VIDI_ERR_ARG;
+        case 14: if constexpr (MODE == MODE_PLAIN && !REPKV) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 4>(p, batch, st); else return VIDI_ERR_ARG;
         // (deeper BK=32 rings, staggered DMA issue and 2-blocks/CU 128x256 tiles were measured slower on MI355X —
         //  DESIGN.md 'GEMM experiments' — the template parameters BK / STAG remain for future schedules)
         default: return VIDI_ERR_ARG;
