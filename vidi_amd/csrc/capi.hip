@@ -21,6 +21,7 @@ int vidi_gemm(const void* X, const void* W, const void* bias, void* Y, const voi
               int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int rmod,
               long long bsX, long long bsY, long long bsR, int batch,
               int act, int repkv_hd, int repkv_g, int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !W || !Y) return VIDI_ERR_ARG;
     if (R && (ldr % 4)) return VIDI_ERR_ALIGN;
     GemmParams p = base_params(X, W, bias, Y, R, M, N, K, ldx, ldw, ldy, ldr, rmod);
@@ -35,6 +36,7 @@ int vidi_gemm(const void* X, const void* W, const void* bias, void* Y, const voi
 
 int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
                     int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !Wgu || !Y) return VIDI_ERR_ARG;
     if (I % 32) return VIDI_ERR_SHAPE;
     GemmParams p = base_params(X, Wgu, nullptr, Y, nullptr, M, 2 * I, K, ldx, ldw, ldy, 0, 0);
@@ -45,6 +47,7 @@ int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K
 int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, void* Vt,
                      int M, int N, int K, int ldx, int ldw, int ldy,
                      int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !W || !Yqk || !Vt) return VIDI_ERR_ARG;
     if (vstart % 4 || hd % 4 || seq <= 0 || seqpad % 16 || seqpad < ((seq + 15) / 16) * 16 || M % seq) return VIDI_ERR_SHAPE;
     if ((N - vstart) != nheads * hd) return VIDI_ERR_SHAPE;
@@ -57,6 +60,7 @@ int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, 
 int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* Vrow,
                        int M, int kvd, int K, int ldx, int ldw, int hd, int ntile64, int tok0,
                        int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !W || !Kc || !Vtc || !Vrow) return VIDI_ERR_ARG;
     if (kvd % hd || hd % 4 || tok0 < 0 || (tok0 + M + 63) / 64 > ntile64) return VIDI_ERR_SHAPE;
     GemmParams p = base_params(X, W, nullptr, Vrow, nullptr, M, 2 * kvd, K, ldx, ldw, kvd, 0, 0);
@@ -67,18 +71,21 @@ int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* 
 
 int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
               int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !W || !Y) return VIDI_ERR_ARG;
     return vidi_gemv_dispatch(X, W, Y, M, N, K, ldx, ldw, ldy, dtype, (hipStream_t)stream);
 }
 
 int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
                   int ldx, int ldw, int ldy, int act, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !W || !Y) return VIDI_ERR_ARG;
     return vidi_gemm_f32_dispatch(X, W, bias, Y, M, N, K, ldx, ldw, ldy, act, (hipStream_t)stream);
 }
 
 int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Npad, int H, int D,
                    int ldqk, int koff, int ldo, float scale, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!QK || !Vt || !O) return VIDI_ERR_ARG;
     AttnSelfParams p;
     p.QK = (const u16*)QK; p.Vt = (const u16*)Vt; p.O = (u16*)O;
@@ -94,6 +101,7 @@ size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD) {
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
                     float scale, float softcap, int zsplit, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!Q || !Kc || !Vtc || !Opart || !ML) return VIDI_ERR_ARG;
     if ((key_start + n_keys + 63) / 64 > ntile64) return VIDI_ERR_SHAPE;
     AttnCrossParams p;
@@ -105,6 +113,7 @@ int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* 
 
 int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF32, float* OutML,
                     int W, int nkv, int R, int Rpad, int G, int HD, int ldo, int zero_out, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!Opart || !ML || (!Out && !OutF32)) return VIDI_ERR_ARG;
     AttnMergeParams p;
     p.Opart = Opart; p.ML = ML; p.Out = (u16*)Out; p.OutF32 = OutF32; p.OutML = OutML;
@@ -115,6 +124,7 @@ int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF3
 int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
                    int B, int Lq, int Lmax, int nq, int nkv, int HD, int past_len, int window,
                    float scale, float softcap, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!Q || !Kc || !Vc || !O) return VIDI_ERR_ARG;
     AttnTextParams p;
     p.Q = (const u16*)Q; p.Kc = (const u16*)Kc; p.Vc = (const u16*)Vc; p.kmask = (const unsigned char*)kmask; p.O = (u16*)O;
@@ -125,6 +135,7 @@ int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* km
 
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
               int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!Q || !K || !cos_ || !sin_) return VIDI_ERR_ARG;
     return vidi_rope_dispatch(Q, K, cos_, sin_, rows, nq, nkv, HD, dtype, (hipStream_t)stream);
 }
@@ -132,6 +143,7 @@ int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, in
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
               void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
               float eps, float normalizer, const int* sample_flag, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if ((!X && !XF32) || !Y) return VIDI_ERR_ARG;
     NormParams p;
     p.X = (const u16*)X; p.XF32 = XF32; p.Wt = (const u16*)W; p.Bias = (const u16*)Bias; p.Res = (const u16*)Res;
@@ -141,6 +153,7 @@ int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const v
 }
 
 int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     // S need not be a multiple of P: Conv2d(padding="valid") drops the remainder (384 = 27*14 + 6)
     if (!px || !A || T <= 0 || S < P || Kpad < 3 * P * P) return VIDI_ERR_ARG;
     void* a[2] = {(void*)px, A};
@@ -149,6 +162,7 @@ int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, in
 }
 
 int vidi_pool_s2d(const void* f, void* out, int T, int side, int C, int h, int w, int m, int resize, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!f || !out || T <= 0 || m <= 0) return VIDI_ERR_ARG;
     if (!resize && (h != side + 1 || w != side + 1)) return VIDI_ERR_SHAPE;
     void* a[2] = {(void*)f, out};
@@ -157,6 +171,7 @@ int vidi_pool_s2d(const void* f, void* out, int T, int side, int C, int h, int w
 }
 
 int vidi_add_pos(void* f, const void* ph, const void* pw, const void* pt, int T, int oh, int ow, int H, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!f) return VIDI_ERR_ARG;
     void* a[4] = {f, (void*)ph, (void*)pw, (void*)pt};
     const long long i[4] = {T, oh, ow, H};
@@ -164,6 +179,7 @@ int vidi_add_pos(void* f, const void* ph, const void* pw, const void* pt, int T,
 }
 
 int vidi_add3(const void* a_, const void* b, const void* c, void* y, long long n, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!a_ || !y) return VIDI_ERR_ARG;
     void* a[4] = {(void*)a_, (void*)b, (void*)c, y};
     const long long i[1] = {n};
@@ -171,6 +187,7 @@ int vidi_add3(const void* a_, const void* b, const void* c, void* y, long long n
 }
 
 int vidi_embed(const long long* ids, const void* E, void* out, int n, int H, long long vocab, float normalizer, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!ids || !E || !out) return VIDI_ERR_ARG;
     void* a[3] = {(void*)ids, (void*)E, out};
     const long long i[3] = {n, H, vocab};
@@ -179,6 +196,7 @@ int vidi_embed(const long long* ids, const void* E, void* out, int n, int H, lon
 }
 
 int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!Yp || !out) return VIDI_ERR_ARG;
     void* a[2] = {(void*)Yp, out};
     const long long i[2] = {M, I};
@@ -186,6 +204,7 @@ int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* 
 }
 
 int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!logits || !idx || B <= 0 || V <= 0) return VIDI_ERR_ARG;
     void* a[2] = {logits, (void*)idx};
     const long long i[3] = {B, V, ld};
@@ -194,6 +213,7 @@ int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld
 }
 
 int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!mel || !out) return VIDI_ERR_ARG;
     void* a[2] = {(void*)mel, out};
     const long long i[3] = {C, nmel, L};
@@ -201,6 +221,7 @@ int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, i
 }
 
 int vidi_scale(const void* x, void* y, long long n, float s, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!x || !y) return VIDI_ERR_ARG;
     void* a[2] = {(void*)x, y};
     const long long i[1] = {n};
@@ -209,6 +230,7 @@ int vidi_scale(const void* x, void* y, long long n, float s, int dtype, void* st
 }
 
 int vidi_any_nonzero(const void* x, long long n, int* flag, int dtype, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!x || !flag) return VIDI_ERR_ARG;
     void* a[2] = {(void*)x, (void*)flag};
     const long long i[1] = {n};
@@ -216,6 +238,7 @@ int vidi_any_nonzero(const void* x, long long n, int* flag, int dtype, void* str
 }
 
 int vidi_sinusoid(float* pe, const float* div_term, int rows, int i0, int l, int N, int d, void* stream) {
+    (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!pe || !div_term) return VIDI_ERR_ARG;
     return vidi_sinusoid_dispatch(pe, div_term, rows, i0, l, N, d, (hipStream_t)stream);
 }
