@@ -98,10 +98,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    force_dev = os.environ.get("VIDI_FORCE_DEVICE")          # test hook: several ranks on one GPU (gloo transport)
+    if force_dev is not None:
+        local = int(force_dev)
     if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group(backend=os.environ.get("VIDI_DIST_BACKEND", "nccl"))
-    dev = f"cuda:{local if world > 1 else 0}"
+    dev = f"cuda:{local if (world > 1 or force_dev is not None) else 0}"
     torch.cuda.set_device(dev)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 
