@@ -1,5 +1,6 @@
 // extern "C" entry points of libvidi_hip.so (declared in include/vidi_hip.h).
 #include "kernels.h"
+#include <stdlib.h>
 #include "../../include/vidi_hip.h"
 
 extern "C" {
@@ -14,6 +15,11 @@ static GemmParams base_params(const void* X, const void* W, const void* bias, vo
     p.X = (const u16*)X; p.W = (const u16*)W; p.bias = (const u16*)bias; p.Y = (u16*)Y; p.R = (const u16*)R;
     p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldr = ldr;
     p.rmod = rmod > 0 ? rmod : 0x7fffffff;
+    {
+        static int gm = -1;
+        if (gm < 0) { const char* e = getenv("VIDI_GEMM_GROUP_M"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
+        p.group_m = gm;
+    }
     return p;
 }
 

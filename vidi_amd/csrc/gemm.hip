@@ -11,6 +11,7 @@
 //
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16/fp16).  Algorithmic FLOPs = 2*M*N*K.
 #include "kernels.h"
+#include <stdlib.h>
 
 
 
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
         const int nb = gridDim.x, b = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
         const int rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        constexpr int GROUP_M = 8;
+        const int GROUP_M = p.group_m;
         const int per_group = GROUP_M * tiles_n;
         const int g = rb / per_group, first_m = g * GROUP_M;
         const int gm = min(tiles_m - first_m, GROUP_M);
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     auto load_part = [&](int stage, int kt, int jw0, int jw1, int jx0, int jx1) {
         char* sW = smem + stage * STAGE_BYTES;
         char* sX = sW + BN * ROWB;
-        const int k0 = kt * BK;
+        const int k0 = (STAG == 8) ? 0 : kt * BK;          // STAG 8 (diagnostic): every DMA re-reads K slice 0 (cache hits)
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) if (j >= jw0 && j < jw1) glds16(wsrc[j] + k0, sW + (j * NT + wave * 64) * 16);
 #pragma unroll
@@ -92,11 +93,16 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
             }
         }
     };
-    auto load_stage = [&](int stage, int kt) { load_part(stage, kt, 0, W_LOADS, 0, X_LOADS); };
+    // STAG 12 (diagnostic): after the prologue only the W tile is re-loaded (half the DMA traffic; wrong results)
+    auto load_stage = [&](int stage, int kt) { load_part(stage, kt, 0, W_LOADS, 0, (STAG == 12 && kt > 0) ? 0 : X_LOADS); };
     // STAG: the two waves that share a SIMD (w and w + NW/2) issue their DMA at different k16-steps, so one
     // wave's load-issue time overlaps the other's MFMAs instead of both stalling the matrix pipe in lockstep.
     constexpr int NS = BK / 16;
-    constexpr bool kStag = (STAG != 0) && (NS == 4) && (W_LOADS % 2 == 0) && (X_LOADS % 2 == 0) && (WN * WM == 8);
+    // STAG == 7: DMA pieces are issued one at a time BETWEEN MFMAs (2 per k16-step), away from the ds_read burst
+    constexpr int NPIECE = W_LOADS + X_LOADS, NMF = TN * TM;
+    constexpr bool kInter = (STAG == 7) && (NS == 4) && (NPIECE % NS == 0) && ((NMF * NS) % NPIECE == 0);
+    constexpr int GAP = kInter ? (NMF * NS) / NPIECE : 1;            // MFMAs between two DMA pieces
+    constexpr bool kStag = (STAG != 0) && (STAG != 7) && (NS == 4) && (W_LOADS % 2 == 0) && (X_LOADS % 2 == 0) && (WN * WM == 8);
     const int grp = (wave >= (WN * WM) / 2) ? 1 : 0;
 
     f32x16 acc[TN][TM];
@@ -113,59 +119,187 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     const int x_row_off = (wm * TM * 32 + l31) * ROWB;
 
     const int nk = p.K / BK;
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) load_stage(s, s);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int rem = min(STAGES - 2, nk - 1 - kt);
-        // tile kt must have landed; up to `rem` younger tiles may stay in flight (loads return in order)
-        if constexpr (STAGES == 2) {
-            wait_vmcnt<0>();
-        } else if constexpr (STAGES == 3) {
-            if (rem >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        } else if constexpr (STAGES == 4) {
-            if (rem >= 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        } else {
-            if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        }
-        if constexpr (STAG != 4) __builtin_amdgcn_s_barrier();
-        const bool do_load = (STAG < 3) && (kt + STAGES - 1 < nk);
-        const int lstage = (kt + STAGES - 1) % STAGES, lkt = kt + STAGES - 1;
-        if constexpr (!kStag) { if (do_load) load_stage(lstage, lkt); }
-
-        const char* sW = smem + (kt % STAGES) * STAGE_BYTES;
+  if constexpr (STAG == 9) {
+    // ================= ping-pong schedule (8 waves, BK = 32 micro-tiles, R-deep ring) =================
+    // The two waves that share a SIMD (w and w+4) alternate roles every barrier interval ("slot"):
+    //   slot 2j   : group A (waves 0-3) runs L(j)  = ds_read the fragments of micro-tile j + issue its own DMA pieces
+    //               group B (waves 4-7) runs M(j-1) = 16 MFMAs from registers
+    //   slot 2j+1 : A runs M(j), B runs L(j)
+    // so every SIMD's matrix pipe is fed back-to-back by one wave while its partner does all LDS/DMA work.
+    // Micro-tile j is read by A in slot 2j and by B in slot 2j+1; its ring slot is refilled (micro-tile j+R)
+    // by A in slot 2j+2 and by B in slot 2j+3, i.e. 2R-2 / 2R-3 slots before the first reader: loads are never
+    // drained (counted vmcnt) and have ~3 K-steps of lead time.
+    static_assert(BK == 32 && WN * WM == 8 && STAGES >= 3 && STAGES <= 5, "ping-pong geometry");
+    constexpr int R = STAGES;
+    auto wait_rem = [&](int rem) {            // allow `rem` younger batches (LPT DMA instructions each) in flight
+        if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    };
+    u32x4 wf[2][TN], xf[2][TM];
+    auto Lseg = [&](int j) {
+        const char* sW = smem + (j % R) * STAGE_BYTES;
         const char* sX = sW + BN * ROWB;
-        // fragments of k16-step s+1 are read before the MFMAs of step s (software pipeline in regs)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int coff = ((2 * st + hi) ^ sw) << 4;
+#pragma unroll
+            for (int a2 = 0; a2 < TN; ++a2) wf[st][a2] = *(const u32x4*)(sW + w_row_off + a2 * 32 * ROWB + coff);
+#pragma unroll
+            for (int b2 = 0; b2 < TM; ++b2) xf[st][b2] = *(const u32x4*)(sX + x_row_off + b2 * 32 * ROWB + coff);
+        }
+        if (j + R - 1 < nk) load_stage((j + R - 1) % R, j + R - 1);      // refill the slot freed by micro-tile j-1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my LDS reads are done before I release the slot
+    };
+    auto Mseg = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int a2 = 0; a2 < TN; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < TM; ++b2) acc[a2][b2] = T::mfma32(wf[st][a2], xf[st][b2], acc[a2][b2]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // before the barrier that precedes A's L(j+1): this wave's pieces of micro-tile j+1 must have landed
+    auto wait_next = [&](int j) { if (j + 1 < nk) wait_rem(min(R - 2, nk - 2 - j)); };
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < nk) load_stage(st, st);
+    wait_rem(min(R - 2, nk - 1));                                          // micro-tile 0 landed
+    if (grp == 0) {
+        for (int j = 0; j < nk; ++j) { bar(); Lseg(j); bar(); Mseg(); wait_next(j); }
+        bar();
+    } else {
+        bar();
+        for (int j = 0; j < nk; ++j) { bar(); Lseg(j); wait_next(j); bar(); Mseg(); }
+    }
+  } else if constexpr (STAG == 15) {
+    // ---- experiment: register-staged double buffer (global_load -> VGPR early, ds_write late) instead of LDS-DMA ----
+    static_assert(!REPKV && STAGES == 2, "regstage experiment");
+    u32x4 wreg[W_LOADS], xreg[X_LOADS];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) wreg[j] = *(const u32x4*)(wsrc[j] + k0);
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j) xreg[j] = *(const u32x4*)(xsrc[j] + k0);
+    };
+    auto lwrite = [&](int stage) {
+        char* sW = smem + stage * STAGE_BYTES;
+        char* sX = sW + BN * ROWB;
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) *(u32x4*)(sW + (j * NT + tid) * 16) = wreg[j];
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j) *(u32x4*)(sX + (j * NT + tid) * 16) = xreg[j];
+    };
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* sW = smem + (kt & 1) * STAGE_BYTES;
+        const char* sX = sW + BN * ROWB;
         u32x4 wf[2][TN], xf[2][TM];
-        auto read_frags = [&](int buf, int s) {
-            const int coff = ((2 * s + hi) ^ sw) << 4;
+        auto read_frags = [&](int buf, int st) {
+            const int coff = ((2 * st + hi) ^ sw) << 4;
 #pragma unroll
-            for (int a = 0; a < TN; ++a) wf[buf][a] = *(const u32x4*)(sW + w_row_off + a * 32 * ROWB + coff);
+            for (int a2 = 0; a2 < TN; ++a2) wf[buf][a2] = *(const u32x4*)(sW + w_row_off + a2 * 32 * ROWB + coff);
 #pragma unroll
-            for (int b = 0; b < TM; ++b) xf[buf][b] = *(const u32x4*)(sX + x_row_off + b * 32 * ROWB + coff);
+            for (int b2 = 0; b2 < TM; ++b2) xf[buf][b2] = *(const u32x4*)(sX + x_row_off + b2 * 32 * ROWB + coff);
         };
         read_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            if (s < BK / 16 - 1) read_frags((s + 1) & 1, s + 1);
-            if constexpr (kStag) {
-                // group 0 issues its halves at steps 0,1 ; group 1 at steps 2,3
-                if (do_load && (s >> 1) == grp) {
-                    const int h = s & 1;
-                    load_part(lstage, lkt, h * (W_LOADS / 2), (h + 1) * (W_LOADS / 2), h * (X_LOADS / 2), (h + 1) * (X_LOADS / 2));
-                }
-            }
+        for (int st = 0; st < BK / 16; ++st) {
+            if (st < BK / 16 - 1) read_frags((st + 1) & 1, st + 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
+            for (int a2 = 0; a2 < TN; ++a2)
 #pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma32(wf[s & 1][a], xf[s & 1][b], acc[a][b]);
-            if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(0);
+                for (int b2 = 0; b2 < TM; ++b2) acc[a2][b2] = T::mfma32(wf[st & 1][a2], xf[st & 1][b2], acc[a2][b2]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (kt + 1 < nk) lwrite((kt + 1) & 1);          // slot (kt+1)&1 was last read in iteration kt-1
+        __syncthreads();
     }
+  } else {
+  #pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s)
+          if (s < nk) load_stage(s, s);
+
+      for (int kt = 0; kt < nk; ++kt) {
+          const int rem = min(STAGES - 2, nk - 1 - kt);
+          // tile kt must have landed; up to `rem` younger tiles may stay in flight (loads return in order)
+          if constexpr (STAGES == 2) {
+              wait_vmcnt<0>();
+          } else if constexpr (STAGES == 3) {
+              if (rem >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+          } else if constexpr (STAGES == 4) {
+              if (rem >= 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+          } else {
+              if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+          }
+          if constexpr (STAG != 4) __builtin_amdgcn_s_barrier();
+          const bool do_load = (STAG != 3 && STAG != 4) && (kt + STAGES - 1 < nk);
+          const int lstage = (kt + STAGES - 1) % STAGES, lkt = kt + STAGES - 1;
+          if constexpr (!kStag && !kInter) { if (do_load) load_stage(lstage, lkt); }
+
+          const char* sW = smem + (kt % STAGES) * STAGE_BYTES;
+          const char* sX = sW + BN * ROWB;
+          // fragments of k16-step s+1 are read before the MFMAs of step s (software pipeline in regs)
+          u32x4 wf[2][TN], xf[2][TM];
+          auto read_frags = [&](int buf, int s) {
+              const int coff = ((2 * s + hi) ^ sw) << 4;
+  #pragma unroll
+              for (int a = 0; a < TN; ++a) wf[buf][a] = *(const u32x4*)(sW + w_row_off + a * 32 * ROWB + coff);
+  #pragma unroll
+              for (int b = 0; b < TM; ++b) xf[buf][b] = *(const u32x4*)(sX + x_row_off + b * 32 * ROWB + coff);
+          };
+          read_frags(0, 0);
+  #pragma unroll
+          for (int s = 0; s < BK / 16; ++s) {
+              if (s < BK / 16 - 1) read_frags((s + 1) & 1, s + 1);
+              if constexpr (kStag) {
+                  // group 0 issues its halves at steps 0,1 ; group 1 at steps 2,3
+                  if (do_load && (s >> 1) == grp) {
+                      const int h = s & 1;
+                      load_part(lstage, lkt, h * (W_LOADS / 2), (h + 1) * (W_LOADS / 2), h * (X_LOADS / 2), (h + 1) * (X_LOADS / 2));
+                  }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(1);
+              if constexpr (kInter) {
+  #pragma unroll
+                  for (int i = 0; i < NMF; ++i) {
+                      const int a = i / TM, b = i % TM;
+                      acc[a][b] = T::mfma32(wf[s & 1][a], xf[s & 1][b], acc[a][b]);
+                      if (i % GAP == (GAP > 1 ? 1 : 0)) {
+                          __builtin_amdgcn_sched_barrier(0);
+                          const int q = s * (NPIECE / NS) + i / GAP;              // piece index: W loads first, then X loads
+                          if (do_load) {
+                              if (q < W_LOADS) load_part(lstage, lkt, q, q + 1, 0, 0);
+                              else load_part(lstage, lkt, 0, 0, q - W_LOADS, q - W_LOADS + 1);
+                          }
+                          __builtin_amdgcn_sched_barrier(0);
+                      }
+                  }
+              } else {
+  #pragma unroll
+                  for (int a = 0; a < TN; ++a)
+  #pragma unroll
+                      for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma32(wf[s & 1][a], xf[s & 1][b], acc[a][b]);
+              }
+              if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(0);
+              __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+
+  }
 
     // ---- epilogue -----------------------------------------------------------------------------
     // Row-major outputs are staged through LDS (the stage ring is free now) and leave as whole-row
@@ -489,8 +623,17 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
-        case 13: if constexpr (MODE == MODE_PLAIN && !REPKV) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 3>(p, batch, st); else return VIDI_ERR_ARG;
-        case 14: if constexpr (MODE == MODE_PLAIN && !REPKV) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 4>(p, batch, st); else return VIDI_ERR_ARG;
+        // ---- experimental / diagnostic schedules (only with VIDI_GEMM_EXPERIMENTAL=1; see profiles/r1_gemm_pmc.md) ----
+        case 9: if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
+                return launch_cfg<T, 256, 256, 2, 4, 4, MODE, REPKV, 32, 9>(p, batch, st);      // ping-pong schedule (correct results)
+        case 8: case 13:                                                                       // diagnostics: WRONG results
+            if constexpr (MODE == MODE_PLAIN && !REPKV) {
+                if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
+                if (tile_cfg == 8) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 8>(p, batch, st);   // DMA always re-reads K slice 0
+                return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 3>(p, batch, st);                        // no DMA in the loop
+            } else {
+                return VIDI_ERR_ARG;
+            }
         // (deeper BK=32 rings, staggered DMA issue and 2-blocks/CU 128x256 tiles were measured slower on MI355X —
         //  DESIGN.md 'GEMM experiments' — the template parameters BK / STAG remain for future schedules)
         default: return VIDI_ERR_ARG;
