@@ -208,7 +208,17 @@ def main():
         roof = {"kernel": "gemm_kernel (MFMA 32x32x16, all GEMM launches of the timed steps)", "bound": "mfma",
                 "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
                 "launches": gm["launches"], "avg_launch_ms": gm["ms"] / gm["launches"],
-                "algorithmic_flop_per_launch_avg": gm["work"] / gm["launches"]}
+                "algorithmic_flop_per_launch_avg": gm["work"] / gm["launches"],
+                "algorithmic_bytes_per_launch_avg": gm["bytes"] / gm["launches"]}
+        # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+        # command (tools/traffic_from_pmc.py -> profiles/); PMC passes cannot run inside the timed region, so the
+        # committed summary is attached when it was taken on this workload (same GEMM launch count per step).
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            tj = json.load(open(tpath))
+            if tj.get("frames") == T and tj.get("launches_fetch_pass") == gm["launches"] // a.steps:
+                roof["traffic"] = tj["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per GEMM launch)"
     fams = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
                 ("TFLOP/s" if v["unit"] == "flop" else "GB/s"): (v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9)) if v["ms"] > 0 else 0.0}
             for k, v in fam.items()}

@@ -101,7 +101,7 @@ int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Np
 /* Text->video / text->audio cross-attention, split-KV partial pass (flash_attn_func /
  * flash_attn_varlen_func: lmm/dattn/xattn.py:123,253 via gemma.py:81-91).  Rows r = token*G + g
  * for each kv head; keys [key_start, key_start+n_keys) of the tiled caches; mask: optional
- * uint8[n_keys] key-padding mask (image/audio_attention_mask).  Writes W = 4*zsplit partials:
+ * uint8[n_keys] key-padding mask (image/audio_attention_mask).  Writes W = zsplit partials (one per block):
  * Opart:[W][nkv][Rpad][HD] fp32, ML:[W][nkv][Rpad][2] fp32 (base-2 running max, sum). */
 size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD);
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,

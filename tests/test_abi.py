@@ -38,7 +38,7 @@ def test_python_binding_covers_the_header(lib_path):
     bound = set(hip.SIGNATURES) | {"vidi_abi_version", "vidi_build_info", "vidi_attn_cross_workspace_bytes"}
     assert set(header_symbols()) == bound, set(header_symbols()) ^ bound
     lib = hip.load_library()
-    assert lib.vidi_attn_cross_workspace_bytes(2, 8, 32, 256) == 8 * 8 * 32 * 258 * 4
+    assert lib.vidi_attn_cross_workspace_bytes(2, 8, 32, 256) == 2 * 8 * 32 * 258 * 4
 
 
 def test_argument_validation_without_gpu(lib_path):

@@ -38,7 +38,7 @@ def dev(t):
 # GEMM family
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_gemm_plain_tiles(hip, dt, cfg):
     """asymmetric operands, M/N not multiples of the tile, bias"""
     M, N, K = 300, 352, 192
@@ -48,7 +48,7 @@ def test_gemm_plain_tiles(hip, dt, cfg):
     report(f"gemm cfg{cfg}", y, ref, *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4])
 def test_gemm_large_k_and_auto(hip, cfg):
     dt = torch.bfloat16
     M, N, K = 1000, 1152, 4352
@@ -93,17 +93,18 @@ def test_gemm_batched_overlapping_rows(hip):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_repkv(hip, dt):
+@pytest.mark.parametrize("cfg", [-1, 2, 4])
+def test_gemm_repkv(hip, dt, cfg):
     nkv, G, hd, H, M = 2, 2, 128, 256, 150
     v = seeded((M, nkv * hd), 14, dtype=dt); wo = seeded((H, nkv * G * hd), 15, 0.05, dtype=dt)
     vrep = O.repeat_kv(v.float().view(1, M, nkv, hd).transpose(1, 2), G).transpose(1, 2).reshape(M, -1)
     ref = vrep @ wo.float().T
-    y = hip.gemm(dev(v), dev(wo), None, repkv=(hd, G), K=G * nkv * hd)
+    y = hip.gemm(dev(v), dev(wo), None, repkv=(hd, G), K=G * nkv * hd, tile_cfg=cfg)
     report("gemm repkv", y, ref, *tol(dt, ref.std().item()))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4])
 def test_gemm_geglu(hip, dt, cfg):
     M, I, K = 200, 256, 128
     x = seeded((M, K), 16, dtype=dt); g = seeded((I, K), 17, 0.1, dtype=dt); u = seeded((I, K), 18, 0.1, dtype=dt)
@@ -113,8 +114,9 @@ def test_gemm_geglu(hip, dt, cfg):
     report("gemm geglu", y, ref, *tol(dt, ref.std().item()))
 
 
+@pytest.mark.parametrize("cfg", [-1, 2, 4])
 @pytest.mark.parametrize("hd,N,nh", [(72, 729, 4), (16, 49, 4), (64, 50, 2)])
-def test_gemm_qkv_vt(hip, hd, N, nh):
+def test_gemm_qkv_vt(hip, hd, N, nh, cfg):
     dt = torch.bfloat16
     B, Hd = 2, nh * hd
     K = 64 if Hd <= 64 else 192
@@ -125,13 +127,14 @@ def test_gemm_qkv_vt(hip, hd, N, nh):
     ref = F.linear(x.float(), w.float(), b.float())
     yqk = torch.zeros((B * N, 2 * Hd), dtype=dt).cuda()
     vt = torch.zeros((B, nh, hd, Npad), dtype=dt).cuda()
-    hip.gemm_qkv_vt(dev(x), dev(w), dev(b), yqk, vt, vstart=2 * Hd, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+    hip.gemm_qkv_vt(dev(x), dev(w), dev(b), yqk, vt, vstart=2 * Hd, hd=hd, seq=N, seqpad=Npad, nheads=nh, tile_cfg=cfg)
     report("qkv_vt QK", yqk, ref[:, : 2 * Hd], *tol(dt, ref.std().item()))
     v = unpack_vt(vt.cpu(), N).reshape(B * N, Hd)
     report("qkv_vt V", v, ref[:, 2 * Hd:], *tol(dt, ref.std().item()))
 
 
-def test_gemm_kv_cache(hip):
+@pytest.mark.parametrize("cfg", [-1, 2, 4])
+def test_gemm_kv_cache(hip, cfg):
     dt = torch.bfloat16
     nkv, hd, K, M, tok0 = 2, 128, 128, 170, 64
     kvd = nkv * hd
@@ -140,7 +143,7 @@ def test_gemm_kv_cache(hip):
     ref = x.float() @ w.float().T
     kc = torch.zeros((nkv, ntile, 64, hd), dtype=dt).cuda(); vtc = torch.zeros((nkv, ntile, hd, 64), dtype=dt).cuda()
     vrow = torch.zeros((M, kvd), dtype=dt).cuda()
-    hip.gemm_kv_cache(dev(x), dev(w), kc, vtc, vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=tok0)
+    hip.gemm_kv_cache(dev(x), dev(w), kc, vtc, vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=tok0, tile_cfg=cfg)
     kref, vtref = pack_kv_cache(ref[:, :kvd].view(M, nkv, hd), ref[:, kvd:].view(M, nkv, hd), ntile, tok0)
     a, r = tol(dt, ref.std().item())
     report("kv_cache Vrow", vrow, ref[:, kvd:], a, r)
@@ -223,7 +226,7 @@ def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
     hip.attn_cross(qd, dev(kc), dev(vtc), dev(mpad) if masked else None, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD,
                    ntile64=ntile, key_start=start, n_keys=N, scale=scale, softcap=softcap, zsplit=zsplit)
     out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
-    hip.attn_merge(opart, ml, out, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+    hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
     report("attn_cross", out, ref, *tol(dt, 0.05))
 
 
@@ -244,13 +247,13 @@ def test_attn_cross_split_invariance(hip):
                        n_keys=N, scale=HD ** -0.5, softcap=50.0, zsplit=zs)
         po = torch.zeros((nkv, 32, HD), dtype=torch.float32, device="cuda")
         pml = torch.zeros((nkv, 32, 2), dtype=torch.float32, device="cuda")
-        hip.attn_merge(opart, ml, None, W=4 * zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD, out_f32=po, out_ml=pml, dtype=0)
+        hip.attn_merge(opart, ml, None, W=zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD, out_f32=po, out_ml=pml, dtype=0)
         # second-level merge of the partial form (what the multi-GPU path does with all-gathered partials)
         o = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda")
         hip.attn_merge(po[None].contiguous(), pml[None].contiguous(), o, W=1, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD)
         outs.append((po[:, : Lq * G] / pml[:, : Lq * G, 1:2]).clone())
         o1 = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda")
-        hip.attn_merge(opart, ml, o1, W=4 * zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD)
+        hip.attn_merge(opart, ml, o1, W=zs, nkv=nkv, R=Lq * G, Rpad=32, G=G, HD=HD)
         assert torch.equal(o.cpu(), o1.cpu()), "two-level merge must equal the direct merge"
     report("split invariance", outs[0], outs[1], 2e-4, 1e-3)
 

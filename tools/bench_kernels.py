@@ -74,7 +74,7 @@ def main():
             def f():
                 hip.attn_cross(q, kc, vtc, None, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD, ntile64=ntile, key_start=0,
                                n_keys=Nk, scale=HD ** -0.5, softcap=50.0, zsplit=zs)
-                hip.attn_merge(opart, ml, o, W=4 * zs, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+                hip.attn_merge(opart, ml, o, W=zs, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
             ms = timeit(f)
             out.append({"kernel": "attn_cross+merge", "Lq": Lq, "keys": Nk, "zsplit": zs, "ms": ms,
                         "GBps": Nk * 2 * nkv * HD * 2 / ms / 1e6})

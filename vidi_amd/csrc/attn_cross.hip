@@ -12,8 +12,9 @@
 //     by the KV-projection GEMM epilogue.  A wave's 32-key sub-tile is 16 KB + 16 KB of perfectly
 //     linear 16-byte global_load_lds DMA.
 //   * split-KV at WAVE granularity: every wave owns a contiguous key range and its private 32 KB
-//     LDS ring, runs its own online softmax (no block barriers in the loop) and emits one partial
-//     (O, m, l); `attn_merge_kernel` combines partials (exact: the tanh softcap is per logit).
+//     LDS ring and runs its own online softmax (no block barriers in the loop); the 4 waves of a block are merged
+//     in LDS and the block emits one partial (O, m, l); `attn_merge_kernel` combines the blocks' partials (exact:
+//     the tanh softcap is per logit).
 //   * swapped MFMAs (S^T = K Q^T, O^T = Vt P^T): per-lane softmax statistics, P stays in registers.
 #include "kernels.h"
 
@@ -217,23 +218,47 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
         if (has_next) issue_v(st + 1);
     }
 
-    // ---- emit this wave's partial ---------------------------------------------------------------
+    // ---- merge the block's 4 waves in LDS (their private K/V rings are free now) and emit ONE partial ---------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const int r = r0 + l31;
-    if (r < p.R) {
-        const size_t base = ((size_t)wg * p.nkv + kvh) * p.Rpad + r;
-        if (hi == 0) {
-            p.ML[base * 2] = m_run;          // base-2 logit units
-            p.ML[base * 2 + 1] = l_tot;
+    float* so = (float*)sK;                                   // [32 rows][HD] fp32 = exactly this wave's ring bytes
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 ov = {o[dt][4 * j], o[dt][4 * j + 1], o[dt][4 * j + 2], o[dt][4 * j + 3]};
+            *(f32x4*)(so + l31 * HD + dt * 32 + 8 * j + 4 * hi) = ov;
         }
-        float* orow = p.Opart + base * HD;
+    float* sml = (float*)sQ;                                  // Q tile is dead (fragments live in registers)
+    if (hi == 0) {
+        sml[(wave * 32 + l31) * 2] = m_run;                   // base-2 logit units
+        sml[(wave * 32 + l31) * 2 + 1] = l_tot;
+    }
+    __syncthreads();
+    const float* so_all = (const float*)(smem + 32 * QROW);
+    constexpr int WSTRIDE = (KBYTES + VBYTES) / 4;            // floats between two waves' tiles
+    for (int idx = tid; idx < 32 * (HD / 4); idx += 256) {
+        const int row = idx / (HD / 4), c4 = idx % (HD / 4);
+        const int r = r0 + row;
+        if (r >= p.R) continue;
+        float mw[4], m = -INFINITY;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int w = 0; w < 4; ++w) { mw[w] = sml[(w * 32 + row) * 2]; m = fmaxf(m, mw[w]); }
+        f32x4 accv = {0.f, 0.f, 0.f, 0.f};
+        float l = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 ov = {o[dt][4 * j], o[dt][4 * j + 1], o[dt][4 * j + 2], o[dt][4 * j + 3]};
-                *(f32x4*)(orow + dt * 32 + 8 * j + 4 * hi) = ov;
-            }
+        for (int w = 0; w < 4; ++w) {
+            if (mw[w] == -INFINITY) continue;
+            const float scw = fast_exp2(mw[w] - m);
+            const f32x4 v = *(const f32x4*)(so_all + w * WSTRIDE + row * HD + c4 * 4);
+            accv += v * scw;
+            l += scw * sml[(w * 32 + row) * 2 + 1];
+        }
+        const size_t base = ((size_t)blockIdx.z * p.nkv + kvh) * p.Rpad + r;
+        *(f32x4*)(p.Opart + base * HD + c4 * 4) = accv;
+        if (c4 == 0) {
+            p.ML[base * 2] = m;
+            p.ML[base * 2 + 1] = l;
+        }
     }
 }
 
@@ -247,6 +272,7 @@ __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
     for (int w = 0; w < p.W; ++w) m = fmaxf(m, p.ML[(((size_t)w * p.nkv + kvh) * p.Rpad + r) * 2]);
     float num = 0.f, den = 0.f;
     if (m != -INFINITY) {
+#pragma unroll 8
         for (int w = 0; w < p.W; ++w) {
             const size_t base = ((size_t)w * p.nkv + kvh) * p.Rpad + r;
             const float mw = p.ML[base * 2];

@@ -100,7 +100,7 @@ int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Np
 }
 
 size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD) {
-    const size_t W = (size_t)zsplit * 4;
+    const size_t W = (size_t)zsplit;           // one partial per block (its 4 waves are merged in LDS)
     return W * nkv * Rpad * (size_t)(HD + 2) * sizeof(float);
 }
 

@@ -15,10 +15,17 @@
 
 
 
-template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int BK = 64, int STAG = 0>
+template <int MI> struct AccOf { typedef f32x16 type; };
+template <> struct AccOf<16> { typedef f32x4 type; };
+
+// MI selects the matrix instruction: 32 -> v_mfma_f32_32x32x16 (k16 steps), 16 -> v_mfma_f32_16x16x32 (k32 steps).
+// Both run at the same peak rate, but the 16x16x32 form moves half the accumulator registers per FLOP and was
+// measured to sustain ~12 % more under the chip's power limit on random data (tools/micro/mfma_power.hip).
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int BK = 64, int STAG = 0, int MI = 32>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int NT = WN * WM * 64;
-    constexpr int TN = BN / WN / 32, TM = BM / WM / 32;
+    constexpr int TN = BN / WN / MI, TM = BM / WM / MI;
+    static_assert(MI == 32 || (MI == 16 && STAG == 0 && BK == 64 && TM <= TN), "MI");
     constexpr int CPR = BK / 8;                       // 16-byte chunks per LDS row (8 for BK=64, 4 for BK=32)
     constexpr int CSH = (CPR == 8) ? 3 : 2;
     constexpr int ROWB = BK * 2;                      // LDS row bytes
@@ -28,7 +35,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int STAGE_BYTES = (BN + BM) * ROWB;
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(BN * CPR % NT == 0 && BM * CPR % NT == 0, "tile/threads mismatch");
-    static_assert(MODE != MODE_GEGLU || (TN % 2 == 0), "GeGLU needs gate/up tile pairs per wave");
+    static_assert(MODE != MODE_GEGLU || ((TN * MI) % 64 == 0), "GeGLU needs whole 32-gate/32-up row blocks per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -105,18 +112,19 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr bool kStag = (STAG != 0) && (STAG != 7) && (NS == 4) && (W_LOADS % 2 == 0) && (X_LOADS % 2 == 0) && (WN * WM == 8);
     const int grp = (wave >= (WN * WM) / 2) ? 1 : 0;
 
-    f32x16 acc[TN][TM];
+    typename AccOf<MI>::type acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+            for (int i = 0; i < (MI == 32 ? 16 : 4); ++i) acc[a][b][i] = 0.f;
 
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int sw = (l31 >> SWSH) & (CPR - 1);              // row swizzle (tile bases are multiples of 32)
-    const int w_row_off = (wn * TN * 32 + l31) * ROWB;
-    const int x_row_off = (wm * TM * 32 + l31) * ROWB;
+    // lane -> (row inside an MI-row tile, 8-element k chunk): 32x32x16 = 32 rows x 2 chunks, 16x16x32 = 16 rows x 4 chunks
+    const int l31 = (MI == 32) ? (lane & 31) : (lane & 15), hi = (MI == 32) ? (lane >> 5) : (lane >> 4);
+    const int sw = (l31 >> SWSH) & (CPR - 1);              // row swizzle (tile bases are multiples of 16)
+    const int w_row_off = (wn * TN * MI + l31) * ROWB;
+    const int x_row_off = (wm * TM * MI + l31) * ROWB;
 
     const int nk = p.K / BK;
   if constexpr (STAG == 9) {
@@ -251,6 +259,32 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
 
           const char* sW = smem + (kt % STAGES) * STAGE_BYTES;
           const char* sX = sW + BN * ROWB;
+          if constexpr (MI == 16) {
+              // k32 steps; W fragments are refilled in place right after their last MFMA of the step, X fragments
+              // are double-buffered (register budget: 2 waves/SIMD = 256 VGPRs, 128 of them accumulators)
+              constexpr int NS16 = BK / 32;
+              u32x4 wf[TN], xf[2][TM];
+              auto rdW = [&](int a, int s) { return *(const u32x4*)(sW + w_row_off + a * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
+              auto rdX = [&](int b, int s) { return *(const u32x4*)(sX + x_row_off + b * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
+  #pragma unroll
+              for (int b = 0; b < TM; ++b) xf[0][b] = rdX(b, 0);
+  #pragma unroll
+              for (int a = 0; a < TN; ++a) wf[a] = rdW(a, 0);
+  #pragma unroll
+              for (int s = 0; s < NS16; ++s) {
+  #pragma unroll
+                  for (int a = 0; a < TN; ++a) {
+                      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+                      for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma16(wf[a], xf[s & 1][b], acc[a][b]);
+                      if (s + 1 < NS16) {
+                          wf[a] = rdW(a, s + 1);
+                          if (a < TM) xf[(s + 1) & 1][a] = rdX(a, s + 1);
+                      }
+                  }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+          } else {
           // fragments of k16-step s+1 are read before the MFMAs of step s (software pipeline in regs)
           u32x4 wf[2][TN], xf[2][TM];
           auto read_frags = [&](int buf, int s) {
@@ -297,6 +331,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
               if constexpr (STAG == 2) __builtin_amdgcn_s_setprio(0);
               __builtin_amdgcn_sched_barrier(0);
           }
+          }   // MI == 32
       }
 
   }
@@ -313,21 +348,25 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int CROW = BNO * 2 + 16;                            // padded LDS row (bytes)
     __syncthreads();                                              // every wave is done with the last K slice
     char* sC = smem;
+    constexpr int NQ = (MI == 32) ? 4 : 1;                        // 4-row quads per lane per tile (32x32: rows 8j+4hi+e; 16x16: 4hi+e)
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-        const int ml = wm * TM * 32 + b * 32 + l31;               // row inside the tile
+        const int ml = wm * TM * MI + b * MI + l31;               // row inside the tile
         const int m = m0 + ml;
         if constexpr (MODE == MODE_GEGLU) {
+            // W rows are interleaved in blocks of 32 gate / 32 up rows: pair every gate quad with its up quad
+            constexpr int TPB = 32 / MI;                          // MI-row tiles per 32-row block
 #pragma unroll
-            for (int a = 0; a < TN; a += 2) {
+            for (int a = 0; a < TN; ++a) {
+                if ((a / TPB) % 2) continue;                      // up tiles are consumed with their gate tile
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nol = ((wn * TN * 32 + a * 32) >> 1) + 8 * j + 4 * hi;      // output column inside the tile
+                for (int j = 0; j < NQ; ++j) {
+                    const int nol = ((wn * TN * MI) >> 1) + (a / (2 * TPB)) * 32 + (a % TPB) * MI + 8 * j + 4 * hi;   // output column inside the tile
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float g = rnd<T>(acc[a][b][4 * j + e]);
-                        const float u = rnd<T>(acc[a + 1][b][4 * j + e]);
+                        const float u = rnd<T>(acc[a + TPB][b][4 * j + e]);
                         v[e] = rnd<T>(gelu_tanh_f(g)) * u;
                     }
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
@@ -338,8 +377,8 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nl = wn * TN * 32 + a * 32 + 8 * j + 4 * hi;
+                for (int j = 0; j < NQ; ++j) {
+                    const int nl = wn * TN * MI + a * MI + 8 * j + 4 * hi;
                     const int n = n0 + nl;
                     if (n >= p.N) continue;
                     float v[4];
@@ -585,12 +624,12 @@ static hipError_t set_lds(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int BK = 64, int STAG = 0>
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int BK = 64, int STAG = 0, int MI = 32>
 static int launch_cfg(const GemmParams& p, int batch, hipStream_t st) {
     constexpr int RING = STAGES * (BN + BM) * BK * 2;
     constexpr int CTILE = BM * ((MODE == MODE_GEGLU ? BN / 2 : BN) * 2 + 16);
     constexpr int LDS = RING > CTILE ? RING : CTILE;
-    auto kern = gemm_kernel<T, BN, BM, WN, WM, STAGES, MODE, REPKV, BK, STAG>;
+    auto kern = gemm_kernel<T, BN, BM, WN, WM, STAGES, MODE, REPKV, BK, STAG, MI>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = set_lds(kern, LDS);
@@ -615,14 +654,16 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
     }
     if (tile_cfg < 0) {
         // measured on MI355X (tools/bench_gemm.py): the 256x256 tile wins from ~1 wave of blocks up, also when
-        // N is not a multiple of 256 (edge tiles are masked); small problems take the 128x128 tile.
+        // N is not a multiple of 256 (edge tiles are masked); small problems take the 128x128 tile.  The
+        // 16x16x32-MFMA body (cfg 4) beats the 32x32x16 one (cfg 2) by 12-20 % on every large shape (power-limited chip).
         const long long t256 = (long long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-        tile_cfg = (t256 >= 192) ? 2 : 0;
+        tile_cfg = (t256 >= 192) ? 4 : 0;
     }
     switch (tile_cfg) {
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
+        case 4: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 0, 16>(p, batch, st);       // 16x16x32 MFMA
         // ---- experimental / diagnostic schedules (only with VIDI_GEMM_EXPERIMENTAL=1; see profiles/r1_gemm_pmc.md) ----
         case 9: if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
                 return launch_cfg<T, 256, 256, 2, 4, 4, MODE, REPKV, 32, 9>(p, batch, st);      // ping-pong schedule (correct results)

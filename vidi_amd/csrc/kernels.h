@@ -40,7 +40,7 @@ struct AttnSelfParams {
 struct AttnCrossParams {
     const u16* Q;            // [tokens_q, ldq]; head (kvh*G+g) at column (kvh*G+g)*HD
     const u16* Kc; const u16* Vtc; const unsigned char* mask;   // mask: [n_keys] (1 = valid) or null
-    float* Opart; float* ML; // Opart[W][nkv][Rpad][HD], ML[W][nkv][Rpad][2]
+    float* Opart; float* ML; // Opart[zsplit][nkv][Rpad][HD], ML[zsplit][nkv][Rpad][2] (one partial per block)
     int R;                   // query rows per kv head = tokens_q * G
     int Rpad;                // R rounded up to 32
     int G, nkv, ldq;

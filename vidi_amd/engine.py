@@ -508,7 +508,7 @@ class VidiEngine:
                            key_start=start, n_keys=n, scale=cfg.query_pre_attn_scalar ** -0.5,
                            softcap=cfg.attn_logit_softcapping, zsplit=zsplit)
         if self.world == 1:
-            hip.attn_merge(opart, ml, out, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+            hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
             return
         # ---- keys are sharded over ranks: local merge -> partial form -> all-gather -> exact LSE merge ----
         import torch.distributed as dist
@@ -520,7 +520,7 @@ class VidiEngine:
                             torch.zeros((self.world, nkv, Rpad, 2), dtype=torch.float32, device=self.dev))
         po, pml, gpo, gpml = self._ws[pk]
         if n > 0:
-            hip.attn_merge(opart, ml, None, W=4 * zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, out_f32=po, out_ml=pml,
+            hip.attn_merge(opart, ml, None, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, out_f32=po, out_ml=pml,
                            dtype=hip._dt(out))
         else:                                   # this rank holds no key of the modality: neutral partial
             po.zero_()

@@ -106,6 +106,19 @@ def _work(name, a):
     return "other", 0.0, "none"
 
 
+def _alg_bytes(name, a):
+    """Algorithmic HBM bytes of one GEMM-family launch: X + W + Y once each (2-byte elements)."""
+    if name == "vidi_gemm":
+        return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6]) * a[16]
+    if name == "vidi_gemm_geglu":
+        return 2.0 * (a[3] * a[5] + 2 * a[4] * a[5] + a[3] * a[4])
+    if name == "vidi_gemm_qkv_vt":
+        return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6])
+    if name == "vidi_gemm_kv_cache":
+        return 2.0 * (a[5] * a[7] + 2 * a[6] * a[7] + 2 * a[5] * a[6])
+    return 0.0
+
+
 class _Timed:
     def __init__(self, fn, name):
         self.fn, self.name = fn, name
@@ -130,14 +143,15 @@ class KernelTimer:
         e0.record()
         rc = fn(*a)
         e1.record()
-        self.rec.append((fam, work, unit, e0, e1))
+        self.rec.append((fam, work, unit, e0, e1, _alg_bytes(name, a)))
         return rc
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, work, unit, e0, e1 in self.rec:
-            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+        for fam, work, unit, e0, e1, nbytes in self.rec:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit, "bytes": 0.0})
+            d["bytes"] += nbytes
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["work"] += work
@@ -266,7 +280,7 @@ def attn_self(qk, vt, out, *, B, N, Npad, H, D, koff, scale):
 
 
 def attn_cross_workspace(zsplit: int, nkv: int, Rpad: int, HD: int, device) -> tuple:
-    W = 4 * zsplit
+    W = zsplit
     opart = torch.empty((W, nkv, Rpad, HD), dtype=torch.float32, device=device)
     ml = torch.empty((W, nkv, Rpad, 2), dtype=torch.float32, device=device)
     return opart, ml
