@@ -15,4 +15,9 @@ else:
     y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     f = lambda: hip.gemm(x, w, None, y, tile_cfg=cfg)
 ms = timeit(f, iters=int(os.environ.get("ITERS", "5")), warm=2)
-print(json.dumps({"M": M, "N": N, "K": K, "cfg": cfg, "ms": ms, "tflops": 2.0 * M * N * K / ms / 1e9}))
+row = {"M": M, "N": N, "K": K, "cfg": cfg, "ms": ms, "tflops": 2.0 * M * N * K / ms / 1e9}
+if os.environ.get("CHECK") and not geglu:          # experimental schedules: compare with the default tile's result
+    y2 = torch.empty_like(y)
+    hip.gemm(x, w, None, y2, tile_cfg=4)
+    row["max_abs_diff_vs_cfg4"] = (y.float() - y2.float()).abs().max().item()
+print(json.dumps(row))

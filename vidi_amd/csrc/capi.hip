@@ -19,6 +19,9 @@ static GemmParams base_params(const void* X, const void* W, const void* bias, vo
         static int gm = -1;
         if (gm < 0) { const char* e = getenv("VIDI_GEMM_GROUP_M"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
         p.group_m = gm;
+        static int dg = -1;
+        if (dg < 0) { const char* e = getenv("VIDI_GEMM_EXPERIMENTAL") ? getenv("VIDI_GEMM_DIAG") : nullptr; dg = e ? atoi(e) : 0; }
+        p.diag = dg;
     }
     return p;
 }

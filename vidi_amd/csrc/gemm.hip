@@ -25,7 +25,10 @@ template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool
 __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int NT = WN * WM * 64;
     constexpr int TN = BN / WN / MI, TM = BM / WM / MI;
-    static_assert(MI == 32 || (MI == 16 && STAG == 0 && BK == 64 && TM <= TN), "MI");
+    static_assert(MI == 32 || (MI == 16 && (STAG == 0 || STAG == 6 || STAG == 7) && BK == 64 && TM <= TN), "MI");
+    // MI == 16 schedules: STAG 0 = DMA issued right after the barrier; 6 = after the first fragment reads;
+    // 7 = one DMA piece after each of the first W_LOADS + X_LOADS row groups of MFMAs
+    constexpr bool kLate16 = (MI == 16) && (STAG == 6 || STAG == 7);
     constexpr int CPR = BK / 8;                       // 16-byte chunks per LDS row (8 for BK=64, 4 for BK=32)
     constexpr int CSH = (CPR == 8) ? 3 : 2;
     constexpr int ROWB = BK * 2;                      // LDS row bytes
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
           if constexpr (STAG != 4) __builtin_amdgcn_s_barrier();
           const bool do_load = (STAG != 3 && STAG != 4) && (kt + STAGES - 1 < nk);
           const int lstage = (kt + STAGES - 1) % STAGES, lkt = kt + STAGES - 1;
-          if constexpr (!kStag && !kInter) { if (do_load) load_stage(lstage, lkt); }
+          if constexpr (!kStag && !kInter && !kLate16) { if (do_load) load_stage(lstage, lkt); }
 
           const char* sW = smem + (kt % STAGES) * STAGE_BYTES;
           const char* sX = sW + BN * ROWB;
@@ -270,6 +273,10 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
               for (int b = 0; b < TM; ++b) xf[0][b] = rdX(b, 0);
   #pragma unroll
               for (int a = 0; a < TN; ++a) wf[a] = rdW(a, 0);
+              if constexpr (STAG == 6) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (do_load) load_stage(lstage, lkt);
+              }
   #pragma unroll
               for (int s = 0; s < NS16; ++s) {
   #pragma unroll
@@ -280,6 +287,16 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                       if (s + 1 < NS16) {
                           wf[a] = rdW(a, s + 1);
                           if (a < TM) xf[(s + 1) & 1][a] = rdX(a, s + 1);
+                      }
+                      if constexpr (STAG == 7) {
+                          constexpr int PPG = (W_LOADS + X_LOADS + TN - 1) / TN;      // pieces per row group
+                          if (s == 0 && do_load) {
+  #pragma unroll
+                              for (int q = a * PPG; q < (a + 1) * PPG && q < W_LOADS + X_LOADS; ++q) {
+                                  if (q < W_LOADS) load_part(lstage, lkt, q, q + 1, 0, 0);
+                                  else load_part(lstage, lkt, 0, 0, q - W_LOADS, q - W_LOADS + 1);
+                              }
+                          }
                       }
                   }
               }
@@ -347,8 +364,23 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int BNO = (MODE == MODE_GEGLU) ? BN / 2 : BN;       // output columns of this tile
     constexpr int CROW = BNO * 2 + 16;                            // padded LDS row (bytes)
     __syncthreads();                                              // every wave is done with the last K slice
+    if (p.diag == 2) return;
     char* sC = smem;
     constexpr int NQ = (MI == 32) ? 4 : 1;                        // 4-row quads per lane per tile (32x32: rows 8j+4hi+e; 16x16: 4hi+e)
+    // this lane's bias quads (one 8-byte load per n-quad, shared by all its m-tiles)
+    const bool has_bias = (MODE != MODE_GEGLU) && (p.bias != nullptr);
+    u32x2 bq[TN][NQ];
+    if constexpr (MODE != MODE_GEGLU) {
+        if (has_bias) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const int n = n0 + wn * TN * MI + a * MI + 8 * j + 4 * hi;
+                    bq[a][j] = *(const u32x2*)(p.bias + min(n, p.N - 4));
+                }
+        }
+    }
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const int ml = wm * TM * MI + b * MI + l31;               // row inside the tile
@@ -384,19 +416,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * j + e];
-                    if (p.bias) {
-                        const u32x2 bv = *(const u32x2*)(p.bias + n);
+                    if (has_bias) {
+                        const u32x2 bv = bq[a][j];
                         v[0] += T::to_f32((u16)(bv[0] & 0xffff)); v[1] += T::to_f32((u16)(bv[0] >> 16));
                         v[2] += T::to_f32((u16)(bv[1] & 0xffff)); v[3] += T::to_f32((u16)(bv[1] >> 16));
                     }
-                    if (act_tanh) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(rnd<T>(v[e]));
-                    }
-                    if (act_erf) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(rnd<T>(v[e]));
-                    }
+                    // (the activation runs in the copy-out pass on the T-rounded staged values — same arithmetic,
+                    //  but one small loop body instead of TN*TM*NQ unrolled copies that overflowed the I-cache)
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                     bool staged = true;
                     if constexpr (MODE == MODE_QKV_VT) {
@@ -437,6 +463,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
         if (m >= p.M || n >= Nout) continue;
         if constexpr (MODE == MODE_QKV_VT) { if (n >= p.vstart) continue; }
         u32x4 val = *(const u32x4*)(sC + ml * CROW + c * 16);
+        if (p.diag == 1 && val[0] != 0x12345678u) continue;
         if constexpr (MODE == MODE_KV_CACHE) {
             if (n < p.kvd) {
                 const int tok = p.tok0 + m, kvh = n / p.hd, d = n % p.hd;
@@ -445,6 +472,19 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                 *(u32x4*)(p.Vrow + (size_t)m * p.kvd + (n - p.kvd)) = val;
             }
         } else {
+            if (act_tanh) {
+                float x[8];
+                unpack8<T>(val, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = gelu_tanh_f(x[e]);
+                val = pack8<T>(x);
+            } else if (act_erf) {
+                float x[8];
+                unpack8<T>(val, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = gelu_erf_f(x[e]);
+                val = pack8<T>(x);
+            }
             if (Rb) {
                 float x[8], r[8];
                 unpack8<T>(val, x);
@@ -663,7 +703,15 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
-        case 4: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 0, 16>(p, batch, st);       // 16x16x32 MFMA
+        case 4: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 6, 16>(p, batch, st);       // 16x16x32 MFMA, DMA issued after the first fragment reads
+        case 5: case 6:                                                                               // other DMA placements (same results)
+            if constexpr (MODE == MODE_PLAIN && !REPKV) {
+                if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
+                if (tile_cfg == 5) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 7, 16>(p, batch, st);
+                return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 0, 16>(p, batch, st);
+            } else {
+                return VIDI_ERR_ARG;
+            }
         // ---- experimental / diagnostic schedules (only with VIDI_GEMM_EXPERIMENTAL=1; see profiles/r1_gemm_pmc.md) ----
         case 9: if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
                 return launch_cfg<T, 256, 256, 2, 4, 4, MODE, REPKV, 32, 9>(p, batch, st);      // ping-pong schedule (correct results)
