@@ -12,34 +12,42 @@
 // Per block: one (batch item, head, 128-query tile); 4 waves x 32 queries.  Scores are computed
 // "swapped" (S^T = K Q^T) so each lane owns one query column: softmax statistics are per lane,
 // P feeds the PV MFMA as the B operand straight from registers, and O^T[d][q] gives 8-byte stores.
-// K/Vt tiles (64 keys) are register-staged into padded, conflict-free LDS rows with the next
-// tile's global loads issued before the current tile's MFMAs.
+// K/Vt tiles (64 keys) arrive by 16-byte LDS-DMA into a 2-deep ring (one barrier per tile); bank
+// conflicts are avoided by permuting the source chunk each lane fetches, not by padding.
+// VALU diet (the exp/convert work is co-dominant with the MFMAs at d = 64..72): scale folded into the
+// exponent FMA, lazy rescaling (accumulators only touched when a maximum grows by > 2^8), cross-half
+// reductions by v_permlane32_swap, softmax denominator accumulated by the PV MFMA through a ones row
+// (d = 72), tail masking only in the last tile.  Built with -amdgpu-mfma-vgpr-form so accumulators
+// stay in architectural VGPRs (150-160 registers -> 3 waves/SIMD).
 //
 // Algorithmic FLOPs = 4*N*N*D per (batch, head).
 #include "kernels.h"
 #include <stdlib.h>
 
 
-template <typename T, int D, int ABL = 0, int NBUF = 2>
+template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
     constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
     constexpr int NCH = D / 8;                 // 16-byte chunks per head row
     constexpr int DT = (D + 31) / 32;          // 32-wide output d tiles
-    constexpr int KCH = (2 * KS) | 1;          // K-tile row stride in chunks (odd => conflict-free)
-    constexpr int KROW = KCH * 16;
-    constexpr int VROW = 9 * 16;               // 64 positions = 8 chunks + 1 pad chunk
-    constexpr int KL = (64 * NCH + 255) / 256; // staging loads per thread (K tile)
-    constexpr int VL = (D * 8 + 255) / 256;    // staging loads per thread (Vt tile)
+    // LDS images are written by 16-byte LDS-DMA (lane-linear), so rows are unpadded and bank conflicts are
+    // avoided by permuting which global chunk each lane fetches: chunk c of row r sits at slot c ^ swz(r).
+    //   K tile  [64 keys][NCH chunks]   (D=72: 144-B rows are conflict-free as they are; slot 9 of the padded
+    //                                    5th k16-step reads the next row's first chunk, multiplied by Q zeros)
+    //   Vt tile [DT*32 rows d][8 chunks of 8 key positions]   (rows >= D are never written: their products land
+    //                                    in output rows that are not stored)
+    constexpr int KBYTES = 64 * NCH * 16, VBYTES = DT * 32 * 128, BUF = KBYTES + VBYTES;
+    constexpr int KRND = (64 * NCH + 255) / 256, VRND = (D * 8 + 255) / 256;
     constexpr int ORW = (NCH % 2 == 0) ? (NCH + 1) * 16 : (NCH + 2) * 16;      // output staging row: odd number of 16-B chunks
-    constexpr int KVBYTES = 64 * KROW + DT * 32 * VROW;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * KVBYTES > 128 * ORW ? NBUF * KVBYTES : 128 * ORW];   // NBUF-deep K/V ring
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW];   // 2-deep K/V ring
+    auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int nqt = (p.N + 127) / 128, per_b = nqt * p.H;
     int qt, h, b;
     {
-        const int L = blockIdx.x, nb = gridDim.x;
+        const int L = blockIdx.x;
         const int nfull = (p.B / 8) * 8;                     // frames that can be dealt round-robin over the 8 XCDs
         // Only when a head's output segment is whole 128-byte lines (D=64): with D=72 the 16 heads write
         // pieces of the SAME lines and co-locating them on one XCD measured 2x slower stores (line contention).
@@ -52,29 +60,20 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
             const int w = L - nfull * per_b;
             b = nfull + w / per_b;
             h = (w % per_b) / nqt; qt = (w % per_b) % nqt;
+        } else if ((p.B * p.H) % 8 == 0) {
+            // D=72: the q-tiles of one (frame, head) run on ONE XCD (they share its K/V through that L2), while
+            // neighbouring heads - whose 144-byte output segments share 128-byte lines - go to different XCDs
+            const int xcd = L & 7, j = L >> 3;
+            const int unit = (j / nqt) * 8 + xcd;
+            qt = j % nqt; b = unit / p.H; h = unit % p.H;
         } else {                                              // q-tile fastest, then head, then frame
             qt = L % nqt; h = (L / nqt) % p.H; b = L / per_b;
         }
-        (void)nb;
     }
     const int q = qt * 128 + wave * 32 + l31;
     const int qc = min(q, p.N - 1);
 
-    // zero the padding that MFMAs read but staging never writes
-    for (int bufi = 0; bufi < NBUF; ++bufi) {
-        char* zK = smem + bufi * KVBYTES;
-        char* zV = zK + 64 * KROW;
-        for (int i = tid; i < 64 * KCH; i += 256) {
-            const int c = i % KCH;
-            if (c >= NCH) *(u32x4*)(zK + (i / KCH) * KROW + c * 16) = u32x4{0, 0, 0, 0};
-        }
-        for (int i = tid; i < DT * 32 * 9; i += 256) {
-            const int d = i / 9, c = i % 9;
-            if (d >= D || c == 8) *(u32x4*)(zV + d * VROW + c * 16) = u32x4{0, 0, 0, 0};
-        }
-    }
-
-    // Q fragments (B operand: column = query, contraction chunk = 2s + hi)
+    // Q fragments (B operand: column = query, contraction chunk = 2s + hi); chunks past D are zero
     u32x4 qf[KS];
     {
         const u16* qrow = p.QK + ((size_t)b * p.N + qc) * p.ldqk + h * D;
@@ -88,37 +87,33 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
     const u16* kbase_ptr = p.QK + (size_t)b * p.N * p.ldqk + p.koff + h * D;
     const u16* vbase_ptr = p.Vt + ((size_t)b * p.H + h) * D * p.Npad;
 
-    u32x4 kreg[KL], vreg[VL];
-    auto issue_loads = [&](int kb) {
+    // per-thread DMA pieces (tile independent): K piece j = (key row, source column), V piece j = source offset
+    int krow[KRND], kcol[KRND];
+    const u16* vsrc[VRND];
 #pragma unroll
-        for (int j = 0; j < KL; ++j) {
-            const int i = j * 256 + tid;
-            if (i < 64 * NCH) {
-                const int key = i / NCH, c = i % NCH;
-                kreg[j] = *(const u32x4*)(kbase_ptr + (size_t)min(kb + key, p.N - 1) * p.ldqk + c * 8);
-            }
+    for (int j = 0; j < KRND; ++j) {
+        const int i = j * 256 + tid;
+        const int row = i / NCH, cs = i % NCH;
+        krow[j] = row; kcol[j] = (cs ^ kswz(row)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < VRND; ++j) {
+        const int i = j * 256 + tid;
+        const int d = min(i >> 3, D - 1), cs = i & 7;
+        vsrc[j] = vbase_ptr + (size_t)d * p.Npad + (cs ^ ((d >> 1) & 7)) * 8;
+    }
+    auto issue_dma = [&](int kb, int bufi) {
+        char* sK = smem + bufi * BUF;
+        char* sV = sK + KBYTES;
+#pragma unroll
+        for (int j = 0; j < KRND; ++j) {
+            const int ib = j * 256 + wave * 64;              // wave-uniform: whole 64-chunk pieces only
+            if (ib < 64 * NCH) glds16(kbase_ptr + (size_t)min(kb + krow[j], p.N - 1) * p.ldqk + kcol[j], sK + ib * 16);
         }
 #pragma unroll
-        for (int j = 0; j < VL; ++j) {
-            const int i = j * 256 + tid;
-            if (i < D * 8) {
-                const int d = i >> 3, c = i & 7;
-                vreg[j] = *(const u32x4*)(vbase_ptr + (size_t)d * p.Npad + kb + c * 8);
-            }
-        }
-    };
-    auto write_lds = [&](int bufi) {
-        char* sK = smem + bufi * KVBYTES;
-        char* sV = sK + 64 * KROW;
-#pragma unroll
-        for (int j = 0; j < KL; ++j) {
-            const int i = j * 256 + tid;
-            if (i < 64 * NCH) *(u32x4*)(sK + (i / NCH) * KROW + (i % NCH) * 16) = kreg[j];
-        }
-#pragma unroll
-        for (int j = 0; j < VL; ++j) {
-            const int i = j * 256 + tid;
-            if (i < D * 8) *(u32x4*)(sV + (i >> 3) * VROW + (i & 7) * 16) = vreg[j];
+        for (int j = 0; j < VRND; ++j) {
+            const int ib = j * 256 + wave * 64;
+            if (ib < D * 8) glds16(vsrc[j] + kb, sV + ib * 16);
         }
     };
 
@@ -127,102 +122,111 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.scale * 1.4426950408889634f;     // fold log2(e): softmax in base 2
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                // m_run in base-2 logit units (score * scale * log2 e)
+    const float sc = p.scale * 1.4426950408889634f;      // fold log2(e): softmax in base 2
 
     const int ntiles = (p.N + 63) / 64;
-    issue_loads(0);
-    __syncthreads();
-    write_lds(0);
-    __syncthreads();
+    const int ksw = kswz(l31), vsw = (l31 >> 1) & 7;
+    // When D is not a multiple of 32 the last Vt d-tile has rows that no DMA ever writes.  Row D is set to
+    // ones: the PV MFMA then accumulates the softmax denominator (sum of the T-rounded P) in output row D for
+    // free, and the 32 VALU adds per tile disappear.  The other spare rows are zeroed.
+    constexpr bool kOnesRow = (DT * 32 > D);
+    if constexpr (kOnesRow) {
+        const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
+        for (int i = tid; i < 2 * (DT * 32 - D) * 8; i += 256) {
+            const int bufi = i / ((DT * 32 - D) * 8), w = i % ((DT * 32 - D) * 8);
+            const int d = D + w / 8, c = w % 8;
+            const unsigned v = (d == D) ? one2 : 0u;
+            *(u32x4*)(smem + bufi * BUF + KBYTES + d * 128 + c * 16) = u32x4{v, v, v, v};
+        }
+    }
+    issue_dma(0, 0);
 
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
-        const char* sK = smem + (NBUF == 2 ? (t & 1) : 0) * KVBYTES;
-        const char* sV = sK + 64 * KROW;
-        if (!(ABL & 2) && t + 1 < ntiles) issue_loads(kb + 64);
+        wait_vmcnt<0>();                                  // my pieces of tile t have landed ...
+        __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
+        if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
+        const char* sK = smem + (t & 1) * BUF;
+        const char* sV = sK + KBYTES;
+        const bool tail = (kb + 64 > p.N);
 
-        // ---- S^T = K Q^T : two 32-key sub-tiles ------------------------------------------------
+        // ---- S^T = K Q^T (swapped: lane = query column) for both 32-key sub-tiles; the two accumulator
+        //      chains are interleaved so no MFMA waits for the previous one's result
         f32x16 s2[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s2[u][i] = 0.f;
-            if (!(ABL & 8)) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const u32x4 kf = *(const u32x4*)(sK + (u * 32 + l31) * KROW + (2 * s + hi) * 16);
-                    s2[u] = T::mfma32(kf, qf[s], s2[u]);
-                }
-            } else {
-                s2[u][0] = __uint_as_float(qf[0][0] & 0x3fffffff);
+            for (int u = 0; u < 2; ++u) {
+                const u32x4 kf = *(const u32x4*)(sK + (u * 32 + l31) * (NCH * 16) + (((2 * s + hi) ^ ksw) << 4));
+                s2[u] = T::mfma32(kf, qf[s], s == 0 ? zero16 : s2[u]);
             }
-        }
-        // ---- online softmax (per lane = per query; halves hold disjoint keys) ------------------
-        float mx = -INFINITY;
-        const bool tail = (kb + 64 > p.N);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = s2[u][r] * sc;
-                if (tail && (kb + u * 32 + krow32(r, hi) >= p.N)) x = -INFINITY;
-                s2[u][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        u32x4 pf[4];
+        // ---- per sub-tile: online softmax (VALU) then O^T += Vt P^T (MFMA); the softmax of sub-tile 1
+        //      runs under the PV MFMAs of sub-tile 0 and under the other waves of this SIMD
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            u32x4 vf[DT][2];                              // issued before the arithmetic so they land under it
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                vf[dt][0] = *(const u32x4*)(sV + (dt * 32 + l31) * 128 + (((4 * u + hi) ^ vsw) << 4));
+                vf[dt][1] = *(const u32x4*)(sV + (dt * 32 + l31) * 128 + (((4 * u + 2 + hi) ^ vsw) << 4));
+            }
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + u * 32 + krow32(r, hi) >= p.N) s2[u][r] = -INFINITY;
+            }
+            // online softmax on raw scores (scale folded into the exponent)
+            float mx = s2[u][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s2[u][r]);
+            mx = xhalf_max(mx);
+            // Lazy rescaling: the running reference m_run only moves when some query's maximum outgrows it by
+            // more than 2^TAU; until then P = exp2(s - m_run) may exceed 1 (<= 2^TAU: harmless in fp32
+            // accumulators and in the 8-bit-exponent P operand) and the 3*16 accumulator registers are left alone.
+            // With a 64-lane wave an exact running maximum would rescale on nearly every sub-tile.
+            constexpr float TAU = 8.0f;
+            const float m_cand = fmaxf(m_run, mx * sc);
+            if (__any(m_cand > m_run + TAU)) {                 // also the very first sub-tile (m_run = -inf)
+                const float alpha = fast_exp2(m_run - m_cand); // 0 on the first sub-tile (o = l = 0 there)
+                m_run = m_cand;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            }
+            float ps0 = 0.f, ps1 = 0.f;
             float pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pv[r] = (ABL & 1) ? s2[u][r] : fast_exp2(s2[u][r] - m_new);
-                psum += pv[r];
+            for (int r = 0; r < 16; r += 2) {
+                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run));
+                pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run));
+                if constexpr (!kOnesRow) { ps0 += pv[r]; ps1 += pv[r + 1]; }
             }
-            pf[2 * u] = pack8<T>(pv);
-            pf[2 * u + 1] = pack8<T>(pv + 8);
-        }
-        l_run = l_run * alpha + psum;
-        if (!__all(alpha == 1.0f)) {
+            const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
+            if constexpr (!kOnesRow) l_run += ps0 + ps1;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-        }
-        // ---- O^T += Vt P^T ---------------------------------------------------------------------
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                if (ABL & 4) { o[dt][sl] += __uint_as_float(pf[sl][0]); continue; }
-                const u32x4 vf = *(const u32x4*)(sV + (dt * 32 + l31) * VROW + (2 * sl + hi) * 16);
-                o[dt] = T::mfma32(vf, pf[sl], o[dt]);
-            }
-        if (!(ABL & 2)) {
-            // the other ring slot was last read during tile t-1, which every wave finished before the
-            // barrier that ended it -> safe to fill now; ONE barrier per tile
-            if constexpr (NBUF == 2) {
-                if (t + 1 < ntiles) write_lds((t + 1) & 1);
-                __syncthreads();
-            } else {
-                __syncthreads();
-                if (t + 1 < ntiles) write_lds(0);
-                __syncthreads();
+            for (int dt = 0; dt < DT; ++dt) {
+                o[dt] = T::mfma32(vf[dt][0], pf0, o[dt]);
+                o[dt] = T::mfma32(vf[dt][1], pf1, o[dt]);
             }
         }
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if constexpr ((ABL & 16) != 0) {              // ablation: no output stores
-        if (o[0][0] * inv == 12345.678f) p.O[0] = 1;
-        return;
+    float l_tot;
+    if constexpr (kOnesRow) {
+        // output row D of the last d-tile: register (D%32 -> j = row/8, e = row%4) of the lanes with hi == (row/4)%2
+        constexpr int ROW = D - (DT - 1) * 32, REG = 4 * (ROW / 8) + (ROW % 4), HI = (ROW / 4) % 2;
+        const float mine = (hi == HI) ? o[DT - 1][REG] : 0.f;
+        l_tot = xhalf_sum(mine);
+    } else {
+        l_tot = xhalf_sum(l_run);
     }
+    const float inv = 1.0f / l_tot;
     // ---- epilogue: O^T registers -> LDS [128 q][D] -> row-contiguous 16-byte global stores.
     //      (per-lane 8-byte stores straight from the MFMA layout touch 32 rows per instruction with
     //      partial 144-byte row segments: measured 10x slower than the whole MFMA loop.)
@@ -256,9 +260,7 @@ int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream
     if ((p.ldqk % 8) || (p.koff % 8) || (p.ldo % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)p.QK & 15) || ((uintptr_t)p.Vt & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
     const dim3 grid(((p.N + 127) / 128) * p.H * p.B);
-// K/V ring depth, measured on MI355X (tools/bench_attn.py): D=72 -> 1 buffer (25 KB LDS, 2 blocks/CU:
-// 0.76 ms vs 1.12 ms with 2 buffers at B=96,N=729,H=16); D=64 -> 2 buffers (0.48 ms vs 0.53 ms).
-#define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_kernel<TT, DD, 0, ((DD) == 72 ? 1 : 2)>), grid, dim3(256), 0, st, p)
+#define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_kernel<TT, DD>), grid, dim3(256), 0, st, p)
     if (dtype == VIDI_DT_BF16) {
         if (D == 72) LAUNCH(BF16, 72); else if (D == 64) LAUNCH(BF16, 64); else if (D == 16) LAUNCH(BF16, 16);
         else if (D == 32) LAUNCH(BF16, 32); else return VIDI_ERR_SHAPE;

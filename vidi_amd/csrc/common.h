@@ -119,6 +119,18 @@ __device__ __forceinline__ int krow32(int r, int hi) { return (r & 3) + 8 * (r >
 // key (e&3) + 8*(e>>2) + 4g.  perm16(key) gives the storage position of `key` (involution-free map).
 __host__ __device__ __forceinline__ int perm16(int x) { return 8 * ((x >> 2) & 1) + (x & 3) + 4 * (x >> 3); }
 
+// Cross-half (lane ^ 32) reductions without LDS: v_permlane32_swap gives every lane both halves' values.
+__device__ __forceinline__ float xhalf_max(float x) {
+    const unsigned v = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const unsigned v = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // async global -> LDS, 16 B per lane, LDS destination = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

@@ -25,7 +25,7 @@ template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool
 __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int NT = WN * WM * 64;
     constexpr int TN = BN / WN / MI, TM = BM / WM / MI;
-    static_assert(MI == 32 || (MI == 16 && (STAG == 0 || STAG == 6 || STAG == 7) && BK == 64 && TM <= TN), "MI");
+    static_assert(MI == 32 || (MI == 16 && TM <= TN && (((STAG == 0 || STAG == 6 || STAG == 7) && BK == 64) || (STAG == 9 && BK == 32))), "MI");
     // MI == 16 schedules: STAG 0 = DMA issued right after the barrier; 6 = after the first fragment reads;
     // 7 = one DMA piece after each of the first W_LOADS + X_LOADS row groups of MFMAs
     constexpr bool kLate16 = (MI == 16) && (STAG == 6 || STAG == 7);
@@ -33,6 +33,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int CSH = (CPR == 8) ? 3 : 2;
     constexpr int ROWB = BK * 2;                      // LDS row bytes
     constexpr int SWSH = (CPR == 8) ? 1 : 2;          // swizzle = (row >> SWSH) & (CPR-1): conflict-free ds_read_b128
+    // 16-byte chunk c of LDS row r lives at chunk c ^ swz(r); chosen so that every ds_read_b128 lane group of the
+    // fragment reads hits 64 distinct banks (32-row x 2-chunk lanes for MI=32, 16-row x 4-chunk lanes for MI=16)
+    auto swz = [](int row) {
+        if constexpr (CPR == 8) return (row >> 1) & 7;
+        else if constexpr (MI == 32) return (row >> 2) & 3;
+        else return (4 - ((row >> 2) & 3)) & 3;
+    };
     constexpr int W_LOADS = BN * CPR / NT, X_LOADS = BM * CPR / NT;
     constexpr int LPT = W_LOADS + X_LOADS;
     constexpr int STAGE_BYTES = (BN + BM) * ROWB;
@@ -71,13 +78,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     int xcol[X_LOADS];
 #pragma unroll
     for (int j = 0; j < W_LOADS; ++j) {
-        const int pidx = j * NT + tid, row = pidx >> CSH, cl = pidx & (CPR - 1), cg = cl ^ ((row >> SWSH) & (CPR - 1));
+        const int pidx = j * NT + tid, row = pidx >> CSH, cl = pidx & (CPR - 1), cg = cl ^ swz(row);
         const int n = min(n0 + row, p.N - 1);
         wsrc[j] = p.W + (size_t)n * p.ldw + cg * 8;
     }
 #pragma unroll
     for (int j = 0; j < X_LOADS; ++j) {
-        const int pidx = j * NT + tid, row = pidx >> CSH, cl = pidx & (CPR - 1), cg = cl ^ ((row >> SWSH) & (CPR - 1));
+        const int pidx = j * NT + tid, row = pidx >> CSH, cl = pidx & (CPR - 1), cg = cl ^ swz(row);
         const int m = min(m0 + row, p.M - 1);
         xsrc[j] = Xb + (size_t)m * p.ldx;
         xcol[j] = cg * 8;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
 
     // lane -> (row inside an MI-row tile, 8-element k chunk): 32x32x16 = 32 rows x 2 chunks, 16x16x32 = 16 rows x 4 chunks
     const int l31 = (MI == 32) ? (lane & 31) : (lane & 15), hi = (MI == 32) ? (lane >> 5) : (lane >> 4);
-    const int sw = (l31 >> SWSH) & (CPR - 1);              // row swizzle (tile bases are multiples of 16)
+    const int sw = swz(l31);                               // row swizzle (tile bases are multiples of 16)
     const int w_row_off = (wn * TN * MI + l31) * ROWB;
     const int x_row_off = (wm * TM * MI + l31) * ROWB;
 
@@ -145,17 +152,19 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     auto wait_rem = [&](int rem) {            // allow `rem` younger batches (LPT DMA instructions each) in flight
         if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     };
-    u32x4 wf[2][TN], xf[2][TM];
+    constexpr int KST = (MI == 32) ? 2 : 1;                // MFMA k-steps per 32-wide micro-tile
+    constexpr int CPS = (MI == 32) ? 2 : 4;                // 16-byte chunks per k-step
+    u32x4 wf[KST][TN], xf[KST][TM];
     auto Lseg = [&](int j) {
         const char* sW = smem + (j % R) * STAGE_BYTES;
         const char* sX = sW + BN * ROWB;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int coff = ((2 * st + hi) ^ sw) << 4;
+        for (int st = 0; st < KST; ++st) {
+            const int coff = ((CPS * st + hi) ^ sw) << 4;
 #pragma unroll
-            for (int a2 = 0; a2 < TN; ++a2) wf[st][a2] = *(const u32x4*)(sW + w_row_off + a2 * 32 * ROWB + coff);
+            for (int a2 = 0; a2 < TN; ++a2) wf[st][a2] = *(const u32x4*)(sW + w_row_off + a2 * MI * ROWB + coff);
 #pragma unroll
-            for (int b2 = 0; b2 < TM; ++b2) xf[st][b2] = *(const u32x4*)(sX + x_row_off + b2 * 32 * ROWB + coff);
+            for (int b2 = 0; b2 < TM; ++b2) xf[st][b2] = *(const u32x4*)(sX + x_row_off + b2 * MI * ROWB + coff);
         }
         if (j + R - 1 < nk) load_stage((j + R - 1) % R, j + R - 1);      // refill the slot freed by micro-tile j-1
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my LDS reads are done before I release the slot
@@ -164,11 +173,14 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < KST; ++st)
 #pragma unroll
             for (int a2 = 0; a2 < TN; ++a2)
 #pragma unroll
-                for (int b2 = 0; b2 < TM; ++b2) acc[a2][b2] = T::mfma32(wf[st][a2], xf[st][b2], acc[a2][b2]);
+                for (int b2 = 0; b2 < TM; ++b2) {
+                    if constexpr (MI == 32) acc[a2][b2] = T::mfma32(wf[st][a2], xf[st][b2], acc[a2][b2]);
+                    else acc[a2][b2] = T::mfma16(wf[st][a2], xf[st][b2], acc[a2][b2]);
+                }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -704,9 +716,11 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
         case 4: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 6, 16>(p, batch, st);       // 16x16x32 MFMA, DMA issued after the first fragment reads
-        case 5: case 6:                                                                               // other DMA placements (same results)
+        case 5: case 6: case 7: case 10:                                                              // other schedules (same results)
             if constexpr (MODE == MODE_PLAIN && !REPKV) {
                 if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
+                if (tile_cfg == 7) return launch_cfg<T, 256, 256, 2, 4, 4, MODE, REPKV, 32, 9, 16>(p, batch, st);   // ping-pong, 16x16x32, 4-deep ring
+                if (tile_cfg == 10) return launch_cfg<T, 256, 256, 2, 4, 5, MODE, REPKV, 32, 9, 16>(p, batch, st);  // ping-pong, 5-deep ring
                 if (tile_cfg == 5) return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 7, 16>(p, batch, st);
                 return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 0, 16>(p, batch, st);
             } else {
