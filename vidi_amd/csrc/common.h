@@ -94,12 +94,27 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 
 // ---- math ---------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3))) — torch gelu(approximate='tanh')
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float inner = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    // 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715x^3) — torch gelu(approximate='tanh').
+    // Evaluated as x / (1 + exp(-2u)): one v_exp + one v_rcp, no branches (tanhf() is ~50 instructions
+    // with divergent ranges; the epilogue evaluates this once per output element with the matrix cores idle).
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = 0.044715f;
+    const float x2 = x * x;
+    const float w = x * __builtin_fmaf(c1, x2, 1.0f);            // x + 0.044715 x^3
+    const float e = __builtin_amdgcn_exp2f(c0 * w);              // exp(-2u); +inf for very negative x -> result -0
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    // 0.5*x*(1+erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7), branch-free
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float q = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 1 - erf(z), z >= 0
+    // x >= 0: 0.5x(2 - q);  x < 0: 0.5x q
+    return 0.5f * x * (x >= 0.f ? 2.0f - q : q);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

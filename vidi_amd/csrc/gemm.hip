@@ -376,8 +376,28 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int BNO = (MODE == MODE_GEGLU) ? BN / 2 : BN;       // output columns of this tile
     constexpr int CROW = BNO * 2 + 16;                            // padded LDS row (bytes)
     __syncthreads();                                              // every wave is done with the last K slice
-    if (p.diag == 2) return;
+    if (p.diag == 2) return;                                     // timing diagnostic: no epilogue at all
     char* sC = smem;
+    // copy-out geometry (chunk i = it*NT + tid -> row i / CH, 16-byte chunk i % CH of the staged tile)
+    constexpr int CH = BNO / 8, ITERS = BM * CH / NT, UNR = 4;
+    static_assert((BM * CH) % NT == 0 && ITERS % UNR == 0, "copy-out geometry");
+    const int no0 = (MODE == MODE_GEGLU) ? (n0 >> 1) : n0;
+    const int Nout = (MODE == MODE_GEGLU) ? (p.N >> 1) : p.N;
+    // the residual tile is fetched NOW, so its HBM latency hides under the staging pass below instead of
+    // stalling the copy-out (the accumulators are still live: 128 + 4*ITERS registers)
+    u32x4 res[ITERS];
+    if constexpr (MODE != MODE_KV_CACHE) {
+        if (Rb) {
+            const bool wrap = p.rmod < p.M;                       // residual rows repeat every rmod rows (position tables)
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int i = it * NT + tid;
+                const int m = min(m0 + i / CH, p.M - 1), n = min(no0 + (i % CH) * 8, Nout - 8);
+                const int mr = wrap ? m % p.rmod : m;
+                res[it] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + n);
+            }
+        }
+    }
     constexpr int NQ = (MI == 32) ? 4 : 1;                        // 4-row quads per lane per tile (32x32: rows 8j+4hi+e; 16x16: 4hi+e)
     // this lane's bias quads (one 8-byte load per n-quad, shared by all its m-tiles)
     const bool has_bias = (MODE != MODE_GEGLU) && (p.bias != nullptr);
@@ -466,46 +486,57 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
     // ---- copy-out: 16-byte chunks, consecutive lanes = consecutive chunks of one row ------------
-    constexpr int CH = BNO / 8;
-    const int no0 = (MODE == MODE_GEGLU) ? (n0 >> 1) : n0;
-    const int Nout = (MODE == MODE_GEGLU) ? (p.N >> 1) : p.N;
-    for (int i = tid; i < BM * CH; i += NT) {
-        const int ml = i / CH, c = i % CH;
-        const int m = m0 + ml, n = no0 + c * 8;
-        if (m >= p.M || n >= Nout) continue;
-        if constexpr (MODE == MODE_QKV_VT) { if (n >= p.vstart) continue; }
-        u32x4 val = *(const u32x4*)(sC + ml * CROW + c * 16);
-        if (p.diag == 1 && val[0] != 0x12345678u) continue;
-        if constexpr (MODE == MODE_KV_CACHE) {
-            if (n < p.kvd) {
-                const int tok = p.tok0 + m, kvh = n / p.hd, d = n % p.hd;
-                *(u32x4*)(p.Kc + ((size_t)kvh * p.ntile64 * 64 + tok) * p.hd + d) = val;
+    // UNR chunks per pass: their LDS reads are issued together, then processed
+#pragma unroll
+    for (int it0 = 0; it0 < ITERS; it0 += UNR) {
+        u32x4 val[UNR];
+        int mm[UNR], nn[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int i = (it0 + k) * NT + tid;
+            const int ml = i / CH, c = i % CH;
+            mm[k] = m0 + ml; nn[k] = no0 + c * 8;
+            ok[k] = (mm[k] < p.M) && (nn[k] < Nout);
+            if constexpr (MODE == MODE_QKV_VT) ok[k] = ok[k] && (nn[k] < p.vstart);
+            val[k] = *(const u32x4*)(sC + ml * CROW + c * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            if (!ok[k]) continue;
+            const int m = mm[k], n = nn[k];
+            if constexpr (MODE == MODE_KV_CACHE) {
+                if (n < p.kvd) {
+                    const int tok = p.tok0 + m, kvh = n / p.hd, d = n % p.hd;
+                    *(u32x4*)(p.Kc + ((size_t)kvh * p.ntile64 * 64 + tok) * p.hd + d) = val[k];
+                } else {
+                    *(u32x4*)(p.Vrow + (size_t)m * p.kvd + (n - p.kvd)) = val[k];
+                }
             } else {
-                *(u32x4*)(p.Vrow + (size_t)m * p.kvd + (n - p.kvd)) = val;
-            }
-        } else {
-            if (act_tanh) {
-                float x[8];
-                unpack8<T>(val, x);
+                u32x4 v = val[k];
+                if (act_tanh) {
+                    float x[8];
+                    unpack8<T>(v, x);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = gelu_tanh_f(x[e]);
-                val = pack8<T>(x);
-            } else if (act_erf) {
-                float x[8];
-                unpack8<T>(val, x);
+                    for (int e = 0; e < 8; ++e) x[e] = gelu_tanh_f(x[e]);
+                    v = pack8<T>(x);
+                } else if (act_erf) {
+                    float x[8];
+                    unpack8<T>(v, x);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = gelu_erf_f(x[e]);
-                val = pack8<T>(x);
-            }
-            if (Rb) {
-                float x[8], r[8];
-                unpack8<T>(val, x);
-                unpack8<T>(*(const u32x4*)(Rb + (size_t)(m % p.rmod) * p.ldr + n), r);
+                    for (int e = 0; e < 8; ++e) x[e] = gelu_erf_f(x[e]);
+                    v = pack8<T>(x);
+                }
+                if (Rb) {
+                    float x[8], r[8];
+                    unpack8<T>(v, x);
+                    unpack8<T>(res[it0 + k], r);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
-                val = pack8<T>(x);
+                    for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
+                    v = pack8<T>(x);
+                }
+                *(u32x4*)(Yb + (size_t)m * p.ldy + n) = v;
             }
-            *(u32x4*)(Yb + (size_t)m * p.ldy + n) = val;
         }
     }
 }
