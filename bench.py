@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--preset", default="vidi15_9b")
+    ap.add_argument("--vis-chunk", type=int, default=0, help="override cfg.vis_frames_per_chunk (activation chunking only)")
+    ap.add_argument("--aud-chunk", type=int, default=0, help="override cfg.aud_chunks_per_batch")
     return ap.parse_args()
 
 
@@ -113,6 +115,10 @@ def main():
     from vidi_amd.model import VidiForCausalLM
     from vidi_amd.weights import init_random_weights
     cfg = getattr(C, a.preset)()
+    if a.vis_chunk > 0:
+        cfg.vis_frames_per_chunk = a.vis_chunk
+    if a.aud_chunk > 0:
+        cfg.aud_chunks_per_batch = a.aud_chunk
     weights = init_random_weights(cfg, seed=3, dtype=dtype, device=dev)          # replicated on every rank (same seed)
     model = VidiForCausalLM(cfg, weights, dtype=dtype, device=dev)
     del weights

@@ -38,7 +38,7 @@ def dev(t):
 # GEMM family
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 11])
 def test_gemm_plain_tiles(hip, dt, cfg):
     """asymmetric operands, M/N not multiples of the tile, bias"""
     M, N, K = 300, 352, 192
@@ -48,7 +48,7 @@ def test_gemm_plain_tiles(hip, dt, cfg):
     report(f"gemm cfg{cfg}", y, ref, *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 11])
 def test_gemm_large_k_and_auto(hip, cfg):
     dt = torch.bfloat16
     M, N, K = 1000, 1152, 4352

@@ -65,7 +65,7 @@ class VidiConfig:
     aud_sampling_rate: int = 16000
     aud_hop_length: int = 160
     # ---- engine knobs (ours) ----
-    vis_frames_per_chunk: int = 360         # SigLIP activation chunk (frames): ~1000 M-tiles per GEMM => <2% tail waves
+    vis_frames_per_chunk: int = 720         # SigLIP activation chunk (frames): ~2050 M-tiles per GEMM => <1% tail waves (720 vs 360: +1% measured)
     aud_chunks_per_batch: int = 60          # Whisper activation chunk (30-s windows)
 
     @property

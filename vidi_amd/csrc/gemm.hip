@@ -747,6 +747,9 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV>(p, batch, st);
         case 2: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV>(p, batch, st);
         case 4: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 6, 16>(p, batch, st);       // 16x16x32 MFMA, DMA issued after the first fragment reads
+        case 11:                                                                                      // 192-wide n tile (N = 1152: 6 exact tiles instead of 4.5)
+            if constexpr (MODE == MODE_PLAIN) return launch_cfg<T, 192, 256, 2, 4, 2, MODE, REPKV, 64, 6, 16>(p, batch, st);
+            else return VIDI_ERR_ARG;
         case 5: case 6: case 7: case 10:                                                              // other schedules (same results)
             if constexpr (MODE == MODE_PLAIN && !REPKV) {
                 if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
