@@ -38,7 +38,7 @@ def dev(t):
 # GEMM family
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 11, 12])
 def test_gemm_plain_tiles(hip, dt, cfg):
     """asymmetric operands, M/N not multiples of the tile, bias"""
     M, N, K = 300, 352, 192
@@ -48,7 +48,7 @@ def test_gemm_plain_tiles(hip, dt, cfg):
     report(f"gemm cfg{cfg}", y, ref, *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 11, 12])
 def test_gemm_large_k_and_auto(hip, cfg):
     dt = torch.bfloat16
     M, N, K = 1000, 1152, 4352
@@ -93,7 +93,7 @@ def test_gemm_batched_overlapping_rows(hip):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 2, 4])
+@pytest.mark.parametrize("cfg", [-1, 2, 4, 12])
 def test_gemm_repkv(hip, dt, cfg):
     nkv, G, hd, H, M = 2, 2, 128, 256, 150
     v = seeded((M, nkv * hd), 14, dtype=dt); wo = seeded((H, nkv * G * hd), 15, 0.05, dtype=dt)
@@ -104,7 +104,7 @@ def test_gemm_repkv(hip, dt, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 12])
 def test_gemm_geglu(hip, dt, cfg):
     M, I, K = 200, 256, 128
     x = seeded((M, K), 16, dtype=dt); g = seeded((I, K), 17, 0.1, dtype=dt); u = seeded((I, K), 18, 0.1, dtype=dt)
@@ -114,7 +114,7 @@ def test_gemm_geglu(hip, dt, cfg):
     report("gemm geglu", y, ref, *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [-1, 2, 4])
+@pytest.mark.parametrize("cfg", [-1, 2, 4, 12])
 @pytest.mark.parametrize("hd,N,nh", [(72, 729, 4), (16, 49, 4), (64, 50, 2)])
 def test_gemm_qkv_vt(hip, hd, N, nh, cfg):
     dt = torch.bfloat16
@@ -133,7 +133,7 @@ def test_gemm_qkv_vt(hip, hd, N, nh, cfg):
     report("qkv_vt V", v, ref[:, 2 * Hd:], *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [-1, 2, 4])
+@pytest.mark.parametrize("cfg", [-1, 2, 4, 12])
 def test_gemm_kv_cache(hip, cfg):
     dt = torch.bfloat16
     nkv, hd, K, M, tok0 = 2, 128, 128, 170, 64

@@ -147,9 +147,10 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 }
 
 // async global -> LDS, 16 B per lane, LDS destination = wave-uniform base + lane*16
+template <int AUX = 0>      // cache policy bits of the load (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 template <int N>

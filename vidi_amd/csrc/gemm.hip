@@ -25,10 +25,13 @@ template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool
 __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int NT = WN * WM * 64;
     constexpr int TN = BN / WN / MI, TM = BM / WM / MI;
-    static_assert(MI == 32 || (MI == 16 && TM <= TN && (((STAG == 0 || STAG == 6 || STAG == 7) && BK == 64) || (STAG == 9 && BK == 32))), "MI");
+    static_assert(MI == 32 || (MI == 16 && TM <= TN && (((STAG == 0 || STAG == 6 || STAG == 7 || STAG == 10 || (STAG >= 16 && STAG <= 19)) && BK == 64) || (STAG == 9 && BK == 32))), "MI");
+    // STAG 16..19 = schedule 6 with a cache policy on the DMA loads (experiments): nt / sc0 / sc1 / sc0+nt
+    constexpr bool kS6 = (STAG == 6) || (STAG >= 16 && STAG <= 19);
+    constexpr int AUX = (STAG == 16) ? 2 : (STAG == 17) ? 1 : (STAG == 18) ? 16 : (STAG == 19) ? 3 : 0;
     // MI == 16 schedules: STAG 0 = DMA issued right after the barrier; 6 = after the first fragment reads;
     // 7 = one DMA piece after each of the first W_LOADS + X_LOADS row groups of MFMAs
-    constexpr bool kLate16 = (MI == 16) && (STAG == 6 || STAG == 7);
+    constexpr bool kLate16 = (MI == 16) && (kS6 || STAG == 7);
     constexpr int CPR = BK / 8;                       // 16-byte chunks per LDS row (8 for BK=64, 4 for BK=32)
     constexpr int CSH = (CPR == 8) ? 3 : 2;
     constexpr int ROWB = BK * 2;                      // LDS row bytes
@@ -97,16 +100,16 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
         char* sX = sW + BN * ROWB;
         const int k0 = (STAG == 8) ? 0 : kt * BK;          // STAG 8 (diagnostic): every DMA re-reads K slice 0 (cache hits)
 #pragma unroll
-        for (int j = 0; j < W_LOADS; ++j) if (j >= jw0 && j < jw1) glds16(wsrc[j] + k0, sW + (j * NT + wave * 64) * 16);
+        for (int j = 0; j < W_LOADS; ++j) if (j >= jw0 && j < jw1) glds16<AUX>(wsrc[j] + k0, sW + (j * NT + wave * 64) * 16);
 #pragma unroll
         for (int j = 0; j < X_LOADS; ++j) {
             if (j < jx0 || j >= jx1) continue;
             if constexpr (REPKV) {
                 const int k = k0 + xcol[j];
                 const int phys = (k / (p.rep_g * p.rep_hd)) * p.rep_hd + (k % p.rep_hd);
-                glds16(xsrc[j] + phys, sX + (j * NT + wave * 64) * 16);
+                glds16<AUX>(xsrc[j] + phys, sX + (j * NT + wave * 64) * 16);
             } else {
-                glds16(xsrc[j] + k0, sX + (j * NT + wave * 64) * 16);
+                glds16<AUX>(xsrc[j] + k0, sX + (j * NT + wave * 64) * 16);
             }
         }
     };
@@ -250,6 +253,61 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
         if (kt + 1 < nk) lwrite((kt + 1) & 1);          // slot (kt+1)&1 was last read in iteration kt-1
         __syncthreads();
     }
+  } else if constexpr (MI == 16 && STAG == 10) {
+    // ============ mid-iteration barrier: the fragment pipeline never drains (2-deep ring, BK = 64) ============
+    // Iteration kt = two k32 steps on stage kt.  All LDS reads of stage kt are issued during step 0 (its own
+    // step-1 fragments, refilled in place); the wait + barrier sit BETWEEN the steps, where every wave already
+    // holds the operands of its next 32 MFMAs.  After the barrier buffer kt%2 is free (DMA of stage kt+2 goes
+    // there) and stage kt+1 has landed, so step 1 refills its registers with the step-0 fragments of stage kt+1:
+    // no MFMA ever waits for a top-of-iteration LDS round trip.
+    static_assert(BK == 64 && STAGES == 2, "mid-barrier schedule geometry");
+    load_stage(0, 0);
+    if (nk > 1) { load_stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    u32x4 wf[TN], xf[2][TM];
+    auto rdW = [&](const char* sW, int a, int s) { return *(const u32x4*)(sW + w_row_off + a * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
+    auto rdX = [&](const char* sX, int b, int s) { return *(const u32x4*)(sX + x_row_off + b * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
+    {
+        const char* sW = smem;
+        const char* sX = sW + BN * ROWB;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xf[0][b] = rdX(sX, b, 0);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[a] = rdW(sW, a, 0);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sW = smem + (kt & 1) * STAGE_BYTES;
+        const char* sX = sW + BN * ROWB;
+        // ---- step 0: MFMAs on the resident fragments; refill with this stage's step-1 fragments
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma16(wf[a], xf[0][b], acc[a][b]);
+            wf[a] = rdW(sW, a, 1);
+            if (a < TM) xf[1][a] = rdX(sX, a, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- mid point: my reads of stage kt are complete, stage kt+1 has landed (all waves: barrier)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.diag != 4 && kt + 2 < nk) load_stage(kt & 1, kt + 2);
+        // ---- step 1: MFMAs; refill with the next stage's step-0 fragments
+        const bool more = (kt + 1 < nk);
+        const char* nW = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        const char* nX = nW + BN * ROWB;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = T::mfma16(wf[a], xf[1][b], acc[a][b]);
+            if (more) {
+                wf[a] = rdW(nW, a, 0);
+                if (a < TM) xf[0][a] = rdX(nX, a, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
   } else {
   #pragma unroll
       for (int s = 0; s < STAGES - 1; ++s)
@@ -268,7 +326,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
               if (rem >= 3) wait_vmcnt<3 * LPT>(); else if (rem == 2) wait_vmcnt<2 * LPT>(); else if (rem == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
           }
           if constexpr (STAG != 4) __builtin_amdgcn_s_barrier();
-          const bool do_load = (STAG != 3 && STAG != 4) && (kt + STAGES - 1 < nk);
+          const bool do_load = (STAG != 3 && STAG != 4) && (p.diag != 4) && (kt + STAGES - 1 < nk);   // diag 4: timing without DMA (wrong results)
           const int lstage = (kt + STAGES - 1) % STAGES, lkt = kt + STAGES - 1;
           if constexpr (!kStag && !kInter && !kLate16) { if (do_load) load_stage(lstage, lkt); }
 
@@ -285,7 +343,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
               for (int b = 0; b < TM; ++b) xf[0][b] = rdX(b, 0);
   #pragma unroll
               for (int a = 0; a < TN; ++a) wf[a] = rdW(a, 0);
-              if constexpr (STAG == 6) {
+              if constexpr (kS6) {
                   __builtin_amdgcn_sched_barrier(0);
                   if (do_load) load_stage(lstage, lkt);
               }
@@ -750,6 +808,15 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         case 11:                                                                                      // 192-wide n tile (N = 1152: 6 exact tiles instead of 4.5)
             if constexpr (MODE == MODE_PLAIN) return launch_cfg<T, 192, 256, 2, 4, 2, MODE, REPKV, 64, 6, 16>(p, batch, st);
             else return VIDI_ERR_ARG;
+        case 12: return launch_cfg<T, 256, 256, 2, 4, 2, MODE, REPKV, 64, 10, 16>(p, batch, st);      // mid-iteration barrier schedule
+        case 14: case 15:                                                                             // 4 waves x (128x128): 1 wave/SIMD, 1/3 fewer LDS fragment bytes per FLOP
+            if constexpr (MODE == MODE_PLAIN && !REPKV) {
+                if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
+                if (tile_cfg == 14) return launch_cfg<T, 256, 256, 2, 2, 2, MODE, REPKV, 64, 10, 16>(p, batch, st);
+                return launch_cfg<T, 256, 256, 2, 2, 2, MODE, REPKV, 64, 6, 16>(p, batch, st);
+            } else {
+                return VIDI_ERR_ARG;
+            }
         case 5: case 6: case 7: case 10:                                                              // other schedules (same results)
             if constexpr (MODE == MODE_PLAIN && !REPKV) {
                 if (!getenv("VIDI_GEMM_EXPERIMENTAL")) return VIDI_ERR_ARG;
