@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--decode-graph", action="store_true", help="replay decode steps from a hipGraph (opt-in: capture costs ~126 ms)")
     ap.add_argument("--preset", default="vidi15_9b")
     ap.add_argument("--vis-chunk", type=int, default=0, help="override cfg.vis_frames_per_chunk (activation chunking only)")
     ap.add_argument("--aud-chunk", type=int, default=0, help="override cfg.aud_chunks_per_batch")
@@ -195,16 +196,30 @@ def main():
     value = Nv * a.steps / dt
 
     # ---- decode leg (s/query = prefill + n_new decode steps on the resident caches) ----
+    # --decode-graph: the step is captured once in a hipGraph (vidi_amd/engine.py:make_decode_graph) and replayed;
+    # the capture (one eager step + graph build) is timed inside the leg, so s/query pays for it.
     torch.cuda.synchronize()
+    use_graph = world == 1 and a.decode_graph and a.decode_steps >= 2
+    t_capture = 0.0
     td0 = time.perf_counter()
-    for _ in range(a.decode_steps):
-        emb = eng.embed_tokens(nxt)
-        posn = ts.n_valid.clone(); ts.n_valid += 1
-        hn = eng.text_forward(emb, posn, ts, mm, Lq=1)
-        _, nxt = eng.logits_argmax(hn)
-        int(nxt[0])                                           # per-token D2H sync, as a stopping criterion needs
+    if use_graph:
+        nxt, replay = eng.make_decode_graph(ts, mm, nxt)
+        int(nxt[0])
+        t_capture = time.perf_counter() - td0
+        for _ in range(a.decode_steps - 1):
+            nxt = replay(nxt)
+            int(nxt[0])                                       # per-token D2H sync, as a stopping criterion needs
+    else:
+        for _ in range(a.decode_steps):
+            emb = eng.embed_tokens(nxt)
+            posn = ts.n_valid.clone(); ts.n_valid += 1
+            hn = eng.text_forward(emb, posn, ts, mm, Lq=1)
+            _, nxt = eng.logits_argmax(hn)
+            int(nxt[0])                                       # per-token D2H sync, as a stopping criterion needs
     torch.cuda.synchronize()
-    t_decode = (time.perf_counter() - td0) / max(1, a.decode_steps)
+    t_total_decode = time.perf_counter() - td0
+    t_decode = t_total_decode / max(1, a.decode_steps)
+    t_replay = (t_total_decode - t_capture) / max(1, a.decode_steps - 1) if use_graph else t_decode
 
     fam = timer.summary() if timer is not None else {}
     roof = None
@@ -237,7 +252,8 @@ def main():
                    "frames": T, "video_tokens": Nv, "audio_tokens": Na, "prompt_tokens": a.prompt_len,
                    "parallelism": f"frame-shard x{world} (K/V shards resident, LSE-merged cross-attention)" if world > 1 else "single GPU"},
         "sec_per_query": ms_per_step / 1e3 + a.decode_steps * t_decode, "decode_ms_per_token": t_decode * 1e3,
-        "decode_tokens": a.decode_steps, "frames_per_s": T * a.steps / dt,
+        "decode_tokens": a.decode_steps, "decode_graph": bool(use_graph), "decode_graph_capture_ms": t_capture * 1e3,
+        "decode_replay_ms_per_token": t_replay * 1e3, "frames_per_s": T * a.steps / dt,
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
         "kernel_families": fams,
         "roofline": roof,

@@ -119,6 +119,12 @@ int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF3
 int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
                    int B, int Lq, int Lmax, int nq, int nkv, int HD, int past_len, int window,
                    float scale, float softcap, int dtype, void* stream);
+/* Same, with the number of cached keys read from device memory at run time (`past_len_dev`, int32): nothing
+ * in the launch depends on the decode position, so a greedy decode step can be captured in a hipGraph and
+ * replayed (own generate() loop without per-token host work; replaces the HF loop gemma.py:646-687). */
+int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
+                       int B, int Lq, int Lmax, int nq, int nkv, int HD, const int* past_len_dev, int window,
+                       float scale, float softcap, int dtype, void* stream);
 /* apply_rotary_pos_emb in place (TP gemma2:146-168); cos/sin:[rows,HD] in the storage dtype. */
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
               int dtype, void* stream);

@@ -170,6 +170,31 @@ def test_generate_matches_oracle(tiny_setup):
     assert got.shape[1] <= n_new and got.dtype == torch.int64
 
 
+def test_graph_decode_equals_eager(tiny_setup, monkeypatch):
+    """The hipGraph-replayed decode (device-side cache position, vidi_attn_text_dyn) must emit exactly the
+    tokens of the eager per-launch loop, for a batch of two prompts of different lengths sharing one video."""
+    cfg, eng, w32, dt = tiny_setup
+    from vidi_amd.model import VidiForCausalLM
+    from types import SimpleNamespace
+    T, C = 3, 1
+    px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 116, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((C, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 117, 0.3).to(dt)
+    model = VidiForCausalLM.__new__(VidiForCausalLM)
+    model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
+    model.generation_config = SimpleNamespace(eos_token_id=-12345, pad_token_id=0)     # never stop early
+    model.model = None
+    ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26]], dtype=torch.int64)
+    n_new = 12
+    mm = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
+    monkeypatch.setenv("VIDI_DECODE_GRAPH", "0")
+    eager = model.generate(ids, mm_state=mm, max_new_tokens=n_new, do_sample=False).cpu()
+    monkeypatch.setenv("VIDI_DECODE_GRAPH", "1")
+    monkeypatch.setenv("VIDI_DECODE_GRAPH_MIN", "2")
+    graph = model.generate(ids, mm_state=mm, max_new_tokens=n_new, do_sample=False).cpu()
+    assert eager.shape == graph.shape == (1, n_new)
+    assert torch.equal(eager, graph), f"graph decode {graph.tolist()} != eager {eager.tolist()}"
+
+
 def test_real_dims_two_layers():
     """Gemma2-9B layer dims (H=3584, 16/8 heads x 256, I=14336), 2 layers, tiny towers: mm stream + text"""
     from vidi_amd.config import tiny

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(64) void attn_text_kernel(AttnTextParams p) {
     const int lane = threadIdx.x;
     const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int kvh = h / (p.nq / p.nkv);
-    const int qi = p.past_len + i;
+    const int qi = (p.past_len_dev ? *p.past_len_dev : p.past_len) + i;
     const int lo = (p.window > 0) ? max(0, qi - p.window) : 0;
     const int hiK = qi;                               // inclusive
     const u16* q = p.Q + ((size_t)b * p.Lq + i) * p.nq * HD + h * HD + lane * EPL;
@@ -88,7 +88,7 @@ int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStrea
     if (p.B <= 0 || p.Lq <= 0 || p.nq <= 0 || p.nkv <= 0 || p.nq % p.nkv) return VIDI_ERR_SHAPE;
     if (p.past_len + p.Lq > p.Lmax) return VIDI_ERR_SHAPE;
     const dim3 grid(p.Lq, p.nq, p.B);
-    const int lds = (p.past_len + p.Lq) * 4;
+    const int lds = (p.past_len_dev ? p.Lmax : p.past_len + p.Lq) * 4;      // device-side length: size for the whole cache
     if (lds > 64 * 1024) return VIDI_ERR_SHAPE;
     if (dtype == VIDI_DT_BF16) {
         if (HD == 256) hipLaunchKernelGGL((attn_text_kernel<BF16, 256>), grid, dim3(64), lds, st, p);

@@ -137,7 +137,19 @@ int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* km
     if (!Q || !Kc || !Vc || !O) return VIDI_ERR_ARG;
     AttnTextParams p;
     p.Q = (const u16*)Q; p.Kc = (const u16*)Kc; p.Vc = (const u16*)Vc; p.kmask = (const unsigned char*)kmask; p.O = (u16*)O;
-    p.B = B; p.Lq = Lq; p.Lmax = Lmax; p.nq = nq; p.nkv = nkv; p.past_len = past_len; p.window = window;
+    p.B = B; p.Lq = Lq; p.Lmax = Lmax; p.nq = nq; p.nkv = nkv; p.past_len = past_len; p.past_len_dev = nullptr; p.window = window;
+    p.scale = scale; p.softcap = softcap;
+    return vidi_attn_text_dispatch(p, HD, dtype, (hipStream_t)stream);
+}
+
+int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
+                       int B, int Lq, int Lmax, int nq, int nkv, int HD, const int* past_len_dev, int window,
+                       float scale, float softcap, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!Q || !Kc || !Vc || !O || !past_len_dev) return VIDI_ERR_ARG;
+    AttnTextParams p;
+    p.Q = (const u16*)Q; p.Kc = (const u16*)Kc; p.Vc = (const u16*)Vc; p.kmask = (const unsigned char*)kmask; p.O = (u16*)O;
+    p.B = B; p.Lq = Lq; p.Lmax = Lmax; p.nq = nq; p.nkv = nkv; p.past_len = 0; p.past_len_dev = past_len_dev; p.window = window;
     p.scale = scale; p.softcap = softcap;
     return vidi_attn_text_dispatch(p, HD, dtype, (hipStream_t)stream);
 }

@@ -64,6 +64,7 @@ struct AttnTextParams {
     u16* O;                       // [B, Lq, nq*HD]
     int B, Lq, Lmax, nq, nkv;
     int past_len;                 // key index of query row 0
+    const int* past_len_dev;      // if non-null, read past_len from device memory (graph-captured decode)
     int window;                   // <= 0: no sliding window
     float scale, softcap;
 };

@@ -87,6 +87,8 @@ class TextState:
     kmask: torch.Tensor                      # uint8 [B, Lmax]
     past_len: int = 0
     n_valid: Optional[torch.Tensor] = None   # int64 [B] number of valid tokens per row
+    pos_dev: Optional[torch.Tensor] = None   # int32 [1] device mirror of past_len (graph-captured decode)
+    pos_idx: Optional[torch.Tensor] = None   # int64 [1] same value, as an index tensor
 
 
 class VidiEngine:
@@ -551,9 +553,11 @@ class VidiEngine:
             dist.all_gather_into_tensor(out.view(cat_shape), inp, group=self.pg)
 
     def text_forward(self, hidden: torch.Tensor, positions: torch.Tensor, ts: TextState, mm: Optional[MMState],
-                     Lq: int, new_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     Lq: int, new_mask: Optional[torch.Tensor] = None, dyn: bool = False) -> torch.Tensor:
         """hidden: [B*Lq, H] embeds already multiplied by the normalizer; positions: int64 [B*Lq].
-        Appends Lq positions to the text cache.  Returns the final-norm hidden states [B*Lq, H]."""
+        Appends Lq positions to the text cache.  Returns the final-norm hidden states [B*Lq, H].
+        dyn=True (Lq == 1): the cache slot comes from the device scalars ts.pos_dev / ts.pos_idx, so nothing in the
+        launch sequence depends on the decode position (hipGraph capture); the caller advances them."""
         cfg = self.cfg
         B = ts.B
         H, nq, nkv, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -566,7 +570,11 @@ class VidiEngine:
         cos_t, sin_t = self._rope_tables(int(ts.Lmax) + 1)
         cos = cos_t.index_select(0, positions).contiguous()
         sin = sin_t.index_select(0, positions).contiguous()
-        if new_mask is None:
+        if dyn:
+            if Lq != 1 or new_mask is not None or ts.pos_dev is None:
+                raise RuntimeError("dyn text_forward is the single-token decode step")
+            ts.kmask.index_fill_(1, ts.pos_idx, 1)
+        elif new_mask is None:
             ts.kmask[:, p0: p0 + Lq] = 1
         else:
             ts.kmask[:, p0: p0 + Lq] = new_mask.to(torch.uint8)
@@ -591,11 +599,17 @@ class VidiEngine:
             kro = self._buf("t_k", (M, kvd))
             kro.copy_(kslice)
             hip.rope(qr, kro, cos, sin, rows=M, nq=nq, nkv=nkv, HD=hd)
-            ts.kc[li][:, p0: p0 + Lq].copy_(kro.view(B, Lq, kvd))
-            ts.vc[li][:, p0: p0 + Lq].copy_(qkv[:, nqd + kvd:].reshape(B, Lq, kvd))
             window = cfg.sliding_window if (li % 2 == 0) else 0                                       # gemma.py:104
-            hip.attn_text(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
-                          past_len=p0, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
+            if dyn:
+                ts.kc[li].index_copy_(1, ts.pos_idx, kro.view(B, 1, kvd))
+                ts.vc[li].index_copy_(1, ts.pos_idx, qkv[:, nqd + kvd:].reshape(B, 1, kvd))
+                hip.attn_text_dyn(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
+                                  past_len_dev=ts.pos_dev, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
+            else:
+                ts.kc[li][:, p0: p0 + Lq].copy_(kro.view(B, Lq, kvd))
+                ts.vc[li][:, p0: p0 + Lq].copy_(qkv[:, nqd + kvd:].reshape(B, Lq, kvd))
+                hip.attn_text(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
+                              past_len=p0, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
             k = 1
             qraw = qkv[:, :nqd]
             G = nq // nkv
@@ -619,8 +633,53 @@ class VidiEngine:
                 hip.gemm_geglu(hn, L["wgu"], gt)
             self.proj(gt, L["wdown"], dn)
             hip.norm(hip.NORM_GEMMA_ADD, dn, L["ln_post_ffn"], eps=eps, residual=hidden, out=hidden)    # :120-121
-        ts.past_len = p0 + Lq
+        if not dyn:
+            ts.past_len = p0 + Lq
         return hip.norm(hip.NORM_GEMMA, hidden, self.final_norm, eps=eps)                               # gemma.py:411
+
+    # ---- graph-captured greedy decode -------------------------------------------------
+    def decode_step_dyn(self, ids: torch.Tensor, ts: TextState, mm: Optional[MMState]) -> torch.Tensor:
+        """One greedy decode step whose launches do not depend on the position: embed(ids) -> 42 layers ->
+        lm_head/softcap/argmax; advances the device-side position scalars.  Returns next ids [B]."""
+        emb = self.embed_tokens(ids)
+        posn = ts.n_valid.clone()                                  # HF: position = cumsum(mask) - 1 of the new token
+        ts.n_valid += 1
+        hn = self.text_forward(emb, posn, ts, mm, Lq=1, dyn=True)
+        _, nxt = self.logits_argmax(hn)
+        ts.pos_dev += 1
+        ts.pos_idx += 1
+        return nxt
+
+    def make_decode_graph(self, ts: TextState, mm: Optional[MMState], first_ids: torch.Tensor):
+        """Runs ONE decode step eagerly on a side stream (warm-up, consumes `first_ids`), then captures the step in
+        a hipGraph.  Returns (next_ids_after_warmup, replay) where replay(ids) -> next ids advances the caches by
+        one token per call.  Single-GPU only: the sharded path has a host-driven collective per layer."""
+        if self.world > 1:
+            raise RuntimeError("graph-captured decode is single-GPU")
+        if ts.past_len + 2 > ts.Lmax:
+            raise RuntimeError("text KV cache exhausted")
+        ts.pos_dev = torch.tensor([ts.past_len], dtype=torch.int32, device=self.dev)
+        ts.pos_idx = torch.tensor([ts.past_len], dtype=torch.int64, device=self.dev)
+        g_in = first_ids.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            warm = self.decode_step_dyn(g_in, ts, mm)
+        torch.cuda.current_stream().wait_stream(side)
+        ts.past_len += 1
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_out = self.decode_step_dyn(g_in, ts, mm)
+
+        def replay(ids: torch.Tensor) -> torch.Tensor:
+            if ts.past_len + 1 > ts.Lmax:
+                raise RuntimeError("text KV cache exhausted")
+            g_in.copy_(ids)
+            graph.replay()
+            ts.past_len += 1
+            return g_out
+        replay.graph = graph
+        return warm, replay
 
     def logits_argmax(self, hn_last: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """lm_head + final softcap (gemma.py:565-569) + greedy argmax.  hn_last: [B, H]."""

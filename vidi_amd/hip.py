@@ -34,6 +34,7 @@ SIGNATURES = {
     "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
+    "vidi_attn_text_dyn": [_c_vp] * 5 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
     "vidi_norm": [_c_int] + [_c_vp] * 7 + [_c_int] * 2 + [_c_ll] * 3 + [_c_f, _c_f, _c_vp, _c_int, _c_vp],
     "vidi_scale": [_c_vp] * 2 + [_c_ll, _c_f, _c_int, _c_vp],
@@ -306,6 +307,15 @@ def attn_text(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len, wind
     lib = load_library()
     _check(lib.vidi_attn_text(_p(q), _p(kc), _p(vc), _p(kmask), _p(out), B, Lq, Lmax, nq, nkv, HD, past_len, window,
                               float(scale), float(softcap or 0.0), _dt(q), _stream()), "vidi_attn_text")
+
+
+def attn_text_dyn(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len_dev, window, scale, softcap):
+    """attn_text with the cache length in device memory (int32[1]): capturable in a hipGraph."""
+    if past_len_dev.dtype != torch.int32 or not past_len_dev.is_cuda:
+        raise VidiHipError("past_len_dev must be a device int32 tensor")
+    lib = load_library()
+    _check(lib.vidi_attn_text_dyn(_p(q), _p(kc), _p(vc), _p(kmask), _p(out), B, Lq, Lmax, nq, nkv, HD, _p(past_len_dev), window,
+                                  float(scale), float(softcap or 0.0), _dt(q), _stream()), "vidi_attn_text_dyn")
 
 
 def rope(q, k, cos, sin, *, rows, nq, nkv, HD):

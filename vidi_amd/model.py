@@ -12,6 +12,8 @@ The greedy loop is our own: HF GenerationMixin is not involve
 coupling to a transformers version.  Everything numeric runs in `VidiEngine` (HIP kernels)."""
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -182,6 +184,12 @@ class VidiForCausalLM:
         finished = torch.zeros(B, dtype=torch.bool, device=eng.dev)
         _, nxt = eng.logits_argmax(last)
         n_done = 0
+        # VIDI_DECODE_GRAPH=1: decode steps are replayed from a hipGraph (device-side cache position, no per-launch
+        # host work).  Measured on MI355X (60-min video): replay 19.3 ms/token vs 21.0 eager, capture 126 ms —
+        # it only pays for generations of ~80+ tokens, so it is opt-in; the sharded path stays eager.
+        use_graph = (eng.world == 1 and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
+                     and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1")
+        replay = None
         for step in range(max_new):
             nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
             out[:, step] = nxt
@@ -189,6 +197,12 @@ class VidiForCausalLM:
             finished = finished | (nxt == eos)
             if bool(finished.all()) or step == max_new - 1:          # one D2H sync per token, like HF's stopping criteria
                 break
+            if use_graph:
+                if replay is None:
+                    nxt, replay = eng.make_decode_graph(ts, mm_state, nxt)
+                else:
+                    nxt = replay(nxt).clone()
+                continue
             emb = eng.embed_tokens(nxt)
             posn = ts.n_valid.clone()                                  # HF: position = cumsum(mask) - 1 of the new token
             ts.n_valid += 1
