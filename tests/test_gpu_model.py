@@ -183,16 +183,48 @@ def test_graph_decode_equals_eager(tiny_setup, monkeypatch):
     model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
     model.generation_config = SimpleNamespace(eos_token_id=-12345, pad_token_id=0)     # never stop early
     model.model = None
-    ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26]], dtype=torch.int64)
+    ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26], [2, 31, -200, 32, 33, 0, 0, 0]], dtype=torch.int64)
+    am = torch.tensor([[1] * 8, [1] * 5 + [0] * 3], dtype=torch.int64)
     n_new = 12
     mm = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
     monkeypatch.setenv("VIDI_DECODE_GRAPH", "0")
-    eager = model.generate(ids, mm_state=mm, max_new_tokens=n_new, do_sample=False).cpu()
+    eager = model.generate(ids, attention_mask=am, mm_state=mm, max_new_tokens=n_new, do_sample=False).cpu()
     monkeypatch.setenv("VIDI_DECODE_GRAPH", "1")
     monkeypatch.setenv("VIDI_DECODE_GRAPH_MIN", "2")
-    graph = model.generate(ids, mm_state=mm, max_new_tokens=n_new, do_sample=False).cpu()
-    assert eager.shape == graph.shape == (1, n_new)
+    graph = model.generate(ids, attention_mask=am, mm_state=mm, max_new_tokens=n_new, do_sample=False).cpu()
+    assert eager.shape == graph.shape == (2, n_new)
     assert torch.equal(eager, graph), f"graph decode {graph.tolist()} != eager {eager.tolist()}"
+
+
+def test_batched_queries_share_one_video(tiny_setup):
+    """BASELINE config 5 shape: several prompts of different lengths (right-padded) against ONE encoded video.
+    Every row's next-token logits must match the same prompt run alone (padding must be invisible)."""
+    cfg, eng, w32, dt = tiny_setup
+    from vidi_amd.model import VidiForCausalLM
+    from types import SimpleNamespace
+    px = seeded((3, 3, cfg.vis_image_size, cfg.vis_image_size), 126, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 127, 0.3).to(dt)
+    model = VidiForCausalLM.__new__(VidiForCausalLM)
+    model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
+    model.generation_config = SimpleNamespace(eos_token_id=-12345, pad_token_id=0)
+    model.model = None
+    mm = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
+    prompts = [[2, 21, 22, 23, -200, 24, 25, 26], [2, 31, -200, 32], [2, 41, 42, -200, 43, 44, 45, 46, 47, 48],
+               [2, -200, 51], [2, 61, 62, 63, 64, -200, 65], [2, 71, -200, 72, 73, 74], [2, 81, 82, -200, 83], [2, 91, -200, 92, 93]]
+    L = max(len(p) for p in prompts)
+    ids = torch.zeros((len(prompts), L), dtype=torch.int64)
+    am = torch.zeros((len(prompts), L), dtype=torch.int64)
+    for i, p in enumerate(prompts):
+        ids[i, : len(p)] = torch.tensor(p); am[i, : len(p)] = 1
+    out = model.forward(ids, attention_mask=am, mm_state=mm)
+    lb = out.logits.float().cpu()                                  # [B, L-1, V] (the <image> position is cut)
+    for i, p in enumerate(prompts):
+        single = model.forward(torch.tensor([p]), mm_state=mm).logits.float().cpu()[0]
+        n = len(p) - 1
+        atol, rtol = tol(dt, single.std().item())
+        report(f"batched row {i}", lb[i, :n], single, 3 * atol, rtol)
+    toks = model.generate(ids, attention_mask=am, mm_state=mm, max_new_tokens=4, do_sample=False).cpu()
+    assert toks.shape == (len(prompts), 4)
 
 
 def test_real_dims_two_layers():
