@@ -50,7 +50,11 @@ IMAGE_TOKEN_INDEX = -200     # constants.py:11
 # --------------------------------------------------------------------------------------------
 @dataclass
 class OracleConfig:
-    # LLM (Gemma2)
+    # "gemma2" = Vidi1.5-9B (Vidi1.5_9B/vidi/model/lmm/dattn/gemma.py); "mistral" = Vidi-7B
+    # (Vidi_7B/model/lmm/dattn/mistral.py): plain RMSNorm, no post-norms, SiLU-GLU, no softcaps, no embedding
+    # normalizer, learned Conv2DPool (Vidi_7B/model/mm_vision/pool.py) instead of the token-budget resize
+    arch: str = "gemma2"
+    # LLM
     hidden_size: int = 3584
     intermediate_size: int = 14336
     num_hidden_layers: int = 42
@@ -105,6 +109,20 @@ def gemma_rmsnorm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
     out = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
     out = out * (1.0 + weight.float())
     return out.type_as(x)
+
+
+def mistral_rmsnorm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
+    """MistralRMSNorm (transformers modeling_mistral, used by Vidi_7B/.../mistral.py:131-134): variance in
+    fp32, normalised tensor cast back to the input dtype, THEN multiplied by the weight."""
+    xf = x.float()
+    h = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return weight * h.to(x.dtype)
+
+
+def llm_rmsnorm(x: Tensor, weight: Tensor, cfg: "OracleConfig") -> Tensor:
+    if cfg.arch == "mistral":
+        return mistral_rmsnorm(x, weight, cfg.rms_norm_eps)
+    return gemma_rmsnorm(x, weight, cfg.rms_norm_eps)
 
 
 def mm_rms_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
@@ -283,6 +301,14 @@ def token_budget_hw(T: int, side: int, pool: int, base: int = 60000) -> Tuple[in
     return 28, 28
 
 
+def learned_conv2d_pool(x: Tensor, weight: Tensor, s_out: int) -> Tensor:
+    """Vidi-7B Conv2DPool.forward — Vidi_7B/model/mm_vision/pool.py:19-26: bias-free conv with kernel
+    ceil(s_in/s_out) (stride 1), then bilinear resize to s_out x s_out with align_corners=True."""
+    x = F.conv2d(x, weight)
+    assert x.shape[-1] >= s_out
+    return F.interpolate(x, size=s_out, mode="bilinear", align_corners=True)
+
+
 def conv2d_pool(x: Tensor, hw: Tuple[int, int], merge: int = 2) -> Tensor:
     """Conv2DPool.forward — mm_vision/pool.py:23-32.  x:[B,C,side,side]."""
     x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
@@ -337,8 +363,11 @@ def encode_video_images(images: Sequence[Tensor], w: W, cfg: OracleConfig,
     feats = siglip_forward(concat, w, cfg) if vis_features is None else vis_features   # :163-169
     side = cfg.vis_side
     feats = feats.reshape(len(feats), side, side, -1).permute(0, 3, 1, 2)              # :171-173
-    hw = token_budget_hw(feats.size(0), side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)  # :175-180
-    feats = conv2d_pool(feats, hw, cfg.mm_image_pool_size)                              # :182-189
+    if cfg.arch == "mistral":                                                           # Vidi_7B/.../multimodal.py:165-170
+        feats = learned_conv2d_pool(feats, w[m + "mm_rand_img_pool.conv.weight"], cfg.mm_image_pool_size)
+    else:
+        hw = token_budget_hw(feats.size(0), side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)  # :175-180
+        feats = conv2d_pool(feats, hw, cfg.mm_image_pool_size)                          # :182-189
     feats = feats.permute(0, 2, 3, 1)                                                   # :190
     feats = projector_mlp(feats, w, m + "mm_rand_img_projector.")                       # :192
     feats = mm_RMSNorm(feats, w[m + "mm_rand_img_norm.weight"])                         # :193
@@ -539,8 +568,18 @@ def gemma_mlp(x: Tensor, w: W, lp: str) -> Tensor:
     return linear(g * u, w[lp + "mlp.down_proj.weight"])
 
 
+def mistral_mlp(x: Tensor, w: W, lp: str) -> Tensor:
+    """MistralMLP: down(silu(gate(x)) * up(x))."""
+    g = F.silu(linear(x, w[lp + "mlp.gate_proj.weight"]))
+    u = linear(x, w[lp + "mlp.up_proj.weight"])
+    return linear(g * u, w[lp + "mlp.down_proj.weight"])
+
+
 def feed_forward(x: Tensor, w: W, lp: str, cfg: OracleConfig) -> Tensor:
-    """DattnGemma2DecoderLayer.feed_foward — gemma.py:116-123."""
+    """DattnGemma2DecoderLayer.feed_foward — gemma.py:116-123; Vidi-7B: mistral.py:131-137."""
+    if cfg.arch == "mistral":
+        h = mistral_rmsnorm(x, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        return x + mistral_mlp(h, w, lp)
     h = gemma_rmsnorm(x, w[lp + "pre_feedforward_layernorm.weight"], cfg.rms_norm_eps)
     h = gemma_mlp(h, w, lp)
     h = gemma_rmsnorm(h, w[lp + "post_feedforward_layernorm.weight"], cfg.rms_norm_eps)
@@ -551,13 +590,14 @@ def mm_stream_layer(x: Tensor, w: W, lp: str, cfg: OracleConfig) -> Tuple[Tensor
     """The per-token 'diagonal' stream of one layer on mm tokens x:[B,N,H] — gemma.py:183-184,
     61-62, 196-202.  Returns (x_next, k[B,N,Hkv*D], v[B,N,Hkv*D])."""
     nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-    h = gemma_rmsnorm(x, w[lp + "input_layernorm.weight"], cfg.rms_norm_eps)
+    h = llm_rmsnorm(x, w[lp + "input_layernorm.weight"], cfg)
     k = linear(h, w[lp + "self_attn.k_proj.weight"])
     v = linear(h, w[lp + "self_attn.v_proj.weight"])
     B, N, _ = v.shape
     vrep = repeat_kv(v.view(B, N, nkv, hd).transpose(1, 2), nq // nkv).transpose(1, 2).flatten(2, 3)
     o = linear(vrep, w[lp + "self_attn.o_proj.weight"])
-    o = gemma_rmsnorm(o, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+    if cfg.arch != "mistral":                                                           # 7B: mistral.py:224-227 (no post norm)
+        o = gemma_rmsnorm(o, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
     x = x + o
     return feed_forward(x, w, lp, cfg), k, v
 
@@ -569,9 +609,10 @@ def decoder_layer(hidden: Tensor, cos: Tensor, sin: Tensor, text_mask: Tensor,
                   ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
     """DattnGemma2DecoderLayer.forward, multimodal branch — gemma.py:153-244."""
     lp = f"model.layers.{layer_idx}."
-    sliding = not bool(layer_idx % 2)                                                   # :104
+    mistral = cfg.arch == "mistral"
+    sliding = True if mistral else (not bool(layer_idx % 2))                            # :104; Mistral: every layer
     residual = hidden
-    h = gemma_rmsnorm(hidden, w[lp + "input_layernorm.weight"], cfg.rms_norm_eps)       # :162
+    h = llm_rmsnorm(hidden, w[lp + "input_layernorm.weight"], cfg)                      # :162 / mistral.py:187
     t = text_self_attn(h, cos, sin, text_mask, w, lp, cfg, caches.text, layer_idx, past_len, sliding)   # :165-175
 
     def branch(embeds, mask, cache):
@@ -579,13 +620,14 @@ def decoder_layer(hidden: Tensor, cos: Tensor, sin: Tensor, text_mask: Tensor,
         n_valid = torch.sum(mask, dim=-1)                                               # :180
         m2 = mask.clone()
         m2[n_valid == 0] = True                                                         # :181-182
-        kv_in = embeds if use_cache else gemma_rmsnorm(embeds, w[lp + "input_layernorm.weight"], cfg.rms_norm_eps)  # :183-184
+        kv_in = embeds if use_cache else llm_rmsnorm(embeds, w[lp + "input_layernorm.weight"], cfg)  # :183-184
         o, vrep = forward_xattn(h, kv_in, m2, w, lp, cfg, cache, layer_idx)             # :185-191
         o = o * (n_valid != 0)[:, None, None]                                           # :192
         if not use_cache:                                                               # :195-202
             vflat = vrep.flatten(2, 3)
             u = linear(vflat, w[lp + "self_attn.o_proj.weight"])
-            u = gemma_rmsnorm(u, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+            if not mistral:
+                u = gemma_rmsnorm(u, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
             embeds = embeds + u
             embeds = feed_forward(embeds, w, lp, cfg)
         return o, embeds
@@ -598,8 +640,11 @@ def decoder_layer(hidden: Tensor, cos: Tensor, sin: Tensor, text_mask: Tensor,
         a_out, audio_embeds = branch(audio_embeds, audio_mask, caches.audio)
     else:
         a_out = 0.0                                                                     # :233
-    s = t + i_out + a_out                                                               # :236
-    hidden = residual + gemma_rmsnorm(s, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)  # :237
+    if mistral:
+        hidden = residual + t + i_out + a_out                                           # mistral.py:261 (left to right)
+    else:
+        s = t + i_out + a_out                                                           # :236
+        hidden = residual + gemma_rmsnorm(s, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)  # :237
     hidden = feed_forward(hidden, w, lp, cfg)                                           # :238
     return hidden, image_embeds, audio_embeds
 
@@ -611,17 +656,19 @@ def model_forward(inputs_embeds: Tensor, position_ids: Tensor, text_mask: Tensor
     """DattnGemma2Model.forward — gemma.py:267-424.  Returns last_hidden_state [B,Lq,H]."""
     dt = inputs_embeds.dtype
     cos, sin = rope_cos_sin(position_ids, cfg.head_dim, cfg.rope_theta, dt)             # :348
-    normalizer = torch.tensor(cfg.hidden_size ** 0.5, dtype=dt)                          # :353 (rounds in fp16/bf16)
-    hidden = inputs_embeds * normalizer                                                 # :354
-    if image_embeds is not None:
-        image_embeds = image_embeds * normalizer                                        # :355
-    if audio_embeds is not None:
-        audio_embeds = audio_embeds * normalizer                                        # :356
+    hidden = inputs_embeds
+    if cfg.arch != "mistral":                                                           # Mistral has no embedding normalizer (mistral.py:369)
+        normalizer = torch.tensor(cfg.hidden_size ** 0.5, dtype=dt)                      # :353 (rounds in fp16/bf16)
+        hidden = inputs_embeds * normalizer                                             # :354
+        if image_embeds is not None:
+            image_embeds = image_embeds * normalizer                                    # :355
+        if audio_embeds is not None:
+            audio_embeds = audio_embeds * normalizer                                    # :356
     for li in range(cfg.num_hidden_layers):                                             # :362-406
         hidden, image_embeds, audio_embeds = decoder_layer(
             hidden, cos, sin, text_mask, image_embeds, image_mask, audio_embeds, audio_mask,
             w, cfg, caches, li, past_len)
-    return gemma_rmsnorm(hidden, w["model.norm.weight"], cfg.rms_norm_eps)              # :411
+    return llm_rmsnorm(hidden, w["model.norm.weight"], cfg)                             # :411 / mistral.py:423
 
 
 def lm_logits(hidden: Tensor, w: W, cfg: OracleConfig) -> Tensor:

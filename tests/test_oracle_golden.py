@@ -59,3 +59,13 @@ def test_projector_mlp():
     w = {"m.model.0.weight": t("mlp_model.0.weight"), "m.model.0.bias": t("mlp_model.0.bias"),
          "m.model.2.weight": t("mlp_model.2.weight"), "m.model.2.bias": t("mlp_model.2.bias")}
     torch.testing.assert_close(O.projector_mlp(t("mlp_x"), w, "m."), t("mlp_y"), rtol=0, atol=0)
+
+
+def test_vidi7b_learned_conv2d_pool():
+    """Vidi-7B Conv2DPool (learned conv + align_corners=True resize) against the reference module's own output."""
+    g7 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules_7b.npz"))
+    for tag in "abcd":
+        d_in, d_out, s_in, s_out = [int(v) for v in g7[f"{tag}_cfg"]]
+        y = O.learned_conv2d_pool(torch.from_numpy(g7[f"{tag}_x"]), torch.from_numpy(g7[f"{tag}_w"]), s_out)
+        assert y.shape == (2, d_out, s_out, s_out)
+        np.testing.assert_allclose(y.numpy(), g7[f"{tag}_y"], rtol=1e-6, atol=1e-6)

@@ -56,6 +56,43 @@ def test_gemma2_blocks_match_hf():
     assert torch.equal(qo, qh) and torch.equal(ko, kh)
 
 
+def test_mistral_text_decoder_matches_hf():
+    """Vidi-7B's text-only path is plain MistralModel (mistral.py:169-174 falls through to super().forward)."""
+    from transformers import MistralConfig, MistralModel
+    torch.manual_seed(4)
+    hc = MistralConfig(vocab_size=128, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                       num_key_value_heads=2, head_dim=16, sliding_window=64, rms_norm_eps=1e-5, rope_theta=10000.0,
+                       max_position_embeddings=128, pad_token_id=0, attn_implementation="eager")
+    m = MistralModel(hc).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0, 0.05)
+    w = {"model." + k: v.detach() for k, v in m.state_dict().items()}
+    cfg = _ocfg(arch="mistral", hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, head_dim=16, query_pre_attn_scalar=16.0, sliding_window=64, vocab_size=128,
+                rms_norm_eps=1e-5, attn_logit_softcapping=None, final_logit_softcapping=None)
+    ids = torch.tensor([[5, 9, 33, 7, 100, 42, 17]])
+    with torch.no_grad():
+        ref = m(input_ids=ids, use_cache=False).last_hidden_state
+    emb = torch.nn.functional.embedding(ids, w["model.embed_tokens.weight"])
+    pos = torch.arange(ids.shape[1])[None]
+    am = torch.ones_like(ids, dtype=torch.bool)
+    got = O.model_forward(emb, pos, am, None, None, None, None, w, cfg, O.OracleCaches(), 0)
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_mistral_blocks_match_hf():
+    from transformers.models.mistral import modeling_mistral as M
+    torch.manual_seed(5)
+    x = torch.randn(3, 5, 64)
+    n = M.MistralRMSNorm(64, eps=1e-5)
+    with torch.no_grad():
+        n.weight.normal_(1.0, 0.3)
+    torch.testing.assert_close(O.mistral_rmsnorm(x, n.weight.detach(), 1e-5), n(x), rtol=0, atol=0)
+    xb = x.to(torch.bfloat16)
+    assert torch.equal(O.mistral_rmsnorm(xb, n.weight.detach().to(torch.bfloat16), 1e-5), n.to(torch.bfloat16)(xb))
+
+
 def test_siglip_tower_matches_hf():
     from transformers import SiglipVisionConfig, SiglipVisionModel
     torch.manual_seed(2)
