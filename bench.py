@@ -142,9 +142,12 @@ def main():
     ids = torch.randint(1000, min(200000, cfg.vocab_size), (a.queries, a.prompt_len + 1), generator=gi)
     ids[:, 0] = cfg.bos_token_id
     ids[:, 4] = -200
-    hw = token_budget_hw(T, cfg.vis_side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)
-    h, w = hw if hw[0] != 28 else (cfg.vis_side + 1, cfg.vis_side + 1)
-    Nv = T * (h // cfg.mm_image_pool_size) * (w // cfg.mm_image_pool_size)
+    if cfg.arch == "mistral":                                   # Vidi-7B: fixed pool x pool tokens per frame (learned Conv2DPool)
+        Nv = T * cfg.mm_image_pool_size ** 2
+    else:
+        hw = token_budget_hw(T, cfg.vis_side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)
+        h, w = hw if hw[0] != 28 else (cfg.vis_side + 1, cfg.vis_side + 1)
+        Nv = T * (h // cfg.mm_image_pool_size) * (w // cfg.mm_image_pool_size)
     Na = audio_token_counts(audio_size, cfg)[1]
     one = torch.ones(1, dtype=torch.int32, device=dev)         # sample-level "any non-zero input" flag (synthetic: true)
 
@@ -246,10 +249,10 @@ def main():
             for k, v in fam.items()}
 
     res = {
-        "metric": "video-tokens/sec (prefill), Vidi1.5-9B 1h@1fps", "value": value, "unit": "video-tokens/s",
+        "metric": "video-tokens/sec (prefill), Vidi1.5-9B 1h@1fps" if cfg.arch != "mistral" else "video-tokens/sec (prefill), Vidi-7B", "value": value, "unit": "video-tokens/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (random frames/mel/prompt, random-init weights)",
-        "config": {"workload": f"Vidi1.5-9B prefill, {T} frames@1fps 384px (+{Cw} audio windows, {a.prompt_len}-token prompt)",
+        "config": {"workload": f"{'Vidi-7B' if cfg.arch == 'mistral' else 'Vidi1.5-9B'} prefill, {T} frames@1fps 384px (+{Cw} audio windows, {a.prompt_len}-token prompt)",
                    "frames": T, "video_tokens": Nv, "audio_tokens": Na, "prompt_tokens": a.prompt_len,
                    "parallelism": f"frame-shard x{world} (K/V shards resident, LSE-merged cross-attention)" if world > 1 else "single GPU"},
         # one video, `queries` prompts answered together: the encode + stream prefill is shared

@@ -33,6 +33,7 @@ extern "C" {
 #define VIDI_ACT_NONE 0
 #define VIDI_ACT_GELU_TANH 1
 #define VIDI_ACT_GELU_ERF 2
+#define VIDI_ACT_SILU 3
 
 #define VIDI_NORM_GEMMA 0      /* TP/models/gemma2/modeling_gemma2.py:55-63                        */
 #define VIDI_NORM_GEMMA_ADD 1  /* residual + Gemma2RMSNorm(x): lmm/dattn/gemma.py:121,201,237       */
@@ -128,6 +129,20 @@ int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void
 /* apply_rotary_pos_emb in place (TP gemma2:146-168); cos/sin:[rows,HD] in the storage dtype. */
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
               int dtype, void* stream);
+
+/* ---- Vidi-7B (Mistral) variants of the same path (Vidi_7B/model/lmm/dattn/mistral.py) ---------------- */
+/* Gated MLP with selectable activation: act = VIDI_ACT_GELU_TANH (Gemma2MLP, same as vidi_gemm_geglu) or
+ * VIDI_ACT_SILU (MistralMLP, mistral.py:131-137 via transformers MistralMLP): Y = T(act(T(x Wg^T))) * T(x Wu^T). */
+int vidi_gemm_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
+                  int act, int tile_cfg, int dtype, void* stream);
+/* Decode-path companion: applies the gate to the raw interleaved [M, 2I] GEMV output. */
+int vidi_glu_unpack(const void* Yp, void* out, int M, int I, int act, int dtype, void* stream);
+/* Learned Conv2DPool of Vidi-7B (Vidi_7B/model/mm_vision/pool.py:19-26) = im2col (this) + vidi_gemm with the
+ * [d_out, k*k*C] repacked kernel + align_corners=True bilinear resize (below).  x:[T, side*side, C] tower
+ * features, out:[T*(side-k+1)^2, k*k*C], column = (dy*k+dx)*C + c. */
+int vidi_im2col_nhwc(const void* x, void* out, int T, int side, int C, int k, int dtype, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=True) on NHWC: x:[T,s_in,s_in,C] -> out:[T,s_out,s_out,C]. */
+int vidi_resize_bilinear_ac(const void* x, void* out, int T, int s_in, int s_out, int C, int dtype, void* stream);
 
 /* ---- row-wise normalisations (see VIDI_NORM_*) ------------------------------------------------ */
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,

@@ -17,6 +17,7 @@ def oracle_cfg(cfg) -> O.OracleConfig:
     names = {f.name for f in dataclasses.fields(O.OracleConfig)}
     d = {k: v for k, v in cfg.to_dict().items() if k in names}
     d["vis_select_layer"] = cfg.mm_vision_select_layer
+    d["arch"] = cfg.arch
     return O.OracleConfig(**d)
 
 

@@ -79,3 +79,28 @@ def test_compat_import_paths():
         sys.path.pop(0)
         for k in [k for k in sys.modules if k == "vidi" or k.startswith("vidi.")]:
             del sys.modules[k]
+
+
+def test_compat_import_paths_7b():
+    """Vidi_7B/inference.py:8-12 import paths resolve through vidi_amd/compat_7b."""
+    sys.path.insert(0, os.path.join(ROOT, "vidi_amd", "compat_7b"))
+    try:
+        for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
+            del sys.modules[k]
+        from model.constants import IMAGE_TOKEN_INDEX, DEFAULT_IMAGE_TOKEN
+        from model.builder import load_pretrained_model
+        from model.img_utils import process_images
+        from model.txt_utils import tokenizer_image_token, preprocess_chat
+        from model.vid_utils import load_video, load_audio, process_audio
+        assert IMAGE_TOKEN_INDEX == -200 and DEFAULT_IMAGE_TOKEN == "<image>" and callable(load_pretrained_model)
+
+        class Tok:
+            bos_token = "<s>"
+
+            def apply_chat_template(self, messages, tokenize=False):
+                return "<s>" + "".join(f"[INST] {m['content']} [/INST]" if m["role"] == "user" else m["content"] for m in messages)
+        assert preprocess_chat([{"from": "human", "value": "hi"}], Tok()) == "[INST] hi [/INST]"
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
+            del sys.modules[k]

@@ -69,8 +69,18 @@ class VidiConfig:
     aud_chunks_per_batch: int = 60          # Whisper activation chunk (30-s windows)
 
     @property
+    def arch(self) -> str:
+        """'gemma2' (Vidi1.5-9B, DattnGemma2*) or 'mistral' (Vidi-7B, DattnMistral*: Vidi_7B/model/lmm/dattn/mistral.py)."""
+        return "mistral" if "mistral" in self.model_type else "gemma2"
+
+    @property
     def vis_side(self) -> int:
         return self.vis_image_size // self.vis_patch_size
+
+    @property
+    def img_pool_kernel(self) -> int:
+        """Vidi-7B learned Conv2DPool kernel size: ceil(s_in / s_out) (Vidi_7B/model/mm_vision/pool.py:15-17)."""
+        return -(-self.vis_side // self.mm_image_pool_size)
 
     @property
     def vis_select_layers(self) -> int:
@@ -83,6 +93,19 @@ class VidiConfig:
     @classmethod
     def from_dict(cls, d: dict) -> "VidiConfig":
         known = {f.name for f in fields(cls)}
+        d = dict(d)
+        if "mistral" in str(d.get("model_type", "")):
+            # a Vidi-7B config.json is a MistralConfig + mm_* keys: no head_dim / query_pre_attn_scalar / softcaps
+            hd = d.get("head_dim") or d["hidden_size"] // d["num_attention_heads"]
+            d.setdefault("head_dim", hd)
+            d["head_dim"] = hd
+            d.setdefault("query_pre_attn_scalar", float(hd))
+            d.setdefault("attn_logit_softcapping", None)
+            d.setdefault("final_logit_softcapping", None)
+            d.setdefault("tie_word_embeddings", False)
+            d.setdefault("rms_norm_eps", 1e-5)
+            if d.get("sliding_window") is None:
+                d["sliding_window"] = 1 << 30
         return cls(**{k: v for k, v in d.items() if k in known})
 
     @classmethod
@@ -102,6 +125,19 @@ def vidi15_9b() -> VidiConfig:
     return VidiConfig()
 
 
+def vidi_7b() -> VidiConfig:
+    """External dims of Vidi-7B: Mistral-7B (32 layers, 32/8 heads x 128, SiLU-GLU 14336, no softcaps, untied
+    lm_head) + siglip-so400m-patch14-384 + whisper-large-v3 with the learned Conv2DPool
+    (Vidi_7B/model/lmm/dattn/mistral.py:456-470, multimodal.py:63-94).  mm_image_pool_size / vocab come from the
+    checkpoint's config.json; the values here are the ones used for synthetic runs."""
+    return VidiConfig(
+        model_type="dattn_mistral", hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+        num_key_value_heads=8, head_dim=128, query_pre_attn_scalar=128.0, attn_logit_softcapping=None,
+        final_logit_softcapping=None, rms_norm_eps=1e-5, rope_theta=10000.0, sliding_window=4096, vocab_size=32000,
+        eos_token_id=2, pad_token_id=0, bos_token_id=1, tie_word_embeddings=False,
+        mm_image_pool_size=2, mm_vision_tower="google/siglip-so400m-patch14-384")
+
+
 def tiny(**over) -> VidiConfig:
     """Small config exercising every padding path (odd patch grid, tower head_dim 16, fc1 pad 176->192, GQA 4/2)."""
     cfg = VidiConfig(
@@ -113,6 +149,16 @@ def tiny(**over) -> VidiConfig:
         aud_max_source_positions=50, aud_nb_max_frames=100,
         vis_frames_per_chunk=4, aud_chunks_per_batch=2,
     )
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def tiny_7b(**over) -> VidiConfig:
+    """Small Mistral-arch (Vidi-7B) config: plain RMSNorm, SiLU-GLU, untied head, learned conv pool (7 -> 2, k = 4)."""
+    cfg = tiny(model_type="dattn_mistral", attn_logit_softcapping=None, final_logit_softcapping=None, rms_norm_eps=1e-5,
+               tie_word_embeddings=False, mm_image_pool_size=2, head_dim=128, query_pre_attn_scalar=128.0,
+               num_attention_heads=4, num_key_value_heads=2)
     for k, v in over.items():
         setattr(cfg, k, v)
     return cfg

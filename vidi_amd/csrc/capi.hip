@@ -53,6 +53,18 @@ int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K
     return vidi_gemm_dispatch(p, 1, MODE_GEGLU, 0, tile_cfg, dtype, (hipStream_t)stream);
 }
 
+int vidi_gemm_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
+                  int act, int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wgu || !Y) return VIDI_ERR_ARG;
+    if (I % 32) return VIDI_ERR_SHAPE;
+    if (act != ACT_GELU_TANH && act != ACT_SILU) return VIDI_ERR_ARG;
+    GemmParams p = base_params(X, Wgu, nullptr, Y, nullptr, M, 2 * I, K, ldx, ldw, ldy, 0, 0);
+    p.act = act;
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_GEGLU, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, void* Vt,
                      int M, int N, int K, int ldx, int ldw, int ldy,
                      int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream) {
@@ -220,8 +232,33 @@ int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* 
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!Yp || !out) return VIDI_ERR_ARG;
     void* a[2] = {(void*)Yp, out};
-    const long long i[2] = {M, I};
+    const long long i[3] = {M, I, ACT_GELU_TANH};
     return vidi_ew_dispatch(EW_GEGLU_UNPACK, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_glu_unpack(const void* Yp, void* out, int M, int I, int act, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!Yp || !out) return VIDI_ERR_ARG;
+    if (act != ACT_GELU_TANH && act != ACT_SILU) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)Yp, out};
+    const long long i[3] = {M, I, act};
+    return vidi_ew_dispatch(EW_GEGLU_UNPACK, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_im2col_nhwc(const void* x, void* out, int T, int side, int C, int k, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !out || T <= 0 || side <= 0 || k <= 0 || k > side || C % 8) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)x, out};
+    const long long i[4] = {T, side, C, k};
+    return vidi_ew_dispatch(EW_IM2COL_NHWC, a, i, nullptr, dtype, (hipStream_t)stream);
+}
+
+int vidi_resize_bilinear_ac(const void* x, void* out, int T, int s_in, int s_out, int C, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !out || T <= 0 || s_in <= 0 || s_out <= 0 || C % 8) return VIDI_ERR_ARG;
+    void* a[2] = {(void*)x, out};
+    const long long i[4] = {T, s_in, s_out, C};
+    return vidi_ew_dispatch(EW_RESIZE_AC, a, i, nullptr, dtype, (hipStream_t)stream);
 }
 
 int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream) {

@@ -103,6 +103,9 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float e = __builtin_amdgcn_exp2f(c0 * w);              // exp(-2u); +inf for very negative x -> result -0
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+__device__ __forceinline__ float silu_f(float x) {                   // x * sigmoid(x) (MistralMLP act), branch-free
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
     // 0.5*x*(1+erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7), branch-free
     const float z = fabsf(x) * 0.7071067811865476f;

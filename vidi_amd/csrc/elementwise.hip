@@ -120,6 +120,56 @@ __global__ void add3_kernel(const u16* a, const u16* b, const u16* c, u16* y, si
     }
 }
 
+// ---- Vidi-7B learned Conv2DPool (Vidi_7B/model/mm_vision/pool.py:19-26) as im2col + GEMM + resize -------------
+// im2col of a stride-1, bias-free k x k convolution over NHWC tower features x[T][side*side][C]:
+// out[(t, oy, ox)][(dy*k + dx)*C + c] = x[t][(oy+dy)*side + (ox+dx)][c]; 16-byte copies.
+template <typename T>
+__global__ void im2col_nhwc_kernel(const u16* __restrict__ x, u16* __restrict__ out, int Tn, int side, int C, int k) {
+    const int oc = side - k + 1, c8 = C / 8;
+    const size_t total = (size_t)Tn * oc * oc * k * k * c8;
+    GRID_STRIDE(idx, total) {
+        const int c = idx % c8;
+        size_t r = idx / c8;
+        const int dx = r % k; r /= k;
+        const int dy = r % k; r /= k;
+        const int ox = r % oc; r /= oc;
+        const int oy = r % oc;
+        const size_t t = r / oc;
+        const u32x4 v = *(const u32x4*)(x + ((t * side + (oy + dy)) * side + (ox + dx)) * (size_t)C + c * 8);
+        *(u32x4*)(out + idx * 8) = v;
+    }
+}
+
+// F.interpolate(mode='bilinear', align_corners=True) on NHWC x[T][s_in][s_in][C] -> out[T][s_out][s_out][C];
+// source coordinate = dst * (s_in-1)/(s_out-1) (0 when s_out == 1), fp32 opmath, one rounding.
+template <typename T>
+__global__ void resize_ac_kernel(const u16* __restrict__ x, u16* __restrict__ out, int Tn, int s_in, int s_out, int C) {
+    const int c8 = C / 8;
+    const size_t total = (size_t)Tn * s_out * s_out * c8;
+    const float sc = (s_out > 1) ? (float)(s_in - 1) / (float)(s_out - 1) : 0.f;
+    GRID_STRIDE(idx, total) {
+        const int c = idx % c8;
+        size_t r = idx / c8;
+        const int ox = r % s_out; r /= s_out;
+        const int oy = r % s_out;
+        const size_t t = r / s_out;
+        const float fy = sc * oy, fx = sc * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, s_in - 1), x1 = min(x0 + 1, s_in - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        float a[8], b[8], cc[8], d[8], y[8];
+        const u16* base = x + t * (size_t)s_in * s_in * C + c * 8;
+        unpack8<T>(*(const u32x4*)(base + ((size_t)y0 * s_in + x0) * C), a);
+        unpack8<T>(*(const u32x4*)(base + ((size_t)y0 * s_in + x1) * C), b);
+        unpack8<T>(*(const u32x4*)(base + ((size_t)y1 * s_in + x0) * C), cc);
+        unpack8<T>(*(const u32x4*)(base + ((size_t)y1 * s_in + x1) * C), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            y[e] = (1.f - ly) * ((1.f - lx) * a[e] + lx * b[e]) + ly * ((1.f - lx) * cc[e] + lx * d[e]);
+        *(u32x4*)(out + idx * 8) = pack8<T>(y);
+    }
+}
+
 // ---- embed_tokens gather * normalizer — multimodal.py:385 + gemma.py:353-354 --------------------
 template <typename T>
 __global__ void embed_kernel(const long long* __restrict__ ids, const u16* __restrict__ E, u16* __restrict__ out,
@@ -146,14 +196,14 @@ __global__ void embed_kernel(const long long* __restrict__ ids, const u16* __res
 // ---- GeGLU on the 32-row-interleaved [gate|up] layout produced by the skinny GEMM path ----------
 //   out[m][i] = T(T(gelu_tanh(g)) * u), g = Y[m][(i/32)*64 + i%32], u = Y[m][(i/32)*64 + 32 + i%32]
 template <typename T>
-__global__ void geglu_unpack_kernel(const u16* __restrict__ Yp, u16* __restrict__ out, int M, int I) {
+__global__ void geglu_unpack_kernel(const u16* __restrict__ Yp, u16* __restrict__ out, int M, int I, int silu) {
     const size_t total = (size_t)M * I;
     GRID_STRIDE(idx, total) {
         const int i = idx % I;
         const size_t m = idx / I;
         const size_t base = m * 2 * (size_t)I + (size_t)(i >> 5) * 64 + (i & 31);
         const float g = T::to_f32(Yp[base]), u = T::to_f32(Yp[base + 32]);
-        out[idx] = T::from_f32(rnd<T>(gelu_tanh_f(g)) * u);
+        out[idx] = T::from_f32(rnd<T>(silu ? silu_f(g) : gelu_tanh_f(g)) * u);
     }
 }
 
@@ -287,7 +337,7 @@ static int ew_dispatch_T(int op, void** a, const long long* i, const float* f, h
             if (i[1] % 32) return VIDI_ERR_SHAPE;
             const size_t total = (size_t)i[0] * i[1];
             hipLaunchKernelGGL(geglu_unpack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const u16*)a[0], (u16*)a[1],
-                               (int)i[0], (int)i[1]);
+                               (int)i[0], (int)i[1], (int)(i[2] == ACT_SILU));
             break;
         }
         case EW_SOFTCAP_ARGMAX: {
@@ -305,6 +355,19 @@ static int ew_dispatch_T(int op, void** a, const long long* i, const float* f, h
             if (i[0] % 8) return VIDI_ERR_SHAPE;
             const size_t n8 = (size_t)i[0] / 8;
             hipLaunchKernelGGL(scale_kernel<T>, dim3(grid_for(n8)), dim3(256), 0, st, (const u16*)a[0], (u16*)a[1], n8, f[0]);
+            break;
+        }
+        case EW_IM2COL_NHWC: {
+            const long long oc = i[1] - i[3] + 1;
+            const size_t total = (size_t)i[0] * oc * oc * i[3] * i[3] * (i[2] / 8);
+            hipLaunchKernelGGL(im2col_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const u16*)a[0], (u16*)a[1],
+                               (int)i[0], (int)i[1], (int)i[2], (int)i[3]);
+            break;
+        }
+        case EW_RESIZE_AC: {
+            const size_t total = (size_t)i[0] * i[2] * i[2] * (i[3] / 8);
+            hipLaunchKernelGGL(resize_ac_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const u16*)a[0], (u16*)a[1],
+                               (int)i[0], (int)i[1], (int)i[2], (int)i[3]);
             break;
         }
         case EW_ANY_NONZERO: {

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     u16* Yb = p.Y + bz * p.bsY;
     const u16* Rb = p.R ? p.R + bz * p.bsR : nullptr;
     const bool act_tanh = (p.act == ACT_GELU_TANH), act_erf = (p.act == ACT_GELU_ERF);
+    const bool glu_silu = (p.act == ACT_SILU);                     // MODE_GEGLU: SiLU-GLU (Mistral) instead of GELU(tanh)-GLU (Gemma2)
     constexpr int BNO = (MODE == MODE_GEGLU) ? BN / 2 : BN;       // output columns of this tile
     constexpr int CROW = BNO * 2 + 16;                            // padded LDS row (bytes)
     __syncthreads();                                              // every wave is done with the last K slice
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                     for (int e = 0; e < 4; ++e) {
                         const float g = rnd<T>(acc[a][b][4 * j + e]);
                         const float u = rnd<T>(acc[a + TPB][b][4 * j + e]);
-                        v[e] = rnd<T>(gelu_tanh_f(g)) * u;
+                        v[e] = rnd<T>(glu_silu ? silu_f(g) : gelu_tanh_f(g)) * u;
                     }
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                     *(u32x2*)(sC + ml * CROW + nol * 2) = o;

@@ -3,7 +3,7 @@
 #include "common.h"
 
 enum { MODE_PLAIN = 0, MODE_GEGLU = 1, MODE_QKV_VT = 2, MODE_KV_CACHE = 3 };
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3 };
 enum { NORM_GEMMA = 0, NORM_GEMMA_ADD = 1, NORM_MM = 2, NORM_MM_NOW = 3, NORM_LLM = 4, NORM_LAYER = 5 };
 #define EW_IM2COL 0
 #define EW_POOL 1
@@ -15,6 +15,8 @@ enum { NORM_GEMMA = 0, NORM_GEMMA_ADD = 1, NORM_MM = 2, NORM_MM_NOW = 3, NORM_LL
 #define EW_MEL_T 7
 #define EW_SCALE 8
 #define EW_ANY_NONZERO 9
+#define EW_IM2COL_NHWC 10
+#define EW_RESIZE_AC 11
 
 struct GemmParams {
     const u16* X; const u16* W; const u16* bias; u16* Y; const u16* R;

@@ -100,7 +100,11 @@ class VidiEngine:
         self.cfg = cfg
         self.dtype = dtype
         self.dev = torch.device(device)
-        self.normalizer = float(torch.tensor(cfg.hidden_size ** 0.5, dtype=dtype).float())   # gemma.py:353
+        self.mistral = cfg.arch == "mistral"                                                  # Vidi-7B wiring (mistral.py)
+        # gemma.py:353 multiplies every embedding stream by sqrt(H) rounded to the model dtype; Mistral has no normalizer
+        self.normalizer = 1.0 if self.mistral else float(torch.tensor(cfg.hidden_size ** 0.5, dtype=dtype).float())
+        self.glu_act = hip.ACT_SILU if self.mistral else hip.ACT_GELU_TANH
+        self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._ws: Dict[str, torch.Tensor] = {}
@@ -139,8 +143,10 @@ class VidiEngine:
             L["wgu"] = torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous()
             del gate, up
             L["wdown"] = g(p + "mlp.down_proj.weight")
-            for n, k in (("input_layernorm", "ln_in"), ("post_attention_layernorm", "ln_post_attn"),
-                         ("pre_feedforward_layernorm", "ln_pre_ffn"), ("post_feedforward_layernorm", "ln_post_ffn")):
+            norm_names = (("input_layernorm", "ln_in"), ("post_attention_layernorm", "ln_post_attn")) if cfg.arch == "mistral" else \
+                (("input_layernorm", "ln_in"), ("post_attention_layernorm", "ln_post_attn"),
+                 ("pre_feedforward_layernorm", "ln_pre_ffn"), ("post_feedforward_layernorm", "ln_post_ffn"))
+            for n, k in norm_names:
                 L[k] = g(p + n + ".weight")
             for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
                       "mlp.up_proj", "mlp.down_proj"):
@@ -203,6 +209,11 @@ class VidiEngine:
             "img_norm": g(m + "mm_rand_img_norm.weight"), "aud_norm": g(m + "mm_rand_aud_norm.weight"),
             "llm_norm": g(m + "mm_rand_llm_norm.weight"),
         }
+        if cfg.arch == "mistral":
+            # learned Conv2DPool kernel [d_out, d_in, k, k] -> GEMM weight [d_out, (dy*k+dx)*d_in + c] (im2col_nhwc order)
+            cw = g(m + "mm_rand_img_pool.conv.weight")
+            self.mm["img_pool_w"] = cw.permute(0, 2, 3, 1).reshape(cw.shape[0], -1).contiguous()
+            pop(m + "mm_rand_img_pool.conv.weight")
         for n in ("h", "w", "t"):
             for k in ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"):
                 self.mm[f"pos_{n}.{k}"] = g(f"{m}mm_rand_pos_{n}.{k}", fp32=True)
@@ -288,13 +299,29 @@ class VidiEngine:
         Ttot = total_frames if total_frames is not None else T
         side, pool, Hv, H = cfg.vis_side, cfg.mm_image_pool_size, cfg.vis_hidden_size, cfg.hidden_size
         f = self.siglip_forward(pixel) if vis_features is None else vis_features
-        hw = token_budget_hw(Ttot, side, pool, cfg.mm_max_tokens_base)                      # global T decides
-        resize = hw[0] != 28
-        h, w = hw if resize else (side + 1, side + 1)
-        oh, ow = h // pool, w // pool
-        C4 = Hv * pool * pool
-        pooled = torch.empty((T * oh * ow, C4), dtype=self.dtype, device=self.dev)
-        hip.pool_s2d(f, pooled, T=T, side=side, C=Hv, h=h, w=w, m=pool, resize=resize)
+        if self.mistral:
+            # Vidi-7B: learned conv (k = ceil(side/pool), stride 1) -> bilinear(align_corners=True) to pool x pool
+            # (Vidi_7B/.../multimodal.py:165-170, mm_vision/pool.py:19-26); no token-budget rule
+            k = cfg.img_pool_kernel
+            oc = side - k + 1
+            oh = ow = pool
+            pooled = torch.empty((T * oh * ow, Hv), dtype=self.dtype, device=self.dev)
+            fc = max(1, min(T, (1 << 30) // (oc * oc * k * k * Hv * 2)))              # im2col chunk <= 1 GiB
+            f3 = f.reshape(T, side * side, Hv)
+            for t0 in range(0, T, fc):
+                t1 = min(T, t0 + fc)
+                col = self._buf("pool_col", ((t1 - t0) * oc * oc, k * k * Hv))
+                hip.im2col_nhwc(f3[t0:t1], col, T=t1 - t0, side=side, C=Hv, k=k)
+                conv = hip.gemm(col, self.mm["img_pool_w"], None)
+                hip.resize_bilinear_ac(conv, pooled[t0 * oh * ow: t1 * oh * ow], T=t1 - t0, s_in=oc, s_out=pool, C=Hv)
+        else:
+            hw = token_budget_hw(Ttot, side, pool, cfg.mm_max_tokens_base)                  # global T decides
+            resize = hw[0] != 28
+            h, w = hw if resize else (side + 1, side + 1)
+            oh, ow = h // pool, w // pool
+            C4 = Hv * pool * pool
+            pooled = torch.empty((T * oh * ow, C4), dtype=self.dtype, device=self.dev)
+            hip.pool_s2d(f, pooled, T=T, side=side, C=Hv, h=h, w=w, m=pool, resize=resize)
         p1 = hip.gemm(pooled, self.mm["img_w0"], self.mm["img_b0"], act=hip.ACT_GELU_ERF)
         p2 = hip.gemm(p1, self.mm["img_w2"], self.mm["img_b2"])
         x = hip.norm(hip.NORM_MM, p2, self.mm["img_norm"], eps=1e-5)
@@ -437,10 +464,16 @@ class VidiEngine:
         gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
         eps = cfg.rms_norm_eps
         for li, L in enumerate(self.layers if ntot > 0 else []):
-            hip.norm(hip.NORM_GEMMA, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184
+            hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184 / mistral.py:204-205
             hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
             if li == Lr - 1:
                 break                                                                                # dead update on the last layer
+            if self.mistral:
+                hip.gemm(vrow, L["wo"], None, X, repkv=(hd, G), K=G * kvd, residual=X)               # mistral.py:219-221: x += o_proj(repeat_kv(V))
+                hip.norm(hip.NORM_MM, X, L["ln_post_attn"], eps=eps, out=hbuf)                       # :131-134 feed_foward
+                hip.gemm_glu(hbuf, L["wgu"], gt, act=hip.ACT_SILU)
+                hip.gemm(gt, L["wdown"], None, X, residual=X)                                        # :135
+                continue
             hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)                               # :196-197 o_proj(repeat_kv(V))
             hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_attn"], eps=eps, residual=X, out=X)           # :198-201
             hip.norm(hip.NORM_GEMMA, X, L["ln_pre_ffn"], eps=eps, out=hbuf)                          # :118
@@ -591,15 +624,16 @@ class VidiEngine:
         gt = self._buf("t_g", (M, cfg.intermediate_size))
         dn = self._buf("t_d", (M, H))
         sc = cfg.query_pre_attn_scalar ** -0.5
+        tmp = self._buf("t_tmp", (M, H)) if self.mistral else None
         for li, L in enumerate(self.layers):
-            hip.norm(hip.NORM_GEMMA, hidden, L["ln_in"], eps=eps, out=hn)                           # gemma.py:162
+            hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                           # gemma.py:162 / mistral.py:187
             self.proj(hn, L["wqkv"], qkv)
             qr.copy_(qkv[:, :nqd])                                                                   # RoPE'd copy for T2T; raw q for x-attn (:58)
             kslice = qkv[:, nqd: nqd + kvd]
             kro = self._buf("t_k", (M, kvd))
             kro.copy_(kslice)
             hip.rope(qr, kro, cos, sin, rows=M, nq=nq, nkv=nkv, HD=hd)
-            window = cfg.sliding_window if (li % 2 == 0) else 0                                       # gemma.py:104
+            window = cfg.sliding_window if (self.mistral or li % 2 == 0) else 0                       # gemma.py:104; Mistral: every layer
             if dyn:
                 ts.kc[li].index_copy_(1, ts.pos_idx, kro.view(B, 1, kvd))
                 ts.vc[li].index_copy_(1, ts.pos_idx, qkv[:, nqd + kvd:].reshape(B, 1, kvd))
@@ -619,6 +653,24 @@ class VidiEngine:
                 self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G); k += 1
             # one o_proj pass over the stacked [text; image; audio] attention outputs (gemma.py:94 x3)
             self.proj(att[: nstream * M], L["wo"], oall[: nstream * M])
+            if self.mistral:
+                # mistral.py:261: residual + text + image + audio, evaluated left to right (each sum rounds), then
+                # feed_foward = x + mlp(post_attention_layernorm(x)) (:131-137)
+                if nstream <= 2:
+                    hip.add3(hidden, oall[:M], oall[M: 2 * M] if nstream == 2 else None, hidden)
+                else:
+                    hip.add3(hidden, oall[:M], oall[M: 2 * M], tmp)
+                    hip.add3(tmp, oall[2 * M: 3 * M], None, hidden)
+                hip.norm(hip.NORM_MM, hidden, L["ln_post_attn"], eps=eps, out=hn)
+                if M <= 8:
+                    hip.gemv(hn, L["wgu"], yp)
+                    hip.glu_unpack(yp, gt, hip.ACT_SILU)
+                    hip.gemv(gt, L["wdown"], dn)
+                    hip.add3(hidden, dn, None, hidden)
+                else:
+                    hip.gemm_glu(hn, L["wgu"], gt, act=hip.ACT_SILU)
+                    hip.gemm(gt, L["wdown"], None, hidden, residual=hidden)
+                continue
             if nstream == 1:
                 src = oall[:M]
             else:
@@ -635,7 +687,7 @@ class VidiEngine:
             hip.norm(hip.NORM_GEMMA_ADD, dn, L["ln_post_ffn"], eps=eps, residual=hidden, out=hidden)    # :120-121
         if not dyn:
             ts.past_len = p0 + Lq
-        return hip.norm(hip.NORM_GEMMA, hidden, self.final_norm, eps=eps)                               # gemma.py:411
+        return hip.norm(self.norm_mode, hidden, self.final_norm, eps=eps)                               # gemma.py:411 / mistral.py:423
 
     # ---- graph-captured greedy decode -------------------------------------------------
     def decode_step_dyn(self, ids: torch.Tensor, ts: TextState, mm: Optional[MMState]) -> torch.Tensor:

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvidi_hip.so")
 
 DT_BF16, DT_F16 = 0, 1
-ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
 NORM_GEMMA, NORM_GEMMA_ADD, NORM_MM, NORM_MM_NOW, NORM_LLM, NORM_LAYER = range(6)
 
 _c_int, _c_ll, _c_f, _c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
@@ -26,6 +26,10 @@ _c_int, _c_ll, _c_f, _c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ct
 SIGNATURES = {
     "vidi_gemm": [_c_vp] * 5 + [_c_int] * 8 + [_c_ll] * 3 + [_c_int] * 6 + [_c_vp],
     "vidi_gemm_geglu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
+    "vidi_gemm_glu": [_c_vp] * 3 + [_c_int] * 9 + [_c_vp],
+    "vidi_glu_unpack": [_c_vp] * 2 + [_c_int] * 4 + [_c_vp],
+    "vidi_im2col_nhwc": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
+    "vidi_resize_bilinear_ac": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
     "vidi_gemm_qkv_vt": [_c_vp] * 5 + [_c_int] * 13 + [_c_vp],
     "vidi_gemm_kv_cache": [_c_vp] * 5 + [_c_int] * 10 + [_c_vp],
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
@@ -236,6 +240,19 @@ def gemm_geglu(x: torch.Tensor, wgu: torch.Tensor, out: Optional[torch.Tensor] =
     return out
 
 
+def gemm_glu(x: torch.Tensor, wgu: torch.Tensor, out: Optional[torch.Tensor] = None, act: int = ACT_GELU_TANH,
+             tile_cfg: int = -1) -> torch.Tensor:
+    """Gated MLP front half, act(gate) * up fused in the epilogue: ACT_GELU_TANH (Gemma2) or ACT_SILU (Mistral)."""
+    lib = load_library()
+    M, K = x.shape
+    I = wgu.shape[0] // 2
+    if out is None:
+        out = torch.empty((M, I), dtype=x.dtype, device=x.device)
+    _check(lib.vidi_gemm_glu(_p(x), _p(wgu), _p(out), M, I, K, x.stride(0), wgu.stride(0), out.stride(0),
+                             act, tile_cfg, _dt(x), _stream()), "vidi_gemm_glu")
+    return out
+
+
 def gemm_qkv_vt(x, w, bias, yqk, vt, *, vstart, hd, seq, seqpad, nheads, tile_cfg=-1):
     lib = load_library()
     M, K = x.shape
@@ -370,6 +387,22 @@ def embed(ids, E, out, *, normalizer):
 def geglu_unpack(yp, out):
     M, I2 = yp.shape
     _check(load_library().vidi_geglu_unpack(_p(yp), _p(out), M, I2 // 2, _dt(yp), _stream()), "vidi_geglu_unpack")
+    return out
+
+
+def glu_unpack(yp, out, act=ACT_GELU_TANH):
+    M, I2 = yp.shape
+    _check(load_library().vidi_glu_unpack(_p(yp), _p(out), M, I2 // 2, act, _dt(yp), _stream()), "vidi_glu_unpack")
+    return out
+
+
+def im2col_nhwc(x, out, *, T, side, C, k):
+    _check(load_library().vidi_im2col_nhwc(_p(x), _p(out), T, side, C, k, _dt(x), _stream()), "vidi_im2col_nhwc")
+    return out
+
+
+def resize_bilinear_ac(x, out, *, T, s_in, s_out, C):
+    _check(load_library().vidi_resize_bilinear_ac(_p(x), _p(out), T, s_in, s_out, C, _dt(x), _stream()), "vidi_resize_bilinear_ac")
     return out
 
 

@@ -175,6 +175,11 @@ class VidiForCausalLM:
         pad = eos if pad is None else pad
         attention_mask = kwargs.get("attention_mask", None)
         eng = self.engine
+        if eng.mistral and attention_mask is not None and int(attention_mask[:, -1].sum()) != attention_mask.shape[0]:
+            # Vidi_7B/.../mistral.py:366-373: batched generation with right padding is rejected
+            raise ValueError("You are attempting to perform batched generation with padding_side='right' this may lead to "
+                             "unexpected behaviour for Flash Attention version of Mistral. Make sure to call "
+                             "`tokenizer.padding_side  = 'left'` before tokenizing the input. ")
         ids, mask, pos = strip_image_token(inputs, attention_mask)
         if mm_state is None and (images is not None or audios is not None):
             mm_state = self.encode_mm_state(images, audios, audio_sizes)

@@ -51,6 +51,12 @@ def preprocess_chat(source: Sequence[Dict[str, str]], tokenizer) -> str:
     return chat_template(source, tokenizer, roles_chat=("user", "model"), roles_data=("human", "gpt")) + "<start_of_turn>model\n"
 
 
+def preprocess_chat_mistral(source: Sequence[Dict[str, str]], tokenizer) -> str:
+    """Vidi-7B chat text: the tokenizer's Mistral [INST] template with user/assistant roles and no generation suffix
+    (Vidi_7B/model/txt_utils.py:78-86, 135-140)."""
+    return chat_template(source, tokenizer, roles_chat=("user", "assistant"), roles_data=("human", "gpt"))
+
+
 # ------------------------------------------------------------------------------------------------
 # images  (img_utils.py:173-198) — 'resize' is the released video configuration
 # ------------------------------------------------------------------------------------------------

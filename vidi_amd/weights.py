@@ -29,7 +29,9 @@ def weight_shapes(cfg: VidiConfig) -> Dict[str, tuple]:
         s[p + "mlp.gate_proj.weight"] = (I, H)
         s[p + "mlp.up_proj.weight"] = (I, H)
         s[p + "mlp.down_proj.weight"] = (H, I)
-        for n in ("input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm"):
+        norms = ("input_layernorm", "post_attention_layernorm") if cfg.arch == "mistral" else \
+            ("input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm")
+        for n in norms:
             s[p + n + ".weight"] = (H,)
     # SigLIP
     Hv, Iv, P = cfg.vis_hidden_size, cfg.vis_intermediate_size, cfg.vis_patch_size
@@ -65,7 +67,13 @@ def weight_shapes(cfg: VidiConfig) -> Dict[str, tuple]:
     # mm glue
     m = "model."
     pool = cfg.mm_image_pool_size
-    s[m + "mm_rand_img_projector.model.0.weight"] = (H, Hv * pool * pool); s[m + "mm_rand_img_projector.model.0.bias"] = (H,)
+    if cfg.arch == "mistral":                                   # learned Conv2DPool feeds the projector directly
+        k = cfg.img_pool_kernel
+        s[m + "mm_rand_img_pool.conv.weight"] = (Hv, Hv, k, k)
+        s[m + "mm_rand_img_projector.model.0.weight"] = (H, Hv)
+    else:
+        s[m + "mm_rand_img_projector.model.0.weight"] = (H, Hv * pool * pool)
+    s[m + "mm_rand_img_projector.model.0.bias"] = (H,)
     s[m + "mm_rand_img_projector.model.2.weight"] = (H, H); s[m + "mm_rand_img_projector.model.2.bias"] = (H,)
     s[m + "mm_rand_aud_pool.weight"] = (H, Da, cfg.mm_audio_pool_size)
     s[m + "mm_rand_aud_projector.model.0.weight"] = (H, H); s[m + "mm_rand_aud_projector.model.0.bias"] = (H,)
@@ -94,8 +102,10 @@ def init_random_weights(cfg: VidiConfig, seed: int = 3, dtype: torch.dtype = tor
         dt = torch.float32 if is_fp32_param(name) else dtype
         if name.endswith("mm_rand_llm_norm.weight"):
             t = torch.full(shape, cfg.mm_std, dtype=torch.float32, device=dev)
-        elif "layernorm.weight" in name or name == "model.norm.weight":        # Gemma (1+w) form
+        elif ("layernorm.weight" in name or name == "model.norm.weight") and cfg.arch != "mistral":   # Gemma (1+w) form
             t = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.1
+        elif "layernorm.weight" in name or name == "model.norm.weight":        # Mistral plain-weight form
+            t = 1.0 + torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.1
         elif name.endswith("norm.weight") or "layer_norm" in name and name.endswith(".weight"):
             t = 1.0 + torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.1
         elif name.endswith(".bias"):
