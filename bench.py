@@ -230,7 +230,7 @@ def main():
     if "gemm" in fam:
         gm = fam["gemm"]
         ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12
-        roof = {"kernel": "gemm_kernel (MFMA 32x32x16, all GEMM launches of the timed steps)", "bound": "mfma",
+        roof = {"kernel": "gemm_kernel (MFMA 16x16x32 bf16, 256x256x64 tiles; all GEMM launches of the timed steps)", "bound": "mfma",
                 "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
                 "launches": gm["launches"], "avg_launch_ms": gm["ms"] / gm["launches"],
                 "algorithmic_flop_per_launch_avg": gm["work"] / gm["launches"],
