@@ -700,7 +700,8 @@ def generate_greedy(input_ids: Tensor, images: Optional[Sequence[Tensor]], audio
     last = hidden[torch.arange(B), lens - 1]                                            # last valid token per row
     logits = lm_logits(last[:, None, :], w, cfg)[:, 0]
     debug = {"prefill_logits": logits.clone(), "image_embeds": img, "image_mask": imask,
-             "audio_embeds": aud, "audio_mask": amask}
+             "audio_embeds": aud, "audio_mask": amask, "prefill_hidden": hidden, "text_mask": am, "position_ids": pos,
+             "caches": caches, "step_logits": []}
     out = []
     finished = torch.zeros(B, dtype=torch.bool)
     text_mask = am.clone()
@@ -719,6 +720,7 @@ def generate_greedy(input_ids: Tensor, images: Optional[Sequence[Tensor]], audio
         hidden = model_forward(e, p, text_mask, img, imask, aud, amask, w, cfg, caches, cur_len)
         cur_len += 1
         logits = lm_logits(hidden, w, cfg)[:, 0]
+        debug["step_logits"].append(logits.clone())
     ids_out = torch.stack(out, dim=1)
     return (ids_out, debug) if return_debug else ids_out
 
