@@ -139,6 +139,16 @@ class ListCache:
     def get_seq_length(self, layer_idx=0):
         return 0 if len(self.key_cache) <= layer_idx else self.key_cache[layer_idx].shape[-2]
 
+    @classmethod
+    def from_legacy_cache(cls, past_key_values=None):
+        c = cls()
+        for i, (k, v) in enumerate(past_key_values or ()):
+            c.update(k, v, i)
+        return c
+
+    def to_legacy_cache(self):
+        return tuple(zip(self.key_cache, self.value_cache))
+
 
 class TextCache(ListCache):
     """Stands in for HybridCache(config, max_batch_size, max_cache_len, dtype): the reference only constructs it and hands
@@ -213,3 +223,60 @@ def install():
     G.DynamicCache = ListCache                                         # the 4.50 protocol (`cache[layer]`, `len(cache)`)
     G.HybridCache = TextCache
     return G, MM, X, mg
+
+
+REF_7B = "/root/reference/Vidi_7B"
+
+
+def install_7b():
+    """Same for Vidi_7B/model (package name `model`; pinned transformers 4.44.2, flash-attn 2.6.3).  Extra stand-in:
+    `modeling_mistral.MistralFlashAttention2` (removed in 5.x) = the installed `MistralAttention` (same projections, RoPE,
+    GQA arithmetic) behind the 4.44 call signature `(hidden_states, attention_mask, position_ids, past_key_value, ...)
+    -> (out, None, past_key_value)`, attending through `_t2t_attention` above."""
+    import transformers  # noqa: F401
+    import transformers.generation.utils  # noqa: F401
+    import transformers.models.mistral.modeling_mistral as mm
+    import transformers.models.siglip.modeling_siglip  # noqa: F401
+    import transformers.models.whisper.modeling_whisper  # noqa: F401
+    import transformers.models.clip.modeling_clip  # noqa: F401
+    import transformers.utils as tu
+    import transformers.cache_utils as cu
+
+    fa = _stub("flash_attn", flash_attn_func=flash_attn_func, flash_attn_varlen_func=flash_attn_varlen_func)
+    fa.__path__ = []
+    _stub("flash_attn.bert_padding", index_first_axis=index_first_axis, pad_input=pad_input, unpad_input=unpad_input)
+    for n in ("decord", "cv2", "ffmpeg"):
+        if n not in sys.modules:
+            try:
+                __import__(n)
+            except Exception:
+                _stub(n)
+    tu.is_flash_attn_2_available = lambda: True
+    tu.is_flash_attn_greater_or_equal = lambda v: True
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS, PreTrainedModel
+    ALL_ATTENTION_FUNCTIONS["flash_attention_2"] = _t2t_attention
+    PreTrainedModel._check_and_adjust_attn_implementation = lambda self, attn_implementation, *a, **k: attn_implementation or "eager"
+
+    class MistralFlashAttention2(mm.MistralAttention):
+        def __init__(self, config, layer_idx=None):
+            super().__init__(config, layer_idx)
+            self.hidden_size = config.hidden_size
+            self.num_heads = config.num_attention_heads
+            self.num_key_value_heads = config.num_key_value_heads
+            self.rotary_emb = mm.MistralRotaryEmbedding(config=config)
+
+        def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                    output_attentions=False, use_cache=False, cache_position=None, **kwargs):
+            pe = self.rotary_emb(hidden_states, position_ids)
+            out, _ = super().forward(hidden_states, pe, attention_mask, past_key_value=past_key_value,
+                                     cache_position=cache_position)
+            return out, None, past_key_value
+
+    mm.MistralFlashAttention2 = MistralFlashAttention2
+    cu.DynamicCache = ListCache
+    if REF_7B not in sys.path:
+        sys.path.insert(0, REF_7B)
+    import model.lmm.dattn.mistral as M7
+    M7.DynamicCache = ListCache
+    M7.Cache = ListCache                                               # `isinstance(past_key_values, Cache)` (mistral.py:338)
+    return M7, mm

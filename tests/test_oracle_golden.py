@@ -166,3 +166,29 @@ def test_dattn_all_zero_video_branch(dattn_setup):
     assert not d("C_image_mask").any() and not dbg["image_mask"].any()
     _close("C prefill logits", dbg["prefill_logits"], d("C_prefill_logits"))
     assert toks.tolist() == D["C_tokens"].tolist()
+
+
+# ---- Vidi-7B: the reference's mistral.py / multimodal.py (learned Conv2DPool, Da->Da audio pool) executed the same way
+D7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_dattn_7b.npz"))
+
+
+def test_dattn_7b_matches_reference_execution():
+    from vidi_amd.config import tiny_7b
+    from vidi_amd.weights import init_random_weights
+    cfg = tiny_7b(head_dim=64, query_pre_attn_scalar=64.0, sliding_window=64)      # = make_golden_dattn_7b.golden_config()
+    w = init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu")
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    ocfg = O.OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in names}, vis_select_layer=cfg.mm_vision_select_layer, arch="mistral")
+    t7 = lambda n: torch.from_numpy(D7[n])                                          # noqa: E731
+    toks, dbg = O.generate_greedy(t7("A_input_ids"), list(t7("A_images")), list(t7("A_audios")), D7["A_audio_sizes"].tolist(),
+                                  w, ocfg, 5, return_debug=True)
+    assert torch.equal(dbg["image_mask"], t7("A_image_mask")) and torch.equal(dbg["audio_mask"], t7("A_audio_mask"))
+    _close("7B image_embeds", dbg["image_embeds"], t7("A_image_embeds"))
+    _close("7B audio_embeds", dbg["audio_embeds"], t7("A_audio_embeds"))
+    for li in range(cfg.num_hidden_layers):
+        _close(f"7B img K layer {li}", dbg["caches"].image[li][0], t7(f"A_img_k_{li}"))
+        _close(f"7B img V layer {li}", dbg["caches"].image[li][1], t7(f"A_img_v_{li}"))
+    _close("7B final hidden", dbg["prefill_hidden"], t7("A_prefill_hidden_last"))
+    _close("7B prefill logits", dbg["prefill_logits"], t7("A_prefill_logits"))
+    assert toks.tolist() == D7["A_tokens"].tolist()
+    _close("7B step logits", torch.stack(dbg["step_logits"], dim=1), t7("A_step_logits"))

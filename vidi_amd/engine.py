@@ -203,7 +203,8 @@ class VidiEngine:
         self.mm = {
             "img_w0": g(m + "mm_rand_img_projector.model.0.weight"), "img_b0": g(m + "mm_rand_img_projector.model.0.bias"),
             "img_w2": g(m + "mm_rand_img_projector.model.2.weight"), "img_b2": g(m + "mm_rand_img_projector.model.2.bias"),
-            "aud_pool": g(m + "mm_rand_aud_pool.weight").permute(0, 2, 1).reshape(H, -1).contiguous(),   # k = tap*Da + c
+            # Conv1d weight [d_out, Da, k] -> GEMM weight [d_out, tap*Da + c]; d_out = H (Vidi1.5) or Da (Vidi-7B)
+            "aud_pool": (lambda t: t.permute(0, 2, 1).reshape(t.shape[0], -1).contiguous())(g(m + "mm_rand_aud_pool.weight")),
             "aud_w0": g(m + "mm_rand_aud_projector.model.0.weight"), "aud_b0": g(m + "mm_rand_aud_projector.model.0.bias"),
             "aud_w2": g(m + "mm_rand_aud_projector.model.2.weight"), "aud_b2": g(m + "mm_rand_aud_projector.model.2.bias"),
             "img_norm": g(m + "mm_rand_img_norm.weight"), "aud_norm": g(m + "mm_rand_aud_norm.weight"),

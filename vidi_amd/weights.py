@@ -75,8 +75,11 @@ def weight_shapes(cfg: VidiConfig) -> Dict[str, tuple]:
         s[m + "mm_rand_img_projector.model.0.weight"] = (H, Hv * pool * pool)
     s[m + "mm_rand_img_projector.model.0.bias"] = (H,)
     s[m + "mm_rand_img_projector.model.2.weight"] = (H, H); s[m + "mm_rand_img_projector.model.2.bias"] = (H,)
-    s[m + "mm_rand_aud_pool.weight"] = (H, Da, cfg.mm_audio_pool_size)
-    s[m + "mm_rand_aud_projector.model.0.weight"] = (H, H); s[m + "mm_rand_aud_projector.model.0.bias"] = (H,)
+    # Vidi1.5: Conv1d(Da -> H) then MLP(H -> H) (Vidi1.5_9B/.../multimodal.py:85-92); Vidi-7B: Conv1d(Da -> Da) then
+    # MLP(Da -> H) (Vidi_7B/.../multimodal.py:80-87)
+    Dp = Da if cfg.arch == "mistral" else H
+    s[m + "mm_rand_aud_pool.weight"] = (Dp, Da, cfg.mm_audio_pool_size)
+    s[m + "mm_rand_aud_projector.model.0.weight"] = (H, Dp); s[m + "mm_rand_aud_projector.model.0.bias"] = (H,)
     s[m + "mm_rand_aud_projector.model.2.weight"] = (H, H); s[m + "mm_rand_aud_projector.model.2.bias"] = (H,)
     for n in ("mm_rand_img_norm", "mm_rand_aud_norm", "mm_rand_llm_norm"):
         s[m + n + ".weight"] = (H,)
