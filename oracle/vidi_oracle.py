@@ -6,20 +6,20 @@ kernels in `vidi_amd/csrc` can be checked against something that follows the ref
 line.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it;
 nothing under `vidi_amd/` does.  It is never the product path.
 
-Parity status: **the reference pins nothing for this path** (it ships no tests, golden vectors or
-known-answer values — SURVEY.md §4/§8c) and cannot itself run in this environment (flash-attn /
-liger / deepspeed / transformers-4.50 are absent).  What pins this oracle instead:
-  * the reference modules that *are* importable by file path (`mm_layer/norm.py`, `mm_layer/mlp.py`,
-    `mm_vision/pool.py`, `mm_vision/pos.py`, `vidi/utils.py`) were executed in the build container
-    and their outputs are committed under `tests/golden/` (generator: `tests/golden/make_golden.py`);
-    `tests/test_oracle_golden.py` checks this file against them;
-  * the third-party blocks (Gemma2 RMSNorm/MLP/RoPE/attention, SigLIP and Whisper encoders) are
-    checked against the installed `transformers` eager implementations in `tests/test_oracle_hf.py`
-    (transformers 5.15, not the 4.50.0 the reference pins — same arithmetic for these blocks);
-  * flash-attn's `flash_attn_func(softcap=..)` is restated from its published definition
-    `softmax(softcap * tanh(q k^T * scale / softcap)) v` with fp32 softmax.
-Everything else (the D-Attn decoder layer, the encode pipeline) is "parity unpinned": a restatement
-with reference file:line citations, no reference-produced vectors.
+Parity status: the reference ships no tests, golden vectors or known-answer values and cannot
+run as shipped in this environment (flash-attn is CUDA-only; liger / deepspeed / the transformers-4.50 pin are absent), so
+this oracle is pinned on OUTPUTS OF THE REFERENCE'S OWN CODE EXECUTED IN THE BUILD CONTAINER:
+  * `tests/golden/ref_harness.py` replaces only the absent third-party packages and then imports and runs the reference's
+    model code unmodified on CPU/fp32; `make_golden_dattn.py` / `make_golden_dattn_7b.py` drive
+    `DattnGemma2ForCausalLM.forward` / `DattnMistralForCausalLM.forward` end to end (encode pipelines, every decoder layer,
+    all three caches, greedy decode steps, padded batches) and commit the results; `tests/test_oracle_golden.py` holds this
+    file to them — bit-exact for masks/indices/tokens, 2e-5 for floats (observed 5e-7);
+  * the small reference modules importable by file path (`mm_layer/norm.py`, `mm_layer/mlp.py`, `mm_vision/pool.py`,
+    `mm_vision/pos.py`, `vidi/utils.py`) are pinned bit-exactly the same way (`make_golden.py`, `make_golden_7b.py`);
+  * the third-party blocks (Gemma2/Mistral RMSNorm/MLP/RoPE/attention, SigLIP and Whisper encoders) are additionally checked
+    against the installed `transformers` eager implementations in `tests/test_oracle_hf.py`;
+  * restated, not executed: flash-attn's kernels (CUDA-only) — `flash_attn_func(softcap=..)` follows its published definition
+    `softmax(softcap * tanh(q k^T * scale / softcap)) v` with fp32 softmax, both here and in the harness stand-in.
 
 All functions are dtype-generic: fed fp32 tensors they are the fp32 oracle; fed bf16/fp16 tensors
 they reproduce the reference's eager rounding points (every nn.Module output rounds to the model
