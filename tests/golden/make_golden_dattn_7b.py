@@ -26,10 +26,10 @@ class _Proc:
 
 
 def golden_config():
-    """tiny Mistral-arch config with head_dim = hidden/heads (transformers 4.44 Mistral has no separate head_dim) and the
+    """tiny Mistral-arch config with head_dim = hidden/heads = 128 (transformers 4.44 Mistral has no separate head_dim; 128 is the real Mistral-7B head size the kernels are built for) and the
     sliding window opened (see make_golden_dattn.golden_config)"""
     from vidi_amd.config import tiny_7b
-    return tiny_7b(head_dim=64, query_pre_attn_scalar=64.0, sliding_window=64)
+    return tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64)
 
 
 def build_reference_model(cfg):

@@ -175,7 +175,7 @@ D7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_dattn_
 def test_dattn_7b_matches_reference_execution():
     from vidi_amd.config import tiny_7b
     from vidi_amd.weights import init_random_weights
-    cfg = tiny_7b(head_dim=64, query_pre_attn_scalar=64.0, sliding_window=64)      # = make_golden_dattn_7b.golden_config()
+    cfg = tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64)      # = make_golden_dattn_7b.golden_config()
     w = init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu")
     names = {f.name for f in dataclasses.fields(O.OracleConfig)}
     ocfg = O.OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in names}, vis_select_layer=cfg.mm_vision_select_layer, arch="mistral")

@@ -111,15 +111,37 @@ class VidiForCausalLM:
             return None
         if isinstance(xs, (list, tuple)) or xs.dim() == 5 or (name == "audios" and xs.dim() == 4):
             if len(xs) != 1:
-                # TODO(next): per-sample videos in one batch (the CLI and the BASELINE configs use one video)
-                raise NotImplementedError("one video per call; a batch of queries may share it")
+                raise ValueError("internal: per-sample batches are split by _n_videos()/_per_sample before encoding")
             return xs[0]
         return xs
+
+    @staticmethod
+    def _n_videos(images, audios) -> int:
+        """batch size of the multimodal inputs: images [B,T,3,S,S] / list of [T,3,S,S]; audios [B,C,mel,frames] / list"""
+        for xs, nd in ((images, 5), (audios, 4)):
+            if xs is None:
+                continue
+            if isinstance(xs, (list, tuple)):
+                return len(xs)
+            if xs.dim() == nd:
+                return int(xs.shape[0])
+        return 1
+
+    @staticmethod
+    def _row(xs, i):
+        return None if xs is None else [xs[i]]
 
     def encode_videos(self, images, audios, audio_sizes):
         """-> (image_features[1,Nv,H], image_mask[1,Nv] bool, audio_features[1,Na,H], audio_mask[1,Na] bool),
         un-normalised like the reference (the normaliser is applied inside the decoder, gemma.py:353-356)."""
         eng = self.engine
+        B = self._n_videos(images, audios)
+        if B > 1:                                   # per-sample encode, then pad_sequence like multimodal.py:199, 243
+            per = [self.encode_videos(self._row(images, i), self._row(audios, i),
+                                      None if audio_sizes is None else [audio_sizes[i]]) for i in range(B)]
+            pad = torch.nn.utils.rnn.pad_sequence
+            cat = lambda k: None if per[0][k] is None else pad([p[k][0] for p in per], batch_first=True)     # noqa: E731
+            return cat(0), cat(1), cat(2), cat(3)
         img = self._single(images, "images")
         aud = self._single(audios, "audios")
         fi = mi = fa = ma = None
@@ -180,6 +202,24 @@ class VidiForCausalLM:
             raise ValueError("You are attempting to perform batched generation with padding_side='right' this may lead to "
                              "unexpected behaviour for Flash Attention version of Mistral. Make sure to call "
                              "`tokenizer.padding_side  = 'left'` before tokenizing the input. ")
+        if mm_state is None and self._n_videos(images, audios) > 1:
+            # one video PER ROW (multimodal.py:156-252 batches them with pad_sequence + masks): rows never interact, so each
+            # row is answered against its own video, unpadded, and the answers are re-padded — the same tokens
+            B = self._n_videos(images, audios)
+            assert inputs.shape[0] == B, "one prompt per video"
+            rows = []
+            for i in range(B):
+                kw = dict(kwargs)
+                kw["attention_mask"] = None
+                am_i = None if attention_mask is None else attention_mask[i].bool().cpu()
+                ids_i = inputs[i].cpu() if am_i is None else inputs[i].cpu()[am_i]
+                rows.append(self.generate(ids_i[None], images=self._row(images, i), audios=self._row(audios, i),
+                                          audio_sizes=None if audio_sizes is None else [audio_sizes[i]], **kw)[0])
+            n = max(int(r.shape[0]) for r in rows)
+            out = torch.full((B, n), int(pad), dtype=torch.int64, device=eng.dev)
+            for i, r in enumerate(rows):
+                out[i, : r.shape[0]] = r
+            return out
         ids, mask, pos = strip_image_token(inputs, attention_mask)
         if mm_state is None and (images is not None or audios is not None):
             mm_state = self.encode_mm_state(images, audios, audio_sizes)
@@ -221,6 +261,27 @@ class VidiForCausalLM:
                 images=None, audios=None, audio_sizes=None, mm_state: Optional[MMState] = None,
                 logits_to_keep: int = 0, **kwargs) -> DattnCausalLMOutputWithPast:
         eng = self.engine
+        if mm_state is None and self._n_videos(images, audios) > 1:
+            # one video per row: rows are independent -> run them one by one, unpadded, and lay the logits back out in the
+            # padded [B, L, V] frame of the reference (pad slots hold zeros there, unspecified values in the reference)
+            B = self._n_videos(images, audios)
+            ids_all, mask_all, _ = strip_image_token(input_ids, attention_mask)
+            L = ids_all.shape[1]
+            outs, states = [], []
+            for i in range(B):
+                am_i = None if attention_mask is None else attention_mask[i].bool().cpu()
+                ids_i = input_ids[i].cpu() if am_i is None else input_ids[i].cpu()[am_i]
+                r = self.forward(ids_i[None], images=self._row(images, i), audios=self._row(audios, i),
+                                 audio_sizes=None if audio_sizes is None else [audio_sizes[i]], logits_to_keep=0)
+                outs.append(r.logits[0])
+                states.append((r.past_key_values, r.past_image_key_values))
+            full = torch.zeros((B, L, outs[0].shape[-1]), dtype=outs[0].dtype, device=eng.dev)
+            for i, o in enumerate(outs):
+                full[i, : o.shape[0]] = o                                         # right padding (multimodal.py:423-432)
+            keep = full if logits_to_keep == 0 else full[:, -logits_to_keep:]
+            return DattnCausalLMOutputWithPast(logits=keep, past_key_values=[s[0] for s in states],
+                                               past_image_key_values=[s[1] for s in states],
+                                               past_audio_key_values=[s[1] for s in states])
         ids, mask, pos = strip_image_token(input_ids, attention_mask)
         if mm_state is None and (images is not None or audios is not None):
             mm_state = self.encode_mm_state(images, audios, audio_sizes)
