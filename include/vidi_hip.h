@@ -24,6 +24,7 @@ extern "C" {
 #define VIDI_ABI_VERSION 1
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
+#define VIDI_DT_F32 2 /* output type of the preprocessing kernels only */
 #define VIDI_OK 0
 #define VIDI_ERR_SHAPE (-1)
 #define VIDI_ERR_DTYPE (-2)
@@ -173,6 +174,30 @@ int vidi_scale(const void* x, void* y, long long n, float s, int dtype, void* st
 int vidi_any_nonzero(const void* x, long long n, int* flag, int dtype, void* stream);
 /* FractionalSinusoidalEmbedding rows i0..i0+rows of l (mm_vision/pos.py:11-26,47-53), fp32 */
 int vidi_sinusoid(float* pe, const float* div_term, int rows, int i0, int l, int N, int d, void* stream);
+
+/* ---- host preprocessing moved to the GPU (dataset/img_utils.py:181-185, dataset/vid_utils.py:53-64) ---------------------
+ * Frames: `image.resize((S, S), Image.BICUBIC)` + `image_processor.preprocess` — BIT-EXACT with Pillow's 8-bit resampler
+ * (src/libImaging/Resample.c: two passes, int32 accumulators, PRECISION_BITS = 22) and with the processor's float
+ * arithmetic.  The host supplies Pillow's per-output-position tables: bounds[out][2] = (first source index, tap count) and
+ * kk[out][ksize] = fixed-point coefficients, and lut[3][256] = normalised value of every byte per channel in the output
+ * element type (2 bytes: bf16/f16 bits, 4 bytes: f32).  `in`/`tmp` 4-byte aligned; tmp rows are `pitch` >= OW*3 bytes apart,
+ * pitch % 4 == 0.
+ *   pass 1: in [rows = T*H0][W0][3] u8 -> tmp [rows][pitch] u8 (OW pixels x 3)
+ *   pass 2: tmp [T][H0][pitch] u8 -> out [T][3][OH][OW] */
+int vidi_resize_h_u8(const void* in, void* tmp, const int* bounds, const int* kk, long long rows, int W0, int OW, int pitch,
+                     int ksize, void* stream);
+int vidi_resize_v_u8_norm(const void* tmp, void* out, const int* bounds, const int* kk, const void* lut, int T, int H0, int OW,
+                          int OH, int pitch, int ksize, int out_elem_bytes, void* stream);
+/* Audio: WhisperFeatureExtractor._torch_extract_fbank_features (TP/models/whisper/feature_extraction_whisper.py) as
+ *   reflect pad -> STFT = vidi_gemm_f32 over overlapping row views (ldx = hop) against the Hann-windowed DFT matrix ->
+ *   |.|^2 -> vidi_gemm_f32 against the mel filter bank -> log10 / per-window (max - 8) floor / (x + 4) / 4 / transpose.
+ * reflect_pad: wave [C][n] -> out [C][stride], out[c][i] = wave[c][reflect(i - pad)] for i < n + 2*pad, 0 beyond.
+ * power_spectrum: Y [M][ldy] = (re[0..nf) | im[nf..2nf)) -> P [M][ldp] = re^2 + im^2, columns >= nf zero.
+ * logmel_finish: mel [C][R][nmel] f32 (first F rows of each window valid; overwritten with log10(max(.,1e-10))),
+ *   cmax [C] scratch, out [C][nmel][F] in out_dtype (VIDI_DT_*). */
+int vidi_reflect_pad_f32(const float* wave, float* out, int C, int n, int pad, int stride, void* stream);
+int vidi_power_spectrum_f32(const float* Y, float* P, long long M, int nf, int ldy, int ldp, void* stream);
+int vidi_logmel_finish(float* mel, float* cmax, void* out, int C, int R, int F, int nmel, int out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@
 // ---- C-ABI constants (mirrored in include/vidi_hip.h) -------------------------------------
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
+#define VIDI_DT_F32 2
 
 #define VIDI_OK 0
 #define VIDI_ERR_SHAPE (-1)

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvidi_hip.so")
 
-DT_BF16, DT_F16 = 0, 1
+DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
 NORM_GEMMA, NORM_GEMMA_ADD, NORM_MM, NORM_MM_NOW, NORM_LLM, NORM_LAYER = range(6)
 
@@ -52,6 +52,11 @@ SIGNATURES = {
     "vidi_softcap_argmax": [_c_vp] * 2 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp],
     "vidi_mel_transpose_pad": [_c_vp] * 2 + [_c_int] * 4 + [_c_vp],
     "vidi_sinusoid": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
+    "vidi_resize_h_u8": [_c_vp] * 4 + [_c_ll, _c_int, _c_int, _c_int, _c_int, _c_vp],
+    "vidi_resize_v_u8_norm": [_c_vp] * 5 + [_c_int] * 7 + [_c_vp],
+    "vidi_reflect_pad_f32": [_c_vp] * 2 + [_c_int] * 4 + [_c_vp],
+    "vidi_power_spectrum_f32": [_c_vp] * 2 + [_c_ll, _c_int, _c_int, _c_int, _c_vp],
+    "vidi_logmel_finish": [_c_vp] * 3 + [_c_int] * 5 + [_c_vp],
 }
 
 _lib = None
@@ -108,6 +113,10 @@ def _work(name, a):
         return "gemv", float(a[4]) * a[5] * 2, "byte"
     if name == "vidi_gemm_f32":
         return "gemm_f32", 2.0 * a[4] * a[5] * a[6], "flop"
+    if name == "vidi_resize_h_u8":                      # read every source byte once, write the uint8 intermediate once
+        return "resize_h", float(a[4]) * (a[5] * 3 + a[7]), "byte"
+    if name == "vidi_resize_v_u8_norm":                 # read the intermediate once, write the planar output once
+        return "resize_v_norm", float(a[5]) * (a[6] * a[9] + 3.0 * a[8] * a[7] * a[11]), "byte"
     return "other", 0.0, "none"
 
 
@@ -433,3 +442,50 @@ def any_nonzero(x, flag):
 def sinusoid(pe, div, *, rows, i0, l, N, d):
     _check(load_library().vidi_sinusoid(_p(pe), _p(div), rows, i0, l, N, d, _stream()), "vidi_sinusoid")
     return pe
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocessing (csrc/preproc.hip): PIL-exact frame resize + normalise, Whisper log-mel pieces
+# ---------------------------------------------------------------------------------------------
+def _out_dt(dtype: torch.dtype) -> int:
+    return {torch.bfloat16: DT_BF16, torch.float16: DT_F16, torch.float32: DT_F32}[dtype]
+
+
+def resize_h_u8(frames: torch.Tensor, tmp: torch.Tensor, bounds: torch.Tensor, kk: torch.Tensor):
+    """frames [T,H0,W0,3] u8 -> tmp [T,H0,pitch] u8 holding OW x 3 bytes per row (Pillow horizontal pass)"""
+    lib = load_library()
+    T, H0, W0, C = frames.shape
+    assert C == 3 and frames.dtype == torch.uint8 and tmp.dtype == torch.uint8 and frames.is_contiguous() and tmp.is_contiguous()
+    OW, pitch = bounds.shape[0], tmp.shape[2]
+    assert bounds.dtype == torch.int32 and kk.dtype == torch.int32 and bounds.shape == (OW, 2) and kk.shape[0] == OW
+    _check(lib.vidi_resize_h_u8(_p(frames), _p(tmp), _p(bounds), _p(kk), T * H0, W0, OW, pitch, kk.shape[1], _stream()), "vidi_resize_h_u8")
+
+
+def resize_v_u8_norm(tmp: torch.Tensor, out: torch.Tensor, bounds: torch.Tensor, kk: torch.Tensor, lut: torch.Tensor):
+    """tmp [T,H0,pitch] u8 -> out [T,3,OH,OW] (Pillow vertical pass + per-channel value table + HWC->CHW)"""
+    lib = load_library()
+    T, H0, pitch = tmp.shape
+    OH, OW = out.shape[2], out.shape[3]
+    assert out.shape == (T, 3, OH, OW) and out.is_contiguous() and lut.shape == (3, 256) and lut.dtype == out.dtype
+    assert bounds.shape == (OH, 2) and kk.shape[0] == OH
+    _check(lib.vidi_resize_v_u8_norm(_p(tmp), _p(out), _p(bounds), _p(kk), _p(lut), T, H0, OW, OH, pitch, kk.shape[1], out.element_size(),
+                                     _stream()), "vidi_resize_v_u8_norm")
+
+
+def reflect_pad_f32(wave: torch.Tensor, out: torch.Tensor, pad: int):
+    lib = load_library()
+    C, n = wave.shape
+    assert wave.dtype == torch.float32 and out.dtype == torch.float32 and wave.is_contiguous() and out.is_contiguous()
+    _check(lib.vidi_reflect_pad_f32(_p(wave), _p(out), C, n, pad, out.shape[1], _stream()), "vidi_reflect_pad_f32")
+
+
+def power_spectrum_f32(Y: torch.Tensor, P: torch.Tensor, nf: int):
+    lib = load_library()
+    _check(lib.vidi_power_spectrum_f32(_p(Y), _p(P), Y.shape[0], nf, Y.stride(0), P.stride(0), _stream()), "vidi_power_spectrum_f32")
+
+
+def logmel_finish(mel: torch.Tensor, cmax: torch.Tensor, out: torch.Tensor, *, C: int, R: int, F: int):
+    lib = load_library()
+    nmel = mel.shape[-1]
+    assert mel.dtype == torch.float32 and cmax.dtype == torch.float32 and out.shape == (C, nmel, F) and out.is_contiguous()
+    _check(lib.vidi_logmel_finish(_p(mel), _p(cmax), _p(out), C, R, F, nmel, _out_dt(out.dtype), _stream()), "vidi_logmel_finish")

@@ -93,6 +93,24 @@ def process_images(images, image_processor, model_cfg):
     return out
 
 
+def process_images_gpu(images, image_processor, model_cfg, dtype=torch.bfloat16, device="cuda"):
+    """`process_images` for the video configuration ('resize') with the per-pixel work on the GPU (vidi_amd/preproc.py):
+    same arguments (PIL images / uint8 arrays of one size, the SigLIP image processor, the model config), same values —
+    bit-exact with PIL's BICUBIC resize + `image_processor.preprocess` + `.to(dtype)` — returned on `device`."""
+    if getattr(model_cfg, "mm_image_aspect_ratio", None) != "resize":
+        raise NotImplementedError("GPU frame preprocessing covers mm_image_aspect_ratio == 'resize' (the video configuration)")
+    from .preproc import FramePreprocessor
+    pre = getattr(image_processor, "_vidi_gpu_pre", None)
+    if pre is None or pre.dtype != dtype or str(pre.dev) != str(torch.device(device)):
+        pre = FramePreprocessor.from_image_processor(image_processor, dtype=dtype, device=device)
+        image_processor._vidi_gpu_pre = pre
+    if isinstance(images, torch.Tensor):
+        frames = images
+    else:
+        frames = np.stack([np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images])
+    return pre(frames)
+
+
 # ------------------------------------------------------------------------------------------------
 # video / audio  (vid_utils.py:10-64) — decord + ffmpeg on the host, like the reference
 # ------------------------------------------------------------------------------------------------
@@ -133,6 +151,17 @@ def process_audio(audio: np.ndarray, audio_processor) -> Tuple[torch.Tensor, int
     feats = audio_processor(pieces, sampling_rate=audio_processor.sampling_rate, return_tensors="pt")
     length = audio_num_frames(len(audio), n, audio_processor.hop_length)
     return feats.input_features, int(length)
+
+
+def process_audio_gpu(audio: np.ndarray, audio_processor, dtype=torch.bfloat16, device="cuda") -> Tuple[torch.Tensor, int]:
+    """`process_audio` with the log-mel computed on the GPU (vidi_amd/preproc.py:LogMelExtractor): same arguments and return
+    values (`input_features` [C, n_mels, 3000] on `device` in `dtype`, `length` bit-exact)."""
+    from .preproc import LogMelExtractor
+    ext = getattr(audio_processor, "_vidi_gpu_ext", None)
+    if ext is None or ext.dtype != dtype or str(ext.dev) != str(torch.device(device)):
+        ext = LogMelExtractor.from_feature_extractor(audio_processor, dtype=dtype, device=device)
+        audio_processor._vidi_gpu_ext = ext
+    return ext(audio)
 
 
 def get_media_length(file) -> float:
