@@ -18,90 +18,141 @@ __device__ __forceinline__ unsigned clip8(int acc) {
     return (unsigned)min(max(v, 0), 255);
 }
 
-// ---- pass 1, horizontal: in [rows = T*H0][W0][3] u8 -> tmp [rows][OW][3] u8 ---------------------------------------------
-// One block per input row.  The row (W0*3 bytes, arbitrary byte alignment) is staged in LDS with aligned dword loads;
-// each thread then produces 4 consecutive output bytes and stores one dword (output rows are `pitch` bytes apart).
-__global__ __launch_bounds__(256) void resize_h_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ tmp,
+// ---- pass 1, horizontal: in [rows = T*H0][W0][3] u8 -> tmp [rows][pitch] u8 (OW pixels x 3 bytes) --------------------------
+// One block = RB consecutive source rows, staged in LDS with aligned dword loads (rows start at arbitrary byte offsets).
+// A thread owns one output pixel column: it keeps that column's <= KMAX coefficients in registers (zero beyond the tap count,
+// so no predication) and applies them to all RB rows.  The 3*KMAX source bytes of a pixel are fetched as aligned LDS dwords
+// and re-aligned with v_alignbyte into a byte stream whose tap/channel positions are compile-time constants.  Results go to
+// an LDS image of the output rows, stored as coalesced dwords.
+template <int KMAX>
+__global__ __launch_bounds__(512) void resize_h_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ tmp,
                                                           const int* __restrict__ bounds, const int* __restrict__ kk,
-                                                          long long rows, int W0, int OW, int pitch, int ksize, long long in_bytes) {
-    extern __shared__ unsigned s_row_u32[];
-    uint8_t* s_row = (uint8_t*)s_row_u32;
-    const long long row = blockIdx.x;
-    const long long base = row * (long long)W0 * 3;
+                                                          long long rows, int W0, int OW, int pitch, int ksize, int RB,
+                                                          int lds_row, long long in_bytes) {
+    constexpr int ND = (3 * KMAX + 3) / 4;                              // dwords of the re-aligned byte stream
+    extern __shared__ unsigned s_mem_h[];
+    uint8_t* s_src = (uint8_t*)s_mem_h;                                // [RB][lds_row]   (lds_row % 4 == 0, >= 4*(ND+1) bytes of slack)
+    uint8_t* s_dst = s_src + (size_t)RB * lds_row;                     // [RB][pitch]
+    const int nthr = blockDim.x;
+    const long long row0 = (long long)blockIdx.x * RB;
+    const int nr = (int)min((long long)RB, rows - row0);
     const int nbytes = W0 * 3;
-    const int mis = (int)((uintptr_t)(in + base) & 3);                 // bytes between the aligned-down address and the row
-    const uint8_t* abase = in + base - mis;
-    const int ndw = (mis + nbytes + 3) >> 2;
-    const long long last_full = (in_bytes - (base - mis)) >> 2;        // dwords that lie wholly inside the buffer
-    for (int i = threadIdx.x; i < ndw; i += 256) {
-        unsigned v;
-        if (i < last_full) v = ((const unsigned*)abase)[i];
-        else {                                                          // tail dword of the whole buffer: byte loads
-            v = 0;
-            for (int b = 0; b < 4; ++b) {
-                const long long off = base - mis + 4ll * i + b;
-                if (off < in_bytes) v |= (unsigned)in[off] << (8 * b);
+    for (int r = 0; r < nr; ++r) {
+        const long long base = (row0 + r) * (long long)nbytes;
+        const int mis = (int)((uintptr_t)(in + base) & 3);             // the row starts `mis` bytes after an aligned dword
+        const uint8_t* abase = in + base - mis;
+        const int ndw = (mis + nbytes + 3) >> 2;
+        const long long last_full = (in_bytes - (base - mis)) >> 2;    // dwords lying wholly inside the buffer
+        unsigned* d = (unsigned*)(s_src + (size_t)r * lds_row);
+        for (int i = threadIdx.x; i < ndw; i += nthr) {
+            unsigned v;
+            if (i < last_full) v = ((const unsigned*)abase)[i];
+            else {                                                      // last dword of the whole buffer: byte loads
+                v = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const long long off = base - mis + 4ll * i + b;
+                    if (off < in_bytes) v |= (unsigned)in[off] << (8 * b);
+                }
             }
+            d[i] = v;
         }
-        s_row_u32[i] = v;
+    }
+    for (int i = threadIdx.x; i < RB * pitch / 4; i += nthr) ((unsigned*)s_dst)[i] = 0;
+    __syncthreads();
+    for (int x = threadIdx.x; x < OW; x += nthr) {
+        const int x0 = bounds[2 * x], n = bounds[2 * x + 1];
+        int k[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) k[j] = j < n ? kk[(size_t)x * ksize + j] : 0;
+        for (int r = 0; r < nr; ++r) {
+            const long long base = (row0 + r) * (long long)nbytes;
+            const int off = (int)((uintptr_t)(in + base) & 3) + x0 * 3;     // byte offset of the first tap inside the LDS row
+            const unsigned* d = (const unsigned*)(s_src + (size_t)r * lds_row) + (off >> 2);
+            const unsigned sh = off & 3;
+            unsigned w[ND + 1];
+#pragma unroll
+            for (int i = 0; i <= ND; ++i) w[i] = d[i];
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const unsigned v = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);   // stream bytes 4i .. 4i+3
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int pos = 4 * i + b, j = pos / 3, c = pos - 3 * j;
+                    if (j < KMAX) {
+                        const int px = (int)((v >> (8 * b)) & 255u) * k[j];
+                        if (c == 0) a0 += px; else if (c == 1) a1 += px; else a2 += px;
+                    }
+                }
+            }
+            uint8_t* o = s_dst + (size_t)r * pitch + 3 * x;
+            o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
+        }
     }
     __syncthreads();
-    const uint8_t* src = s_row + mis;
-    const int nout4 = pitch / 4;                                        // tmp rows are `pitch` = round_up(OW*3, 4) bytes apart
-    unsigned* dst = (unsigned*)(tmp + row * (long long)pitch);
-    for (int i = threadIdx.x; i < nout4; i += 256) {
-        unsigned packed = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int idx = 4 * i + b, x = idx / 3, c = idx - 3 * x;
-            if (x >= OW) break;                                         // pitch padding bytes stay zero
-            const int x0 = bounds[2 * x], n = bounds[2 * x + 1];
-            const int* k = kk + (size_t)x * ksize;
-            int acc = 1 << (PRECISION_BITS - 1);
-            for (int j = 0; j < n; ++j) acc += (int)src[(x0 + j) * 3 + c] * k[j];
-            packed |= clip8(acc) << (8 * b);
-        }
-        dst[i] = packed;
-    }
+    unsigned* dst = (unsigned*)(tmp + row0 * (long long)pitch);
+    for (int i = threadIdx.x; i < nr * pitch / 4; i += nthr) dst[i] = ((const unsigned*)s_dst)[i];
 }
 
-// ---- pass 2, vertical + normalise + HWC->CHW: tmp [T][H0][OW][3] u8 -> out [T][3][OH][OW] (2- or 4-byte elements) -------
-// One block per output row (t, y).  A thread owns 4 consecutive bytes of the interleaved row across all taps (dword loads,
-// rows are `pitch` bytes apart), looks the results up in the per-channel value table and the block writes the three
-// planes coalesced through LDS.
-template <typename E>
+// ---- pass 2, vertical + normalise + HWC->CHW: tmp [T][H0][pitch] u8 -> out [T][3][OH][OW] (2- or 4-byte elements) -------
+// One block = RB consecutive output rows of one frame.  An item = (row, dword of the interleaved row): it accumulates its 4
+// bytes over KMAX taps (coefficients zero beyond the row's tap count, source row clamped — KMAX independent coalesced loads in
+// flight; neighbouring output rows share source rows through L1/L2), maps the results through the per-channel value table
+// and drops them into an LDS image of the three planes, which is stored coalesced.
+template <typename E, int RB, int KMAX>
 __global__ __launch_bounds__(256) void resize_v_u8_norm_kernel(const uint8_t* __restrict__ tmp, E* __restrict__ out,
                                                                const int* __restrict__ bounds, const int* __restrict__ kk,
                                                                const E* __restrict__ lut, int H0, int OW, int OH, int pitch, int ksize) {
     extern __shared__ unsigned s_mem[];
-    E* s_lut = (E*)s_mem;                       // [3][256]
-    E* s_out = s_lut + 768;                     // [3][OW]
-    const int t = blockIdx.x / OH, y = blockIdx.x - t * OH;
+    int* s_b = (int*)s_mem;                     // [RB][2]
+    int* s_k = s_b + 2 * RB;                    // [RB][KMAX]
+    E* s_lut = (E*)(s_k + RB * KMAX);           // [3][256]
+    E* s_out = s_lut + 768;                     // [RB][3][OW]
+    const int bpf = (OH + RB - 1) / RB;         // blocks per frame
+    const int t = blockIdx.x / bpf, y_base = (blockIdx.x - t * bpf) * RB;
+    const int nr = min(RB, OH - y_base);
     for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = lut[i];
-    const int y0 = bounds[2 * y], n = bounds[2 * y + 1];
-    const int* k = kk + (size_t)y * ksize;
-    const int row_dw = pitch / 4;
-    const unsigned* src = (const unsigned*)(tmp + ((size_t)t * H0 + y0) * pitch);
+    for (int i = threadIdx.x; i < nr * 2; i += 256) s_b[i] = bounds[2 * y_base + i];
+    for (int i = threadIdx.x; i < nr * KMAX; i += 256) {
+        const int r = i / KMAX, j = i - r * KMAX;
+        s_k[i] = j < bounds[2 * (y_base + r) + 1] ? kk[(size_t)(y_base + r) * ksize + j] : 0;
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < row_dw; i += 256) {
+    const int row_dw = pitch / 4;
+    const unsigned* frame = (const unsigned*)(tmp + (size_t)t * H0 * pitch);
+    for (int it = threadIdx.x; it < nr * row_dw; it += 256) {
+        const int r = it / row_dw, i = it - r * row_dw;
+        const int y0 = s_b[2 * r];
+        const int* k = s_k + r * KMAX;
+        unsigned v[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) v[j] = frame[(size_t)min(y0 + j, H0 - 1) * row_dw + i];
         int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
-        for (int j = 0; j < n; ++j) {
-            const unsigned v = src[(size_t)j * row_dw + i];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
             const int kj = k[j];
-            a0 += (int)(v & 255u) * kj; a1 += (int)((v >> 8) & 255u) * kj;
-            a2 += (int)((v >> 16) & 255u) * kj; a3 += (int)(v >> 24) * kj;
+            a0 += (int)(v[j] & 255u) * kj; a1 += (int)((v[j] >> 8) & 255u) * kj;
+            a2 += (int)((v[j] >> 16) & 255u) * kj; a3 += (int)(v[j] >> 24) * kj;
         }
         const int acc[4] = {a0, a1, a2, a3};
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int idx = 4 * i + b, x = idx / 3, c = idx - 3 * x;
-            if (x < OW) s_out[c * OW + x] = s_lut[c * 256 + clip8(acc[b])];
+            if (x < OW) s_out[(r * 3 + c) * OW + x] = s_lut[c * 256 + clip8(acc[b])];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * OW; i += 256) {
-        const int c = i / OW, x = i - c * OW;
-        out[(((size_t)t * 3 + c) * OH + y) * OW + x] = s_out[i];
+    if (sizeof(E) == 2 && (OW & 1) == 0) {                              // two 16-bit elements per store
+        const int ow2 = OW / 2;
+        for (int i = threadIdx.x; i < nr * 3 * ow2; i += 256) {
+            const int rc = i / ow2, x2 = i - rc * ow2, r = rc / 3, c = rc - 3 * r;
+            ((unsigned*)(out + (((size_t)t * 3 + c) * OH + y_base + r) * OW))[x2] = ((const unsigned*)s_out)[i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nr * 3 * OW; i += 256) {
+            const int rc = i / OW, x = i - rc * OW, r = rc / 3, c = rc - 3 * r;
+            out[(((size_t)t * 3 + c) * OH + y_base + r) * OW + x] = s_out[i];
+        }
     }
 }
 
@@ -201,11 +252,32 @@ int vidi_resize_h_u8(const void* in, void* tmp, const int* bounds, const int* kk
     (void)hipGetLastError();
     if (!in || !tmp || !bounds || !kk) return VIDI_ERR_ARG;
     if (((uintptr_t)in & 3) || ((uintptr_t)tmp & 3)) return VIDI_ERR_ALIGN;
-    if (rows <= 0 || W0 <= 0 || OW <= 0 || ksize <= 0 || pitch < OW * 3 || pitch % 4 || rows > 0x7fffffffll) return VIDI_ERR_SHAPE;
-    const int lds = ((W0 * 3 + 3 + 3) / 4 + 1) * 4;
+    if (rows <= 0 || W0 <= 0 || OW <= 0 || ksize <= 0 || ksize > 48 || pitch < OW * 3 || pitch % 4) return VIDI_ERR_SHAPE;
+    const int kmax = ksize <= 8 ? 8 : ksize <= 12 ? 12 : ksize <= 16 ? 16 : ksize <= 24 ? 24 : ksize <= 32 ? 32 : 48;
+    const int lds_row = (W0 * 3 + 3 + 3) / 4 * 4 + 4 * ((3 * kmax + 3) / 4 + 2);   // row + slack for the fixed-length tap fetch
+    int RB = (30 * 1024) / (lds_row + pitch);                            // rows per block: ~30 KB of LDS (5 blocks per CU), <= 8
+    if (RB > 8) RB = 8;
+    if (RB < 1) RB = 1;
+    const int lds = RB * (lds_row + pitch);
     if (lds > 64 * 1024) return VIDI_ERR_SHAPE;
-    hipLaunchKernelGGL(resize_h_u8_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, (const uint8_t*)in, (uint8_t*)tmp,
-                       bounds, kk, rows, W0, OW, pitch, ksize, rows * (long long)W0 * 3);
+    const long long nblk = (rows + RB - 1) / RB;
+    if (nblk > 0x7fffffffll) return VIDI_ERR_SHAPE;
+    const long long in_bytes = rows * (long long)W0 * 3;
+    int nthr = (OW + 63) / 64 * 64;                                      // one output column per thread when it fits
+    if (nthr > 512) nthr = 512;
+    hipStream_t st = (hipStream_t)stream;
+#define VIDI_LAUNCH_H(KM)                                                                                                     \
+    hipLaunchKernelGGL(resize_h_u8_kernel<KM>, dim3((unsigned)nblk), dim3(nthr), lds, st, (const uint8_t*)in, (uint8_t*)tmp,   \
+                       bounds, kk, rows, W0, OW, pitch, ksize, RB, lds_row, in_bytes)
+    switch (kmax) {
+        case 8: VIDI_LAUNCH_H(8); break;
+        case 12: VIDI_LAUNCH_H(12); break;
+        case 16: VIDI_LAUNCH_H(16); break;
+        case 24: VIDI_LAUNCH_H(24); break;
+        case 32: VIDI_LAUNCH_H(32); break;
+        default: VIDI_LAUNCH_H(48); break;
+    }
+#undef VIDI_LAUNCH_H
     return (int)hipGetLastError();
 }
 
@@ -213,15 +285,34 @@ int vidi_resize_v_u8_norm(const void* tmp, void* out, const int* bounds, const i
                           int pitch, int ksize, int out_elem_bytes, void* stream) {
     (void)hipGetLastError();
     if (!tmp || !out || !bounds || !kk || !lut) return VIDI_ERR_ARG;
-    if (T <= 0 || H0 <= 0 || OW <= 0 || OH <= 0 || pitch < OW * 3 || pitch % 4 || (long long)T * OH > 0x7fffffffll) return VIDI_ERR_SHAPE;
-    const dim3 grid((unsigned)((long long)T * OH));
-    if (out_elem_bytes == 2) {
-        hipLaunchKernelGGL(resize_v_u8_norm_kernel<u16>, grid, dim3(256), (768 + 3 * OW) * 2, (hipStream_t)stream, (const uint8_t*)tmp,
-                           (u16*)out, bounds, kk, (const u16*)lut, H0, OW, OH, pitch, ksize);
-    } else if (out_elem_bytes == 4) {
-        hipLaunchKernelGGL(resize_v_u8_norm_kernel<float>, grid, dim3(256), (768 + 3 * OW) * 4, (hipStream_t)stream, (const uint8_t*)tmp,
-                           (float*)out, bounds, kk, (const float*)lut, H0, OW, OH, pitch, ksize);
-    } else return VIDI_ERR_DTYPE;
+    if (T <= 0 || H0 <= 0 || OW <= 0 || OH <= 0 || ksize <= 0 || ksize > 48 || pitch < OW * 3 || pitch % 4) return VIDI_ERR_SHAPE;
+    if (out_elem_bytes != 2 && out_elem_bytes != 4) return VIDI_ERR_DTYPE;
+    constexpr int RB = 8;
+    const int kmax = ksize <= 8 ? 8 : ksize <= 12 ? 12 : ksize <= 16 ? 16 : ksize <= 24 ? 24 : ksize <= 32 ? 32 : 48;
+    const long long nblk = (long long)T * ((OH + RB - 1) / RB);
+    if (nblk > 0x7fffffffll) return VIDI_ERR_SHAPE;
+    const dim3 grid((unsigned)nblk);
+    const size_t lds = (size_t)(2 * RB + RB * kmax) * 4 + (size_t)(768 + RB * 3 * OW) * out_elem_bytes;
+    if (lds > 64 * 1024) return VIDI_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define VIDI_LAUNCH_V(KM)                                                                                                              \
+    do {                                                                                                                               \
+        if (out_elem_bytes == 2)                                                                                                       \
+            hipLaunchKernelGGL((resize_v_u8_norm_kernel<u16, RB, KM>), grid, dim3(256), lds, st, (const uint8_t*)tmp, (u16*)out, bounds, \
+                               kk, (const u16*)lut, H0, OW, OH, pitch, ksize);                                                         \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((resize_v_u8_norm_kernel<float, RB, KM>), grid, dim3(256), lds, st, (const uint8_t*)tmp, (float*)out,    \
+                               bounds, kk, (const float*)lut, H0, OW, OH, pitch, ksize);                                               \
+    } while (0)
+    switch (kmax) {
+        case 8: VIDI_LAUNCH_V(8); break;
+        case 12: VIDI_LAUNCH_V(12); break;
+        case 16: VIDI_LAUNCH_V(16); break;
+        case 24: VIDI_LAUNCH_V(24); break;
+        case 32: VIDI_LAUNCH_V(32); break;
+        default: VIDI_LAUNCH_V(48); break;
+    }
+#undef VIDI_LAUNCH_V
     return (int)hipGetLastError();
 }
 
