@@ -261,3 +261,25 @@ def test_real_dims_two_layers():
     href2 = O.model_forward(e, p, tm, img.float(), imask, aud.float(), amask, w32, ocfg, caches, idt.shape[1])
     hn2 = eng.text_forward(eng.embed_tokens(nxt.cuda()), p.reshape(-1).cuda(), ts, mm, Lq=1)
     report("real-dims decode hidden", hn2, href2[0], 4e-2 * href2.std().item(), 4e-2)
+
+
+def test_generate_do_sample(tiny_setup):
+    """do_sample=True: top_k=1 must reproduce greedy; a seeded generator is reproducible; tokens stay in-vocabulary"""
+    cfg, eng, w32, dt = tiny_setup
+    from types import SimpleNamespace
+    from vidi_amd.model import VidiForCausalLM
+    model = VidiForCausalLM.__new__(VidiForCausalLM)
+    model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
+    model.generation_config = SimpleNamespace(eos_token_id=cfg.eos_token_id, pad_token_id=0)
+    model.model = None
+    px = seeded((3, 3, cfg.vis_image_size, cfg.vis_image_size), 206, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 207, 0.3).to(dt)
+    ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26]], dtype=torch.int64)
+    st = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
+    greedy = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=False, eos_token_id=-1)
+    k1 = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, top_k=1, eos_token_id=-1)
+    assert torch.equal(greedy, k1)
+    g = lambda: torch.Generator(device="cuda").manual_seed(11)                      # noqa: E731
+    a = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, temperature=1.5, top_p=0.95, generator=g(), eos_token_id=-1)
+    b = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, temperature=1.5, top_p=0.95, generator=g(), eos_token_id=-1)
+    assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < cfg.vocab_size

@@ -186,11 +186,13 @@ class VidiForCausalLM:
     def generate(self, inputs: Optional[torch.Tensor] = None, images=None, image_sizes=None, audios=None,
                  audio_sizes: Optional[Sequence[int]] = None, mm_state: Optional[MMState] = None, **kwargs) -> torch.Tensor:
         """gemma.py:603-655.  Accepts do_sample/max_new_tokens/use_cache/disable_compile/pad_token_id/
-        attention_mask/position_ids; greedy only (the reference CLI uses do_sample=False)."""
+        attention_mask/position_ids, and for do_sample=True: temperature/top_k/top_p/generator (HF warper semantics,
+        vidi_amd/sampling.py); the reference CLI uses do_sample=False."""
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")            # gemma.py:615-616
-        if kwargs.get("do_sample", False):
-            raise NotImplementedError("sampling is not implemented (reference CLI is greedy)")
+        do_sample = bool(kwargs.get("do_sample", False))
+        if kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is not implemented (the reference CLI decodes greedily)")
         max_new = int(kwargs.get("max_new_tokens", 20))
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
         pad = kwargs.get("pad_token_id", None)
@@ -227,12 +229,20 @@ class VidiForCausalLM:
         B = ids.shape[0]
         out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
         finished = torch.zeros(B, dtype=torch.bool, device=eng.dev)
-        _, nxt = eng.logits_argmax(last)
+        def pick(h):
+            logits, idx = eng.logits_argmax(h)                          # lm_head + final softcap (in place) + argmax
+            if not do_sample:
+                return idx
+            from .sampling import sample, warp_logits
+            return sample(warp_logits(logits, kwargs.get("temperature"), kwargs.get("top_k"), kwargs.get("top_p")),
+                          kwargs.get("generator"))
+
+        nxt = pick(last)
         n_done = 0
         # VIDI_DECODE_GRAPH=1: decode steps are replayed from a hipGraph (device-side cache position, no per-launch
         # host work).  Measured on MI355X (60-min video): replay 19.3 ms/token vs 21.0 eager, capture 126 ms —
         # it only pays for generations of ~80+ tokens, so it is opt-in; the sharded path stays eager.
-        use_graph = (eng.world == 1 and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
+        use_graph = (not do_sample and eng.world == 1 and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
                      and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1")
         replay = None
         for step in range(max_new):
@@ -252,7 +262,7 @@ class VidiForCausalLM:
             posn = ts.n_valid.clone()                                  # HF: position = cumsum(mask) - 1 of the new token
             ts.n_valid += 1
             hn = eng.text_forward(emb, posn, ts, mm_state, Lq=1)
-            _, nxt = eng.logits_argmax(hn)
+            nxt = pick(hn)
         return out[:, :n_done]
 
     # ---- forward (gemma.py:484-601): prefill-style call returning logits ----
