@@ -104,3 +104,38 @@ def test_compat_import_paths_7b():
         sys.path.pop(0)
         for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
             del sys.modules[k]
+
+
+# ---- host logic vs values produced by EXECUTING the reference's functions (tests/golden/make_golden_host.py) --------
+def _host_golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_host.json")) as f:
+        return json.load(f)
+
+
+def test_tokenizer_image_token_matches_reference_execution():
+    for case in _host_golden()["tokenizer_image_token"]:
+        assert P.tokenizer_image_token(case["prompt"], FakeTok(), -200) == case["ids"], case["prompt"]
+
+
+def test_preprocess_chat_matches_reference_execution():
+    for case in _host_golden()["preprocess_chat"]:
+        assert P.preprocess_chat(case["source"], FakeTok()) == case["text"]
+
+
+def test_ask_prompt_and_postprocessing_match_reference_execution():
+    """eval/inference.py:18-66 run end to end with a stub model: the ids it hands to generate() and the HH:MM:SS string"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vidi_oracle as O
+    for case in _host_golden()["ask"]:
+        q = case["question"]
+        qs = P.DEFAULT_IMAGE_TOKEN + "\n" + "During which time segments in the video can we see {}?".format(q[:-1] if q.endswith(".") else q)
+        prompt = P.preprocess_chat([{"from": "human", "value": qs}], FakeTok())
+        ids = P.tokenizer_image_token(prompt, FakeTok(), P.IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0)
+        assert ids.tolist() == case["input_ids"]
+        assert O.format_time_ranges(case["answer"], case["length"]) == case["result"]
+        # every keyword the reference passes to generate() is accepted by ours
+        import inspect
+        from vidi_amd.model import VidiForCausalLM
+        sig = inspect.signature(VidiForCausalLM.generate)
+        assert all(k in sig.parameters or any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values()) for k in case["generate_kwargs"])
