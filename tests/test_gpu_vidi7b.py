@@ -153,3 +153,23 @@ def test_7b_real_dims_two_layers():
     href2 = O.model_forward(e, p, tm, img.float(), imask, aud.float(), amask, w32, ocfg, caches, idt.shape[1])
     hn2 = eng.text_forward(eng.embed_tokens(nxt.cuda()), p.reshape(-1).cuda(), ts, mm, Lq=1)
     report("7b real-dims decode hidden", hn2, href2[0], 7e-2 * href2.std().item(), 4e-2)
+
+
+def test_7b_left_padded_batch_equals_single_rows(setup7b):
+    """batched generation the way Vidi-7B accepts it (left padding, mistral.py:366-373): each row == that prompt alone"""
+    cfg, eng, w32, dt = setup7b
+    from vidi_amd.model import VidiForCausalLM
+    from types import SimpleNamespace
+    model = VidiForCausalLM.__new__(VidiForCausalLM)
+    model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
+    model.generation_config = SimpleNamespace(eos_token_id=cfg.eos_token_id, pad_token_id=0)
+    model.model = None
+    px = seeded((3, 3, cfg.vis_image_size, cfg.vis_image_size), 150, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 151, 0.3).to(dt)
+    st = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
+    ids = torch.tensor([[0, 0, 1, 21, -200, 22], [1, 31, 32, -200, 33, 34]])
+    am = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1]])
+    both = model.generate(ids, attention_mask=am, mm_state=st, max_new_tokens=4, eos_token_id=-1).cpu()
+    for i in range(2):
+        one = model.generate(ids[i][am[i].bool()][None], mm_state=st, max_new_tokens=4, eos_token_id=-1).cpu()
+        assert torch.equal(both[i], one[0])

@@ -222,9 +222,22 @@ class VidiForCausalLM:
             for i, r in enumerate(rows):
                 out[i, : r.shape[0]] = r
             return out
-        ids, mask, pos = strip_image_token(inputs, attention_mask)
         if mm_state is None and (images is not None or audios is not None):
             mm_state = self.encode_mm_state(images, audios, audio_sizes)
+        if attention_mask is not None and inputs.shape[0] > 1 and not bool(attention_mask[:, 0].bool().all()):
+            # LEFT-padded batch (what Vidi-7B demands for batched generation, mistral.py:366-373; multimodal.py:413-421 re-pads
+            # on the tokenizer's side): rows never interact, so every row is decoded unpadded against the shared video state
+            rows = []
+            for i in range(inputs.shape[0]):
+                kw = dict(kwargs)
+                kw["attention_mask"] = None
+                rows.append(self.generate(inputs[i].cpu()[attention_mask[i].bool().cpu()][None], mm_state=mm_state, **kw)[0])
+            n = max(int(r.shape[0]) for r in rows)
+            out = torch.full((len(rows), n), int(pad), dtype=torch.int64, device=eng.dev)
+            for i, r in enumerate(rows):
+                out[i, : r.shape[0]] = r
+            return out
+        ids, mask, pos = strip_image_token(inputs, attention_mask)
         ts, last = self._prefill(ids, mask, pos, mm_state, max_new)
         B = ids.shape[0]
         out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
