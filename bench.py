@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--preset", default="vidi15_9b")
     ap.add_argument("--vis-chunk", type=int, default=0, help="override cfg.vis_frames_per_chunk (activation chunking only)")
     ap.add_argument("--aud-chunk", type=int, default=0, help="override cfg.aud_chunks_per_batch")
+    ap.add_argument("--no-preproc", action="store_true", help="skip the extra (untimed-in-`value`) GPU preprocessing leg")
+    ap.add_argument("--src-hw", type=int, nargs=2, default=[480, 854], help="decoded frame size fed to the preprocessing leg")
     return ap.parse_args()
 
 
@@ -264,6 +266,29 @@ def main():
         "kernel_families": fams,
         "roofline": roof,
     }
+    if world == 1 and not a.no_preproc:
+        # SURVEY §8f-2 leg, reported beside the metric and never part of `value`: decoded RGB frames (uint8) and 16 kHz PCM
+        # resident in HBM -> pixel_values / input_features through csrc/preproc.hip (bit-exact with PIL + the HF processors)
+        try:
+            from vidi_amd.preproc import FramePreprocessor, LogMelExtractor
+            H0, W0 = a.src_hw
+            gp = torch.Generator(device=dev).manual_seed(7)
+            frames_u8 = torch.randint(0, 256, (T, H0, W0, 3), dtype=torch.uint8, device=dev, generator=gp)
+            pcm = torch.randn(T * 16000, device=dev, generator=gp) * 0.1
+            fp = FramePreprocessor(cfg.vis_image_size, dtype=dtype, device=dev, frames_per_chunk=512)
+            lm = LogMelExtractor(n_mels=cfg.aud_num_mel_bins, dtype=dtype, device=dev)
+            fp(frames_u8[:8]); lm(pcm[: 480000 * 2]); torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            px2 = fp(frames_u8)
+            mel2, alen = lm(pcm)
+            torch.cuda.synchronize()
+            t_pre = time.perf_counter() - tp0
+            assert px2.shape == pixel.shape and mel2.shape == mel.shape and alen == audio_size
+            res["preproc"] = {"ms_per_video": t_pre * 1e3, "source": f"{T} frames {H0}x{W0} RGB uint8 + {T} s PCM, resident in HBM",
+                              "value_incl_preproc": Nv / (ms_per_step / 1e3 + t_pre)}
+            del frames_u8, pcm, px2, mel2
+        except Exception as e:
+            res["preproc"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(cfg, T, Nv, Na, a.prompt_len)
