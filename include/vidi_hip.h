@@ -77,7 +77,7 @@ int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, 
 
 /* LLM K/V projection of the multimodal stream straight into the cross-attention caches
  * (gemma.py:59-65: k_proj, v_proj, DynamicCache.update).  W:[2*kvd,K] = [Wk;Wv].
- * Kc[kvh][tile][64][hd], Vtc[kvh][tile][hd][64 (perm16)], Vrow:[M,kvd] row-major copy of V for the
+ * Kc[kvh][tile64][64][hd], Vtc[kvh][tile32][hd][32 (perm16)] (2*ntile64 sub-tiles), Vrow:[M,kvd] row-major copy of V for the
  * diagonal-stream o_proj.  Token index = tok0 + m. */
 int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* Vrow,
                        int M, int kvd, int K, int ldx, int ldw, int hd, int ntile64, int tok0,

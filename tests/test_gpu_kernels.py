@@ -141,7 +141,7 @@ def test_gemm_kv_cache(hip, cfg):
     ntile = (tok0 + M + 63) // 64
     x = seeded((M, K), 22, dtype=dt); w = seeded((2 * kvd, K), 23, 0.1, dtype=dt)
     ref = x.float() @ w.float().T
-    kc = torch.zeros((nkv, ntile, 64, hd), dtype=dt).cuda(); vtc = torch.zeros((nkv, ntile, hd, 64), dtype=dt).cuda()
+    kc = torch.zeros((nkv, ntile, 64, hd), dtype=dt).cuda(); vtc = torch.zeros((nkv, 2 * ntile, hd, 32), dtype=dt).cuda()
     vrow = torch.zeros((M, kvd), dtype=dt).cuda()
     hip.gemm_kv_cache(dev(x), dev(w), kc, vtc, vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=tok0, tile_cfg=cfg)
     kref, vtref = pack_kv_cache(ref[:, :kvd].view(M, nkv, hd), ref[:, kvd:].view(M, nkv, hd), ntile, tok0)
@@ -238,7 +238,7 @@ def test_attn_cross_split_invariance(hip):
     g = torch.Generator(device="cuda").manual_seed(5)
     ntile = (N + 63) // 64
     kc = (torch.randn((nkv, ntile, 64, HD), generator=g, device="cuda")).to(dt)
-    vtc = (torch.randn((nkv, ntile, HD, 64), generator=g, device="cuda")).to(dt)
+    vtc = (torch.randn((nkv, 2 * ntile, HD, 32), generator=g, device="cuda")).to(dt)
     q = torch.randn((Lq, nq * HD), generator=g, device="cuda").to(dt)
     outs = []
     for zs in (4, 32):

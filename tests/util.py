@@ -54,13 +54,13 @@ def unpack_vt(vt, n):
 
 
 def pack_kv_cache(k, v, ntile64, tok0=0):
-    """k,v:[N,nkv,hd] -> Kc[nkv,ntile,64,hd], Vtc[nkv,ntile,hd,64(perm16)]."""
+    """k,v:[N,nkv,hd] -> Kc[nkv,ntile64,64,hd], Vtc[nkv,2*ntile64,hd,32(perm16)]."""
     N, nkv, hd = k.shape
     kc = torch.zeros((nkv, ntile64 * 64, hd), dtype=k.dtype)
-    vt = torch.zeros((nkv, ntile64, hd, 64), dtype=v.dtype)
+    vt = torch.zeros((nkv, 2 * ntile64, hd, 32), dtype=v.dtype)
     kc[:, tok0: tok0 + N] = k.permute(1, 0, 2)
     tok = np.arange(tok0, tok0 + N)
-    tile = torch.from_numpy(tok >> 6)
-    pos = torch.from_numpy(perm_positions(64)[tok & 63])
+    tile = torch.from_numpy(tok >> 5)
+    pos = torch.from_numpy(perm_positions(32)[tok & 31])
     vt[:, tile, :, pos] = v            # advanced indices (tile,pos) separated by a slice -> result [N,nkv,hd]
     return kc.view(nkv, ntile64, 64, hd), vt

@@ -61,7 +61,7 @@ def main():
     # ---- cross attention decode (60-min video keys)
     nkv, G, HD, Nk = 8, 2, 256, 90000
     ntile = (Nk + 63) // 64
-    kc = rnd((nkv, ntile, 64, HD)); vtc = rnd((nkv, ntile, HD, 64))
+    kc = rnd((nkv, ntile, 64, HD)); vtc = rnd((nkv, 2 * ntile, HD, 32))
     for Lq in (1, 40):
         q = rnd((Lq, nkv * G * HD))
         R = Lq * G; Rpad = (R + 31) // 32 * 32

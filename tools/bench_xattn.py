@@ -1,0 +1,53 @@
+"""Cross-attention decode micro-benchmark (Lq=1 over the 60-min video's keys): ms and algorithmic GB/s per zsplit.
+    PYTHONPATH=. python tools/bench_xattn.py [--keys 126000] [--iters 20]"""
+import argparse
+import json
+
+import torch
+
+from vidi_amd import hip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keys", type=int, default=126000)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--lq", type=int, default=1)
+    ap.add_argument("--zsplit", type=int, nargs="*", default=[16, 32, 64])
+    a = ap.parse_args()
+    hip.load_library()
+    nkv, G, HD, Nk = 8, 2, 256, a.keys
+    ntile = (Nk + 63) // 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    kc = (torch.randn((nkv, ntile, 64, HD), device="cuda", generator=g)).to(torch.bfloat16)
+    vtc = (torch.randn((nkv, 2 * ntile, HD, 32), device="cuda", generator=g)).to(torch.bfloat16)
+    # several independent caches so that consecutive iterations do not hit in the 256 MB infinity cache (42 layers in the model)
+    caches = [(kc, vtc)] + [(torch.randn_like(kc), torch.randn_like(vtc)) for _ in range(5)]
+    q = torch.randn((a.lq, nkv * G * HD), device="cuda", generator=g).to(torch.bfloat16)
+    R = a.lq * G
+    Rpad = (R + 31) // 32 * 32
+    for zs in a.zsplit:
+        opart, ml = hip.attn_cross_workspace(zs, nkv, Rpad, HD, "cuda")
+        o = torch.empty((a.lq, nkv * G * HD), dtype=torch.bfloat16, device="cuda")
+
+        def f(i):
+            k, v = caches[i % len(caches)]
+            hip.attn_cross(q, k, v, None, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD, ntile64=ntile, key_start=0,
+                           n_keys=Nk, scale=HD ** -0.5, softcap=50.0, zsplit=zs)
+            hip.attn_merge(opart, ml, o, W=zs, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+        for i in range(3):
+            f(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(a.iters):
+            f(i)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        print(json.dumps({"kernel": "attn_cross+merge", "Lq": a.lq, "keys": Nk, "zsplit": zs, "ms": ms,
+                          "GBps": Nk * 2 * nkv * HD * 2 / ms / 1e6}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -7,8 +7,8 @@
 // n_keys * 2 * n_kv_heads * head_dim * 2 B.  Design:
 //   * GQA-native: the G query heads sharing a KV head are stacked as rows (row = (token, g)), so
 //     K/V are never repeat_kv'ed (the reference doubles the bytes, gemma.py:77-78).
-//   * K cache is tile-contiguous  Kc[kvh][tile64][64 keys][HD];  V cache is stored transposed and
-//     tile-contiguous  Vtc[kvh][tile64][HD][64 positions]  with the perm16 key order, both written
+//   * K cache is tile-contiguous  Kc[kvh][tile64][64 keys][HD];  V cache is stored transposed in 32-key
+//     sub-tiles  Vtc[kvh][tile32][HD][32 positions]  with the perm16 key order, both written
 //     by the KV-projection GEMM epilogue.  A wave's 32-key sub-tile is 16 KB + 16 KB of perfectly
 //     linear 16-byte global_load_lds DMA.
 //   * split-KV at WAVE granularity: every wave owns a contiguous key range and its private 32 KB
@@ -81,12 +81,12 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     };
     auto issue_v = [&](int st) {
         const int kb = p.key_start + st * 32;
-        const u16* src = vt_head + (size_t)(kb >> 6) * HD * 64 + ((kb >> 5) & 1) * 32;
+        const u16* src = vt_head + (size_t)(kb >> 5) * HD * 32;          // [HD][32 positions]: 16 KB of linear 64-byte rows
 #pragma unroll
         for (int j = 0; j < VLD; ++j) {
             const int pidx = j * 64 + lane, d = pidx >> 2, cl = pidx & 3;
             const int cg = cl ^ ((d >> 2) & 3);
-            glds16(src + d * 64 + cg * 8, sV + j * 1024);
+            glds16(src + d * 32 + cg * 8, sV + j * 1024);
         }
     };
 

@@ -530,12 +530,15 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                         }
                     } else if constexpr (MODE == MODE_KV_CACHE) {
                         if (n >= p.kvd && m < p.M) {               // V: also the transposed, perm16 tile image
-                            const int tok = p.tok0 + m, tile = tok >> 6, tk = tok & 63;
+                            // Vtc[kvh][tile32][hd][32 positions (perm16)]: a 32-key sub-tile is 64-byte rows back to back, so the
+                            // cross-attention fetches whole 128-byte lines (a [hd][64] tile made every sub-tile fetch half-lines
+                            // and the other halves were evicted before the next sub-tile came: 1.5x the HBM bytes, measured)
+                            const int tok = p.tok0 + m, tile = tok >> 5, tk = tok & 31;
                             const int c = n - p.kvd, kvh = c / p.hd, d = c % p.hd;
                             const int pos = (tk & ~15) | perm16(tk & 15);
-                            u16* dst = p.Vtc + (((size_t)kvh * p.ntile64 + tile) * p.hd + d) * 64 + pos;
-                            dst[0] = (u16)(o[0] & 0xffff); dst[64] = (u16)(o[0] >> 16);
-                            dst[128] = (u16)(o[1] & 0xffff); dst[192] = (u16)(o[1] >> 16);
+                            u16* dst = p.Vtc + (((size_t)kvh * p.ntile64 * 2 + tile) * p.hd + d) * 32 + pos;
+                            dst[0] = (u16)(o[0] & 0xffff); dst[32] = (u16)(o[0] >> 16);
+                            dst[64] = (u16)(o[1] & 0xffff); dst[96] = (u16)(o[1] >> 16);
                         }
                     }
                     if (staged) *(u32x2*)(sC + ml * CROW + nl * 2) = o;

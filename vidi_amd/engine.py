@@ -63,7 +63,7 @@ class MMState:
     aud_start: int = 0
     ntile64: int = 0
     kc: Optional[torch.Tensor] = None        # [L, nkv, ntile64, 64, hd]
-    vtc: Optional[torch.Tensor] = None       # [L, nkv, ntile64, hd, 64]
+    vtc: Optional[torch.Tensor] = None       # [L, nkv, 2*ntile64, hd, 32]  (32-key sub-tiles of 64-byte rows)
     img_mask: Optional[torch.Tensor] = None  # uint8 [>= n_img] or None when every key is valid
     aud_mask: Optional[torch.Tensor] = None
     img_any_valid: bool = True
@@ -458,7 +458,7 @@ class VidiEngine:
                 else:
                     hip.scale(src.contiguous(), X[off: off + n], self.normalizer)
         st.kc = torch.empty((Lr, nkv, ntile, 64, hd), dtype=self.dtype, device=self.dev)
-        st.vtc = torch.empty((Lr, nkv, ntile, hd, 64), dtype=self.dtype, device=self.dev)
+        st.vtc = torch.empty((Lr, nkv, 2 * ntile, hd, 32), dtype=self.dtype, device=self.dev)
         hbuf = self._buf("mm_h", (ntot, H))
         vrow = self._buf("mm_vrow", (ntot, kvd))
         u = self._buf("mm_u", (ntot, H))
