@@ -130,6 +130,11 @@ int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void
 /* apply_rotary_pos_emb in place (TP gemma2:146-168); cos/sin:[rows,HD] in the storage dtype. */
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
               int dtype, void* stream);
+/* RoPE + text KV-cache append fused (Gemma2Attention.forward: apply_rotary_pos_emb then past_key_value.update, TP gemma2:262-275):
+ * qkv [B*Lq][ldqkv] = (q | k | v) -> QR [B*Lq][nq*HD] = rope(q); Kc[b][pos0+i] = rope(k); Vc[b][pos0+i] = v, caches
+ * [B][Lmax][nkv*HD].  pos_dev (device int, may be null) overrides pos0: capturable in a hipGraph. */
+int vidi_rope_cache(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cos_, const void* sin_, int B, int Lq,
+                    int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, void* stream);
 
 /* ---- Vidi-7B (Mistral) variants of the same path (Vidi_7B/model/lmm/dattn/mistral.py) ---------------- */
 /* Gated MLP with selectable activation: act = VIDI_ACT_GELU_TANH (Gemma2MLP, same as vidi_gemm_geglu) or

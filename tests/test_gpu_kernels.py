@@ -415,3 +415,29 @@ def test_sinusoid_and_pos_table(hip):
     p = torch.arange(l, dtype=torch.float) / (l - 1) * (N - 1)
     ref = O.fractional_sinusoid(p, d)[i0: i0 + rows]
     report("sinusoid", pe, ref, 2e-5, 0.0)                     # fp32 sin/cos of identical fp32 arguments
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("dyn", [False, True], ids=["host-pos", "device-pos"])
+def test_rope_cache_fused(hip, dt, dyn):
+    """rope(q) + rope(k) + cache append in one launch == vidi_rope followed by slot copies, bit for bit; other slots untouched"""
+    B, Lq, past, nq, nkv, HD, Lmax = 2, (1 if dyn else 5), 9, 4, 2, 128, 32
+    kvd = nkv * HD
+    qkv = seeded((B * Lq, nq * HD + 2 * kvd + 16), 60, dtype=dt)[:, : nq * HD + 2 * kvd]        # row stride != width
+    pos = torch.arange(past, past + Lq)[None].repeat(B, 1)
+    cos, sin = O.rope_cos_sin(pos, HD, 10000.0, dt)
+    cs, sn = dev(cos.reshape(B * Lq, HD).contiguous()), dev(sin.reshape(B * Lq, HD).contiguous())
+    qd = dev(qkv[:, : nq * HD].contiguous()); kd = dev(qkv[:, nq * HD: nq * HD + kvd].contiguous())
+    hip.rope(qd, kd, cs, sn, rows=B * Lq, nq=nq, nkv=nkv, HD=HD)
+    kc0 = seeded((B, Lmax, kvd), 61, dtype=dt); vc0 = seeded((B, Lmax, kvd), 62, dtype=dt)
+    kref, vref = kc0.clone(), vc0.clone()
+    kref[:, past: past + Lq] = kd.cpu().view(B, Lq, kvd)
+    vref[:, past: past + Lq] = qkv[:, nq * HD + kvd:].reshape(B, Lq, kvd)
+    kc, vc = dev(kc0), dev(vc0)
+    qr = torch.empty((B * Lq, nq * HD), dtype=dt, device="cuda")
+    pos_dev = torch.tensor([past], dtype=torch.int32, device="cuda") if dyn else None
+    hip.rope_cache(dev(qkv) if False else qkv.cuda(), qr, kc, vc, cs, sn, B=B, Lq=Lq, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD,
+                   pos0=(0 if dyn else past), pos_dev=pos_dev)
+    assert torch.equal(qr.cpu().view(torch.int16), qd.cpu().view(torch.int16))
+    assert torch.equal(kc.cpu().view(torch.int16), kref.view(torch.int16))
+    assert torch.equal(vc.cpu().view(torch.int16), vref.view(torch.int16))

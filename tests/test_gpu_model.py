@@ -276,9 +276,14 @@ def test_generate_do_sample(tiny_setup):
     mel = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 207, 0.3).to(dt)
     ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26]], dtype=torch.int64)
     st = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
-    greedy = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=False, eos_token_id=-1)
-    k1 = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, top_k=1, eos_token_id=-1)
-    assert torch.equal(greedy, k1)
+    # top_k=1 keeps the maximum and everything tied with it (HF semantics; bf16 logits over a 512-token vocabulary do tie):
+    # the drawn token must carry the maximal logit, and equal the greedy token when the maximum is unique
+    logits = model.forward(ids, mm_state=st, logits_to_keep=1).logits[0, -1].float()
+    greedy = model.generate(ids, mm_state=st, max_new_tokens=1, do_sample=False, eos_token_id=-1)
+    k1 = model.generate(ids, mm_state=st, max_new_tokens=1, do_sample=True, top_k=1, eos_token_id=-1)
+    assert float(logits[int(k1[0, 0])]) == float(logits.max())
+    if int((logits == logits.max()).sum()) == 1:
+        assert torch.equal(greedy, k1)
     g = lambda: torch.Generator(device="cuda").manual_seed(11)                      # noqa: E731
     a = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, temperature=1.5, top_p=0.95, generator=g(), eos_token_id=-1)
     b = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, temperature=1.5, top_p=0.95, generator=g(), eos_token_id=-1)

@@ -268,18 +268,42 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 template <typename T, int HD>
 __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
     const int r = blockIdx.x, kvh = blockIdx.y, d = threadIdx.x;
+    // the W (m, l) pairs of this (row, kv head) are fetched by W threads at once and shared through LDS; the weights
+    // 2^(m_w - m) are then uniform values and the numerator loads of all partials are independent of each other
+    __shared__ float s_m[256], s_l[256];
     float m = -INFINITY;
-    for (int w = 0; w < p.W; ++w) m = fmaxf(m, p.ML[(((size_t)w * p.nkv + kvh) * p.Rpad + r) * 2]);
+    for (int w0 = 0; w0 < p.W; w0 += 256) {
+        __syncthreads();
+        const int nw = min(256, p.W - w0);
+        for (int w = d; w < nw; w += HD) {
+            const size_t base = ((size_t)(w0 + w) * p.nkv + kvh) * p.Rpad + r;
+            s_m[w] = p.ML[base * 2];
+            s_l[w] = p.ML[base * 2 + 1];
+        }
+        __syncthreads();
+        for (int w = 0; w < nw; ++w) m = fmaxf(m, s_m[w]);
+    }
     float num = 0.f, den = 0.f;
     if (m != -INFINITY) {
+        for (int w0 = 0; w0 < p.W; w0 += 256) {
+            const int nw = min(256, p.W - w0);
+            if (p.W > 256) {                                            // re-stage this window (single window: still resident)
+                __syncthreads();
+                for (int w = d; w < nw; w += HD) {
+                    const size_t base = ((size_t)(w0 + w) * p.nkv + kvh) * p.Rpad + r;
+                    s_m[w] = p.ML[base * 2];
+                    s_l[w] = p.ML[base * 2 + 1];
+                }
+                __syncthreads();
+            }
 #pragma unroll 8
-        for (int w = 0; w < p.W; ++w) {
-            const size_t base = ((size_t)w * p.nkv + kvh) * p.Rpad + r;
-            const float mw = p.ML[base * 2];
-            if (mw == -INFINITY) continue;
-            const float sc = fast_exp2(mw - m);
-            den += sc * p.ML[base * 2 + 1];
-            num += sc * p.Opart[base * HD + d];
+            for (int w = 0; w < nw; ++w) {
+                const float mw = s_m[w];
+                const float sc = (mw == -INFINITY) ? 0.f : fast_exp2(mw - m);
+                den += sc * s_l[w];
+                const float v = p.Opart[(((size_t)(w0 + w) * p.nkv + kvh) * p.Rpad + r) * HD + d];
+                num += (mw == -INFINITY) ? 0.f : sc * v;                // a skipped partial may hold stale (even non-finite) data
+            }
         }
     }
     const int tq = r / p.G, g = r % p.G;

@@ -173,6 +173,13 @@ int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, in
     return vidi_rope_dispatch(Q, K, cos_, sin_, rows, nq, nkv, HD, dtype, (hipStream_t)stream);
 }
 
+int vidi_rope_cache(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cos_, const void* sin_, int B, int Lq,
+                    int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!qkv || !QR || !Kc || !Vc || !cos_ || !sin_) return VIDI_ERR_ARG;
+    return vidi_rope_cache_dispatch(qkv, ldqkv, QR, Kc, Vc, cos_, sin_, B, Lq, Lmax, nq, nkv, HD, pos0, pos_dev, dtype, (hipStream_t)stream);
+}
+
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
               void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
               float eps, float normalizer, const int* sample_flag, int dtype, void* stream) {

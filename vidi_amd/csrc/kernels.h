@@ -86,6 +86,8 @@ int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int d
 int vidi_attn_merge_dispatch(const AttnMergeParams& p, int HD, int dtype, hipStream_t st);
 int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStream_t st);
 int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int rows, int nq, int nkv, int HD, int dtype, hipStream_t st);
+int vidi_rope_cache_dispatch(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cs, const void* sn, int B, int Lq,
+                             int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, hipStream_t st);
 int vidi_norm_dispatch(const NormParams& p, int mode, int dtype, hipStream_t st);
 int vidi_ew_dispatch(int op, void** a, const long long* i, const float* f, int dtype, hipStream_t st);
 int vidi_sinusoid_dispatch(float* pe, const float* div, int rows, int i0, int l, int N, int d, hipStream_t st);

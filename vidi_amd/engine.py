@@ -629,20 +629,15 @@ class VidiEngine:
         for li, L in enumerate(self.layers):
             hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                           # gemma.py:162 / mistral.py:187
             self.proj(hn, L["wqkv"], qkv)
-            qr.copy_(qkv[:, :nqd])                                                                   # RoPE'd copy for T2T; raw q for x-attn (:58)
-            kslice = qkv[:, nqd: nqd + kvd]
-            kro = self._buf("t_k", (M, kvd))
-            kro.copy_(kslice)
-            hip.rope(qr, kro, cos, sin, rows=M, nq=nq, nkv=nkv, HD=hd)
+            # RoPE'd q for T2T (raw q stays in qkv for the cross-attention, gemma.py:58), RoPE'd k and v appended to the cache
             window = cfg.sliding_window if (self.mistral or li % 2 == 0) else 0                       # gemma.py:104; Mistral: every layer
             if dyn:
-                ts.kc[li].index_copy_(1, ts.pos_idx, kro.view(B, 1, kvd))
-                ts.vc[li].index_copy_(1, ts.pos_idx, qkv[:, nqd + kvd:].reshape(B, 1, kvd))
+                hip.rope_cache(qkv, qr, ts.kc[li], ts.vc[li], cos, sin, B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
+                               pos_dev=ts.pos_dev)
                 hip.attn_text_dyn(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
                                   past_len_dev=ts.pos_dev, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
             else:
-                ts.kc[li][:, p0: p0 + Lq].copy_(kro.view(B, Lq, kvd))
-                ts.vc[li][:, p0: p0 + Lq].copy_(qkv[:, nqd + kvd:].reshape(B, Lq, kvd))
+                hip.rope_cache(qkv, qr, ts.kc[li], ts.vc[li], cos, sin, B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd, pos0=p0)
                 hip.attn_text(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
                               past_len=p0, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
             k = 1

@@ -40,6 +40,7 @@ SIGNATURES = {
     "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text_dyn": [_c_vp] * 5 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
+    "vidi_rope_cache": [_c_vp, _c_int] + [_c_vp] * 5 + [_c_int] * 7 + [_c_vp, _c_int, _c_vp],
     "vidi_norm": [_c_int] + [_c_vp] * 7 + [_c_int] * 2 + [_c_ll] * 3 + [_c_f, _c_f, _c_vp, _c_int, _c_vp],
     "vidi_scale": [_c_vp] * 2 + [_c_ll, _c_f, _c_int, _c_vp],
     "vidi_any_nonzero": [_c_vp, _c_ll, _c_vp, _c_int, _c_vp],
@@ -342,6 +343,16 @@ def attn_text_dyn(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len_d
     lib = load_library()
     _check(lib.vidi_attn_text_dyn(_p(q), _p(kc), _p(vc), _p(kmask), _p(out), B, Lq, Lmax, nq, nkv, HD, _p(past_len_dev), window,
                                   float(scale), float(softcap or 0.0), _dt(q), _stream()), "vidi_attn_text_dyn")
+
+
+def rope_cache(qkv, qr, kc, vc, cos, sin, *, B, Lq, Lmax, nq, nkv, HD, pos0=0, pos_dev=None):
+    """rope(q) -> qr, rope(k) / v -> cache slots pos0.. (or *pos_dev..) of kc/vc [B, Lmax, nkv*HD], in one launch"""
+    lib = load_library()
+    if pos_dev is not None and (pos_dev.dtype != torch.int32 or not pos_dev.is_cuda):
+        raise VidiHipError("pos_dev must be a device int32 tensor")
+    _rowmajor(qkv, "qkv")
+    _check(lib.vidi_rope_cache(_p(qkv), qkv.stride(0), _p(qr), _p(kc), _p(vc), _p(cos), _p(sin), B, Lq, Lmax, nq, nkv, HD, int(pos0),
+                               _p(pos_dev), _dt(qkv), _stream()), "vidi_rope_cache")
 
 
 def rope(q, k, cos, sin, *, rows, nq, nkv, HD):
