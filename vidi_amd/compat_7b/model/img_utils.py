@@ -1,1 +1,1 @@
-from vidi_amd.processors import process_images  # noqa: F401
+from vidi_amd.processors import process_images, process_images_gpu  # noqa: F401
