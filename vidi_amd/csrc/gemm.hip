@@ -58,9 +58,14 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
 
     // ---- block -> tile: XCD-contiguous remap (bijective), then grouped ordering --------------
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    // Persistent tile loop: the grid may be smaller than the tile count (one block per CU); a block walks tiles
+    // vb = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0 keeps vb on the block's XCD), so the output stores of
+    // one tile drain while the next tile's first K slices are already being fetched, and no block relaunch sits between tiles.
+    const int total_tiles = tiles_n * tiles_m;
+  for (int vb = blockIdx.x; vb < total_tiles; vb += gridDim.x) {
     int tile_n, tile_m;
     {
-        const int nb = gridDim.x, b = blockIdx.x;
+        const int nb = total_tiles, b = vb;
         const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
         const int rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         const int GROUP_M = p.group_m;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
     constexpr int BNO = (MODE == MODE_GEGLU) ? BN / 2 : BN;       // output columns of this tile
     constexpr int CROW = BNO * 2 + 16;                            // padded LDS row (bytes)
     __syncthreads();                                              // every wave is done with the last K slice
-    if (p.diag == 2) return;                                     // timing diagnostic: no epilogue at all
+    if (p.diag == 2) continue;                                     // timing diagnostic: no epilogue at all
     char* sC = smem;
     // copy-out geometry (chunk i = it*NT + tid -> row i / CH, 16-byte chunk i % CH of the staged tile)
     constexpr int CH = BNO / 8, ITERS = BM * CH / NT, UNR = 4;
@@ -601,10 +606,10 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
             }
         }
     }
+    __syncthreads();                                              // the staging tile / ring is reused by the next tile
+  }
 }
 
-// ---- conservative variant: register-staged (global_load -> ds_write), same LDS image ----------
-// Used by the self-test to cross-check the LDS-DMA path and as a fallback selectable from the ABI.
 template <typename T, int MODE, bool REPKV>
 __global__ __launch_bounds__(256) void gemm_kernel_regstage(GemmParams p) {
     constexpr int BN = 128, BM = 128, WM = 2, TN = 2, TM = 2, NT = 256;
@@ -782,7 +787,23 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(WN * WM * 64), LDS, st, p);
+    // One block per CU, each walking several tiles (measured +1...5 % per shape over one block per tile: the stores of a tile
+    // drain under the next tile's first loads and no block relaunch sits between tiles).  VIDI_GEMM_PERSIST=n overrides the
+    // block count (multiple of 8 so a block's tiles stay on its XCD), 0 = one block per tile.
+    static int persist = -1;
+    if (persist < 0) {
+        const char* e = getenv("VIDI_GEMM_PERSIST");
+        if (e) persist = atoi(e);
+        else {
+            int dev = 0, ncu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+            persist = ncu;
+        }
+        if (persist < 0) persist = 0;
+        persist = persist / 8 * 8;
+    }
+    const int gx = (persist > 0 && tiles > persist) ? persist : tiles;
+    hipLaunchKernelGGL(kern, dim3(gx, batch), dim3(WN * WM * 64), LDS, st, p);
     return (int)hipGetLastError();
 }
 
