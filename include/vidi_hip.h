@@ -87,6 +87,11 @@ int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* 
  * lm_head (gemma.py:565) at Lq = 1. */
 int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
               int dtype, void* stream);
+/* Skinny gated-MLP front half (M <= 8): Y[m][i] = T( T(act(T(gate_i . x_m))) * T(up_i . x_m) ) on the vidi_gemm_geglu weight
+ * layout (gate/up rows interleaved in blocks of 32); act = VIDI_ACT_GELU_TANH (Gemma2MLP) or VIDI_ACT_SILU (MistralMLP).
+ * Same values as vidi_gemv + vidi_geglu_unpack / vidi_glu_unpack, one launch. */
+int vidi_gemv_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype,
+                  void* stream);
 
 /* fp32 projection on exact-fp32 MFMA: LearnablePosEmbd's fp32 MLP (mm_vision/pos.py:36-39,55;
  * model/mm_layer/mlp.py:31-40). act: VIDI_ACT_NONE / VIDI_ACT_GELU_ERF. */
@@ -115,6 +120,10 @@ int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* 
  * zero_out=1 reproduces gemma.py:180-192 for a sample with no valid key. */
 int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF32, float* OutML,
                     int W, int nkv, int R, int Rpad, int G, int HD, int ldo, int zero_out, int dtype, void* stream);
+/* Two merges in one launch: the T2V (A) and T2A (B) partials of one decoder layer (same R / nkv / G / ldo). */
+int vidi_attn_merge2(const float* OpartA, const float* MLA, void* OutA, int WA, int zeroA,
+                     const float* OpartB, const float* MLB, void* OutB, int WB, int zeroB,
+                     int nkv, int R, int Rpad, int G, int HD, int ldo, int dtype, void* stream);
 
 /* Text causal self-attention with softcap / sliding window / key mask (gemma.py:165-175 ->
  * TP gemma2:248-288 under FA2) over the text KV cache [B,Lmax,nkv*HD]. */
@@ -154,6 +163,12 @@ int vidi_resize_bilinear_ac(const void* x, void* out, int T, int s_in, int s_out
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,
               void* Y, void* Mask, int rows, int H, long long ldx, long long ldy, long long ldr,
               float eps, float normalizer, const int* sample_flag /* device int, null = 1 */, int dtype, void* stream);
+/* Text-stream fusion of the Gemma2 wiring, one pass per row, results identical to vidi_add3 -> vidi_norm(GEMMA_ADD) ->
+ * vidi_norm(GEMMA):  s = T(T(A+B)+C) (B, C optional);  Y1 = T(Res + T(gemma(s; W1)));  Y2 = T(gemma(Y1; W2)).
+ * gemma.py:236-237 + :118 (attention side) and :120-121 + the next layer's :162 / the final :411 (FFN side).
+ * All tensors [rows, H] with row stride ld; Y1 may alias Res. */
+int vidi_resid_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, void* Y2,
+                     int rows, int H, long long ld, float eps, int dtype, void* stream);
 
 /* ---- data movement / elementwise -------------------------------------------------------------- */
 /* SiglipVisionEmbeddings conv as GEMM input (TP siglip:124-130,178): px:[T,3,S,S] -> A:[T*(S/P)^2,Kpad] */

@@ -441,3 +441,38 @@ def test_rope_cache_fused(hip, dt, dyn):
     assert torch.equal(qr.cpu().view(torch.int16), qd.cpu().view(torch.int16))
     assert torch.equal(kc.cpu().view(torch.int16), kref.view(torch.int16))
     assert torch.equal(vc.cpu().view(torch.int16), vref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,H,nsrc", [(1, 3584, 3), (5, 3584, 1), (39, 256, 2), (3, 1536, 3)])
+def test_resid_norm2_equals_unfused(hip, dt, M, H, nsrc):
+    """add3 -> norm(GEMMA_ADD) -> norm(GEMMA) in one launch: bit-identical to the three launches"""
+    a = seeded((M, H), 70, dtype=dt).cuda(); b = seeded((M, H), 71, dtype=dt).cuda(); c = seeded((M, H), 72, dtype=dt).cuda()
+    res = seeded((M, H), 73, dtype=dt).cuda()
+    w1 = seeded((H,), 74, 0.1, dtype=dt).cuda(); w2 = seeded((H,), 75, 0.1, dtype=dt).cuda()
+    bb, cc = (b if nsrc >= 2 else None), (c if nsrc >= 3 else None)
+    if nsrc == 1:
+        s = a
+    else:
+        s = torch.empty_like(a)
+        hip.add3(a, bb, cc, s)
+    y1_ref = hip.norm(hip.NORM_GEMMA_ADD, s, w1, eps=1e-6, residual=res)
+    y2_ref = hip.norm(hip.NORM_GEMMA, y1_ref, w2, eps=1e-6)
+    y1 = res.clone(); y2 = torch.empty_like(a)
+    hip.resid_norm2(a, bb, cc, y1, w1, w2, y1, y2, eps=1e-6)                      # Y1 aliases Res, as the engine uses it
+    assert torch.equal(y1.view(torch.int16), y1_ref.view(torch.int16))
+    assert torch.equal(y2.view(torch.int16), y2_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,I,K,act", [(1, 14336, 3584, "gelu"), (3, 512, 256, "gelu"), (1, 96, 64, "silu"), (8, 64, 128, "silu")])
+def test_gemv_glu_equals_gemv_plus_unpack(hip, dt, M, I, K, act):
+    """gate/up GEMV with the gated activation fused: bit-identical to vidi_gemv + (ge)glu_unpack"""
+    x = seeded((M, K), 80, dtype=dt).cuda(); w = seeded((2 * I, K), 81, 0.05, dtype=dt).cuda()
+    yp = hip.gemv(x, w)
+    ref = torch.empty((M, I), dtype=dt, device="cuda")
+    code = hip.ACT_GELU_TANH if act == "gelu" else hip.ACT_SILU
+    hip.glu_unpack(yp, ref, code)
+    out = torch.empty_like(ref)
+    hip.gemv_glu(x, w, out, code)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))

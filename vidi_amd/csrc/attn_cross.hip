@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 // Optionally emits the merged result in PARTIAL form (numerator, m, l) for a further cross-GPU merge.
 
 template <typename T, int HD>
-__global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
+__device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
     const int r = blockIdx.x, kvh = blockIdx.y, d = threadIdx.x;
     // the W (m, l) pairs of this (row, kv head) are fetched by W threads at once and shared through LDS; the weights
     // 2^(m_w - m) are then uniform values and the numerator loads of all partials are independent of each other
@@ -317,6 +317,32 @@ __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) {
         p.OutML[pbase * 2] = m;
         p.OutML[pbase * 2 + 1] = den;
     }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) { attn_merge_body<T, HD>(p); }
+
+// two independent merges (the T2V and the T2A partials of one layer) in one launch: blockIdx.z picks the set
+template <typename T, int HD>
+__global__ __launch_bounds__(HD) void attn_merge2_kernel(AttnMergeParams a, AttnMergeParams b) {
+    if (blockIdx.z == 0) attn_merge_body<T, HD>(a); else attn_merge_body<T, HD>(b);
+}
+
+int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b, int HD, int dtype, hipStream_t st) {
+    if (a.R <= 0 || a.W <= 0 || b.W <= 0 || a.R != b.R || a.nkv != b.nkv) return VIDI_ERR_SHAPE;
+    const dim3 grid(a.R, a.nkv, 2);
+    if (dtype == VIDI_DT_BF16) {
+        if (HD == 256) hipLaunchKernelGGL((attn_merge2_kernel<BF16, 256>), grid, dim3(256), 0, st, a, b);
+        else if (HD == 128) hipLaunchKernelGGL((attn_merge2_kernel<BF16, 128>), grid, dim3(128), 0, st, a, b);
+        else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (HD == 256) hipLaunchKernelGGL((attn_merge2_kernel<F16, 256>), grid, dim3(256), 0, st, a, b);
+        else if (HD == 128) hipLaunchKernelGGL((attn_merge2_kernel<F16, 128>), grid, dim3(128), 0, st, a, b);
+        else return VIDI_ERR_SHAPE;
+    } else {
+        return VIDI_ERR_DTYPE;
+    }
+    return (int)hipGetLastError();
 }
 
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st) {

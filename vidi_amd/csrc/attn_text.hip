@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void attn_text_kernel(AttnTextParams p) {
         if (j <= hiK) {
             const u16* kr = kbase + (size_t)j * kvstride;
             float a0 = 0.f, a1 = 0.f;
-#pragma unroll 4
+#pragma unroll (HD / 8 >= 16 ? 16 : HD / 8)                         // 16 row chunks in flight per lane: two L2 round trips per key row at HD = 256
             for (int c = 0; c < HD / 8; ++c) {
                 float f[8];
                 unpack8<T>(*(const u32x4*)(kr + c * 8), f);
@@ -67,8 +67,22 @@ __global__ __launch_bounds__(64) void attn_text_kernel(AttnTextParams p) {
     float o[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < n; ++j) {
+    // PV: the V rows are independent loads -> 16 in flight per lane (the loop is one L2 round trip per batch of rows)
+    int j = 0;
+    for (; j + 16 <= n; j += 16) {
+        u16 vv[16][EPL];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) vv[u][e] = vb[(size_t)(lo + j + u) * kvstride + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float pj = sc[j + u];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] = fmaf(pj, T::to_f32(vv[u][e]), o[e]);
+        }
+    }
+    for (; j < n; ++j) {
         const float pj = sc[j];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = fmaf(pj, T::to_f32(vb[(size_t)(lo + j) * kvstride + e]), o[e]);

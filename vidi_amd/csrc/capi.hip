@@ -97,6 +97,13 @@ int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ld
     return vidi_gemv_dispatch(X, W, Y, M, N, K, ldx, ldw, ldy, dtype, (hipStream_t)stream);
 }
 
+int vidi_gemv_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype,
+                  void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wgu || !Y) return VIDI_ERR_ARG;
+    return vidi_gemv_glu_dispatch(X, Wgu, Y, M, I, K, ldx, ldw, ldy, act, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
                   int ldx, int ldw, int ldy, int act, void* stream) {
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
@@ -142,6 +149,19 @@ int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF3
     return vidi_attn_merge_dispatch(p, HD, dtype, (hipStream_t)stream);
 }
 
+int vidi_attn_merge2(const float* OpartA, const float* MLA, void* OutA, int WA, int zeroA,
+                     const float* OpartB, const float* MLB, void* OutB, int WB, int zeroB,
+                     int nkv, int R, int Rpad, int G, int HD, int ldo, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!OpartA || !MLA || !OutA || !OpartB || !MLB || !OutB) return VIDI_ERR_ARG;
+    AttnMergeParams a, b;
+    a.Opart = OpartA; a.ML = MLA; a.Out = (u16*)OutA; a.OutF32 = nullptr; a.OutML = nullptr;
+    a.W = WA; a.nkv = nkv; a.R = R; a.Rpad = Rpad; a.G = G; a.ldo = ldo; a.zero_out = zeroA;
+    b = a;
+    b.Opart = OpartB; b.ML = MLB; b.Out = (u16*)OutB; b.W = WB; b.zero_out = zeroB;
+    return vidi_attn_merge2_dispatch(a, b, HD, dtype, (hipStream_t)stream);
+}
+
 int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
                    int B, int Lq, int Lmax, int nq, int nkv, int HD, int past_len, int window,
                    float scale, float softcap, int dtype, void* stream) {
@@ -178,6 +198,13 @@ int vidi_rope_cache(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, co
     (void)hipGetLastError();
     if (!qkv || !QR || !Kc || !Vc || !cos_ || !sin_) return VIDI_ERR_ARG;
     return vidi_rope_cache_dispatch(qkv, ldqkv, QR, Kc, Vc, cos_, sin_, B, Lq, Lmax, nq, nkv, HD, pos0, pos_dev, dtype, (hipStream_t)stream);
+}
+
+int vidi_resid_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, void* Y2,
+                     int rows, int H, long long ld, float eps, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!A || !Res || !W1 || !W2 || !Y1 || !Y2) return VIDI_ERR_ARG;
+    return vidi_resid_norm2_dispatch(A, B, C, Res, W1, W2, Y1, Y2, rows, H, ld, eps, dtype, (hipStream_t)stream);
 }
 
 int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const void* Bias, const void* Res,

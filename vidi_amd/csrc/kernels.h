@@ -78,12 +78,16 @@ struct NormParams {
     float eps, normalizer; const int* sample_flag;   // device flag (null = 1)
 };
 
+int vidi_resid_norm2_dispatch(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1,
+                              void* Y2, int rows, int H, long long ld, float eps, int dtype, hipStream_t st);
 int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int tile_cfg, int dtype, hipStream_t st);
+int vidi_gemv_glu_dispatch(const void* X, const void* W, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype, hipStream_t st);
 int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int dtype, hipStream_t st);
 int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t st);
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);
 int vidi_attn_merge_dispatch(const AttnMergeParams& p, int HD, int dtype, hipStream_t st);
+int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b, int HD, int dtype, hipStream_t st);
 int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStream_t st);
 int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int rows, int nq, int nkv, int HD, int dtype, hipStream_t st);
 int vidi_rope_cache_dispatch(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cs, const void* sn, int B, int Lq,

@@ -102,6 +102,103 @@ __global__ __launch_bounds__(256) void norm_kernel(NormParams p) {
     }
 }
 
+// ---- text-stream fusion (Gemma2 wiring): add3 -> residual + post-norm -> next pre-norm in ONE pass over the row ------------
+//   s  = T(T(a + b) + c)                      (b, c optional)                      gemma.py:236
+//   y1 = T(res + T(gemma(s;  w1)))            -> Y1 (may alias res)                gemma.py:237 / :120-121
+//   y2 = T(gemma(y1; w2))                     -> Y2                                gemma.py:118 / :162 of the next layer / :411
+// Arithmetic, rounding points and summation order are those of add3_kernel + norm_kernel<GEMMA_ADD> + norm_kernel<GEMMA> run one
+// after the other (bit-identical results); it replaces 3 (attention side) or 2 (FFN side) launches of the decode step.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void resid_norm2_kernel(const u16* __restrict__ A, const u16* __restrict__ B, const u16* __restrict__ C,
+                                                          const u16* Res, const u16* __restrict__ W1, const u16* __restrict__ W2,
+                                                          u16* Y1, u16* __restrict__ Y2, int rows, int H, long long ld, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = H / 8;
+    // every operand of the row is requested up front (one memory round trip for the whole kernel: at M = 1 a single wave
+    // runs this and the three dependent phases would otherwise each pay a full load latency)
+    u32x4 ra[MAXC], rb[MAXC], rc[MAXC], rr[MAXC], rw1[MAXC], rw2[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            ra[c] = *(const u32x4*)(A + row * ld + ch * 8);
+            if (B) rb[c] = *(const u32x4*)(B + row * ld + ch * 8);
+            if (C) rc[c] = *(const u32x4*)(C + row * ld + ch * 8);
+            rr[c] = *(const u32x4*)(Res + row * ld + ch * 8);
+            rw1[c] = *(const u32x4*)(W1 + ch * 8);
+            rw2[c] = *(const u32x4*)(W2 + ch * 8);
+        }
+    }
+    float x[MAXC][8];
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            unpack8<T>(ra[c], x[c]);
+            float z[8];
+            if (B) {
+                unpack8<T>(rb[c], z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(x[c][e] + z[e]);
+            }
+            if (C) {
+                unpack8<T>(rc[c], z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(x[c][e] + z[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s2 += x[c][e] * x[c][e];
+        }
+    }
+    const float rs1 = rsqrtf(wave_sum(s2) / H + eps);
+    float t2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float w[8], r[8];
+            unpack8<T>(rw1[c], w);
+            unpack8<T>(rr[c], r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(r[e] + rnd<T>(x[c][e] * rs1 * (1.0f + w[e])));
+            *(u32x4*)(Y1 + row * ld + ch * 8) = pack8<T>(x[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t2 += x[c][e] * x[c][e];
+        }
+    }
+    const float rs2 = rsqrtf(wave_sum(t2) / H + eps);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float w[8], y[8];
+            unpack8<T>(rw2[c], w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = x[c][e] * rs2 * (1.0f + w[e]);
+            *(u32x4*)(Y2 + row * ld + ch * 8) = pack8<T>(y);
+        }
+    }
+}
+
+int vidi_resid_norm2_dispatch(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1,
+                              void* Y2, int rows, int H, long long ld, float eps, int dtype, hipStream_t st) {
+    if (rows <= 0 || H <= 0 || H % 8 || ld % 8) return VIDI_ERR_SHAPE;
+    const int nchunk = H / 8, grid = (rows + 3) / 4;
+#define VIDI_RN2(TT, MC)                                                                                                         \
+    hipLaunchKernelGGL((resid_norm2_kernel<TT, MC>), dim3(grid), dim3(256), 0, st, (const u16*)A, (const u16*)B, (const u16*)C,    \
+                       (const u16*)Res, (const u16*)W1, (const u16*)W2, (u16*)Y1, (u16*)Y2, rows, H, ld, eps)
+    if (dtype == VIDI_DT_BF16) {
+        if (nchunk <= 64) VIDI_RN2(BF16, 1); else if (nchunk <= 192) VIDI_RN2(BF16, 3); else if (nchunk <= 512) VIDI_RN2(BF16, 8); else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (nchunk <= 64) VIDI_RN2(F16, 1); else if (nchunk <= 192) VIDI_RN2(F16, 3); else if (nchunk <= 512) VIDI_RN2(F16, 8); else return VIDI_ERR_SHAPE;
+    } else return VIDI_ERR_DTYPE;
+#undef VIDI_RN2
+    return (int)hipGetLastError();
+}
+
 template <typename T, int MODE>
 static int norm_launch(const NormParams& p, hipStream_t st) {
     const int nchunk = p.H / 8;

@@ -523,7 +523,7 @@ class VidiEngine:
             self._rope_cache = (emb.cos().to(self.dtype).to(self.dev), emb.sin().to(self.dtype).to(self.dev))
         return self._rope_cache
 
-    def _cross(self, q: torch.Tensor, li: int, mm: MMState, which: str, out: torch.Tensor, R: int):
+    def _cross(self, q: torch.Tensor, li: int, mm: MMState, which: str, out: torch.Tensor, R: int, defer_merge: bool = False):
         cfg = self.cfg
         nkv, hd = cfg.num_key_value_heads, cfg.head_dim
         G = cfg.num_attention_heads // nkv
@@ -535,7 +535,7 @@ class VidiEngine:
         nsub = (n + 31) // 32
         row_tiles = Rpad // 32
         zsplit = max(1, min(256 // max(1, nkv * row_tiles), (nsub + 7) // 8))
-        key = f"xattn_ws_{zsplit}_{Rpad}"
+        key = f"xattn_ws_{which}_{zsplit}_{Rpad}"        # one workspace per modality: both partial sets live until the merge
         if key not in self._ws:
             self._ws[key] = hip.attn_cross_workspace(zsplit, nkv, Rpad, hd, self.dev)
         opart, ml = self._ws[key]
@@ -544,8 +544,10 @@ class VidiEngine:
                            key_start=start, n_keys=n, scale=cfg.query_pre_attn_scalar ** -0.5,
                            softcap=cfg.attn_logit_softcapping, zsplit=zsplit)
         if self.world == 1:
+            if defer_merge and n > 0:
+                return (opart, ml, out, zsplit, not any_valid)      # merged together with the other modality (attn_merge2)
             hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
-            return
+            return None
         # ---- keys are sharded over ranks: local merge -> partial form -> all-gather -> exact LSE merge ----
         import torch.distributed as dist
         pk = f"xattn_part_{Rpad}"
@@ -626,8 +628,12 @@ class VidiEngine:
         dn = self._buf("t_d", (M, H))
         sc = cfg.query_pre_attn_scalar ** -0.5
         tmp = self._buf("t_tmp", (M, H)) if self.mistral else None
+        fused = not self.mistral       # Gemma2 wiring: add3 + post-norm/residual + next pre-norm run as one launch (vidi_resid_norm2)
+        nL = len(self.layers)
+        final_out = None
         for li, L in enumerate(self.layers):
-            hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                           # gemma.py:162 / mistral.py:187
+            if not (fused and li > 0):                                                               # fused: produced by the previous layer's FFN side
+                hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                       # gemma.py:162 / mistral.py:187
             self.proj(hn, L["wqkv"], qkv)
             # RoPE'd q for T2T (raw q stays in qkv for the cross-attention, gemma.py:58), RoPE'd k and v appended to the cache
             window = cfg.sliding_window if (self.mistral or li % 2 == 0) else 0                       # gemma.py:104; Mistral: every layer
@@ -643,10 +649,20 @@ class VidiEngine:
             k = 1
             qraw = qkv[:, :nqd]
             G = nq // nkv
+            both = has_img and has_aud and self.world == 1
+            pend = []
             if has_img:
-                self._cross(qraw, li, mm, "img", att[k * M: (k + 1) * M], R=M * G); k += 1
+                pend.append(self._cross(qraw, li, mm, "img", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
             if has_aud:
-                self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G); k += 1
+                pend.append(self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
+            if both:
+                if pend[0] is not None and pend[1] is not None:     # T2V and T2A partials merged by one launch
+                    (oa, mla, outa, wa, za), (ob, mlb, outb, wb, zb) = pend
+                    hip.attn_merge2(oa, mla, outa, wa, za, ob, mlb, outb, wb, zb, nkv=nkv, R=M * G, Rpad=_round_up(M * G, 32), G=G, HD=hd)
+                else:
+                    for pd in pend:
+                        if pd is not None:
+                            hip.attn_merge(pd[0], pd[1], pd[2], W=pd[3], nkv=nkv, R=M * G, Rpad=_round_up(M * G, 32), G=G, HD=hd, zero_out=pd[4])
             # one o_proj pass over the stacked [text; image; audio] attention outputs (gemma.py:94 x3)
             self.proj(att[: nstream * M], L["wo"], oall[: nstream * M])
             if self.mistral:
@@ -659,30 +675,31 @@ class VidiEngine:
                     hip.add3(tmp, oall[2 * M: 3 * M], None, hidden)
                 hip.norm(hip.NORM_MM, hidden, L["ln_post_attn"], eps=eps, out=hn)
                 if M <= 8:
-                    hip.gemv(hn, L["wgu"], yp)
-                    hip.glu_unpack(yp, gt, hip.ACT_SILU)
+                    hip.gemv_glu(hn, L["wgu"], gt, hip.ACT_SILU)
                     hip.gemv(gt, L["wdown"], dn)
                     hip.add3(hidden, dn, None, hidden)
                 else:
                     hip.gemm_glu(hn, L["wgu"], gt, act=hip.ACT_SILU)
                     hip.gemm(gt, L["wdown"], None, hidden, residual=hidden)
                 continue
-            if nstream == 1:
-                src = oall[:M]
-            else:
-                hip.add3(oall[:M], oall[M: 2 * M], oall[2 * M: 3 * M] if nstream == 3 else None, ssum)   # :236
-                src = ssum
-            hip.norm(hip.NORM_GEMMA_ADD, src, L["ln_post_attn"], eps=eps, residual=hidden, out=hidden)  # :237
-            hip.norm(hip.NORM_GEMMA, hidden, L["ln_pre_ffn"], eps=eps, out=hn)                          # :118
+            # text + image + audio (:236), residual + post_attention_layernorm (:237), pre_feedforward_layernorm (:118)
+            hip.resid_norm2(oall[:M], oall[M: 2 * M] if nstream >= 2 else None, oall[2 * M: 3 * M] if nstream == 3 else None,
+                            hidden, L["ln_post_attn"], L["ln_pre_ffn"], hidden, hn, eps=eps)
             if M <= 8:
-                hip.gemv(hn, L["wgu"], yp)
-                hip.geglu_unpack(yp, gt)
+                hip.gemv_glu(hn, L["wgu"], gt, hip.ACT_GELU_TANH)
             else:
                 hip.gemm_geglu(hn, L["wgu"], gt)
             self.proj(gt, L["wdown"], dn)
-            hip.norm(hip.NORM_GEMMA_ADD, dn, L["ln_post_ffn"], eps=eps, residual=hidden, out=hidden)    # :120-121
+            # residual + post_feedforward_layernorm (:120-121), then the NEXT layer's input_layernorm (:162) or the final norm (:411)
+            if li + 1 < nL:
+                hip.resid_norm2(dn, None, None, hidden, L["ln_post_ffn"], self.layers[li + 1]["ln_in"], hidden, hn, eps=eps)
+            else:
+                final_out = torch.empty_like(hidden)
+                hip.resid_norm2(dn, None, None, hidden, L["ln_post_ffn"], self.final_norm, hidden, final_out, eps=eps)
         if not dyn:
             ts.past_len = p0 + Lq
+        if final_out is not None:
+            return final_out
         return hip.norm(self.norm_mode, hidden, self.final_norm, eps=eps)                               # gemma.py:411 / mistral.py:423
 
     # ---- graph-captured greedy decode -------------------------------------------------

@@ -33,15 +33,18 @@ SIGNATURES = {
     "vidi_gemm_qkv_vt": [_c_vp] * 5 + [_c_int] * 13 + [_c_vp],
     "vidi_gemm_kv_cache": [_c_vp] * 5 + [_c_int] * 10 + [_c_vp],
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
+    "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
     "vidi_attn_self": [_c_vp] * 3 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
     "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
+    "vidi_attn_merge2": [_c_vp] * 3 + [_c_int] * 2 + [_c_vp] * 3 + [_c_int] * 2 + [_c_int] * 7 + [_c_vp],
     "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text_dyn": [_c_vp] * 5 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
     "vidi_rope_cache": [_c_vp, _c_int] + [_c_vp] * 5 + [_c_int] * 7 + [_c_vp, _c_int, _c_vp],
     "vidi_norm": [_c_int] + [_c_vp] * 7 + [_c_int] * 2 + [_c_ll] * 3 + [_c_f, _c_f, _c_vp, _c_int, _c_vp],
+    "vidi_resid_norm2": [_c_vp] * 8 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp],
     "vidi_scale": [_c_vp] * 2 + [_c_ll, _c_f, _c_int, _c_vp],
     "vidi_any_nonzero": [_c_vp, _c_ll, _c_vp, _c_int, _c_vp],
     "vidi_im2col_patch": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
@@ -110,8 +113,12 @@ def _work(name, a):
         return "attn_cross", float(a[14]) * 2 * a[9] * a[10] * 2, "byte"
     if name == "vidi_norm":
         return "norm", float(a[8]) * a[9] * 2 * 2, "byte"
+    if name == "vidi_resid_norm2":
+        return "norm", float(a[8]) * a[9] * 2 * (2 + (a[1] is not None) + (a[2] is not None) + 2), "byte"
     if name == "vidi_gemv":
         return "gemv", float(a[4]) * a[5] * 2, "byte"
+    if name == "vidi_gemv_glu":
+        return "gemv", 2.0 * a[4] * a[5] * 2, "byte"
     if name == "vidi_gemm_f32":
         return "gemm_f32", 2.0 * a[4] * a[5] * a[6], "flop"
     if name == "vidi_resize_h_u8":                      # read every source byte once, write the uint8 intermediate once
@@ -287,6 +294,16 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -
     return out
 
 
+def gemv_glu(x: torch.Tensor, wgu: torch.Tensor, out: torch.Tensor, act: int = ACT_GELU_TANH) -> torch.Tensor:
+    """out[m, i] = act(gate_i . x_m) * (up_i . x_m) for M <= 8 rows on the interleaved gate/up weight (gemv + unpack in one launch)"""
+    lib = load_library()
+    M, K = x.shape
+    I = wgu.shape[0] // 2
+    _check(lib.vidi_gemv_glu(_p(x), _p(wgu), _p(out), M, I, K, x.stride(0), wgu.stride(0), out.stride(0), act, _dt(x), _stream()),
+           "vidi_gemv_glu")
+    return out
+
+
 def gemm_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
     lib = load_library()
     assert x.dtype == torch.float32 and w.dtype == torch.float32
@@ -328,6 +345,14 @@ def attn_merge(opart, ml, out, *, W, nkv, R, Rpad, G, HD, zero_out=False, out_f3
     dt = _dt(out) if out is not None else (dtype if dtype is not None else DT_BF16)
     _check(lib.vidi_attn_merge(_p(opart), _p(ml), _p(out), _p(out_f32), _p(out_ml), W, nkv, R, Rpad, G, HD, ldo,
                                1 if zero_out else 0, dt, _stream()), "vidi_attn_merge")
+
+
+def attn_merge2(opart_a, ml_a, out_a, W_a, zero_a, opart_b, ml_b, out_b, W_b, zero_b, *, nkv, R, Rpad, G, HD):
+    """two attn_merge calls (image and audio partials of one layer) in one launch"""
+    lib = load_library()
+    assert out_a.stride(0) == out_b.stride(0)
+    _check(lib.vidi_attn_merge2(_p(opart_a), _p(ml_a), _p(out_a), W_a, 1 if zero_a else 0, _p(opart_b), _p(ml_b), _p(out_b), W_b,
+                                1 if zero_b else 0, nkv, R, Rpad, G, HD, out_a.stride(0), _dt(out_a), _stream()), "vidi_attn_merge2")
 
 
 def attn_text(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len, window, scale, softcap):
@@ -378,6 +403,18 @@ def norm(mode: int, x: Optional[torch.Tensor], weight: Optional[torch.Tensor], *
     _check(lib.vidi_norm(mode, _p(x), _p(x_f32), _p(weight), _p(bias), _p(residual), _p(out), _p(mask_out), rows, H,
                          ldx, ldy, ldr, float(eps), float(normalizer), _p(sample_flag), _dt(out), _stream()), "vidi_norm")
     return out
+
+
+def resid_norm2(a, b, c, res, w1, w2, y1, y2, *, eps: float):
+    """y1 = T(res + T(gemma(T(T(a+b)+c); w1))), y2 = T(gemma(y1; w2)) — add3 + norm_add + norm in one launch (y1 may alias res)"""
+    lib = load_library()
+    rows, H = a.shape
+    for t in (a, b, c, res, y1, y2):
+        if t is not None and (t.stride(0) != a.stride(0) or t.stride(1) != 1):
+            raise VidiHipError("resid_norm2: all row tensors must share the row stride")
+    _check(lib.vidi_resid_norm2(_p(a), _p(b), _p(c), _p(res), _p(w1), _p(w2), _p(y1), _p(y2), rows, H, a.stride(0), float(eps), _dt(a),
+                                _stream()), "vidi_resid_norm2")
+    return y1, y2
 
 
 def im2col_patch(px, out, *, T, S, P, Kpad):
