@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvidi_hip.so")
+LIB_PATH = os.environ.get("VIDI_HIP_LIB") or os.path.join(_HERE, "libvidi_hip.so")      # VIDI_HIP_LIB: A/B a second build of the same ABI
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
