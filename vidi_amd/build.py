@@ -14,7 +14,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libvidi_hip.so")
 SOURCES = ["gemm.hip", "attn_self.hip", "attn_cross.hip", "attn_text.hip", "rowops.hip", "elementwise.hip", "preproc.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "vidi_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]      # (+ the resource-usage remark, see _compile)
 # MFMA results in architectural VGPRs: without this hipcc parks the attention accumulators in AGPRs and copies them
 # to VGPRs and back around every softmax step (attn_self: 2192 v_accvgpr moves, 204 registers -> 0 moves, 150)
 EXTRA_FLAGS = {"attn_self.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attn_cross.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
@@ -46,10 +46,15 @@ def _compile(src: str, force: bool) -> str:
     dig = _digest([os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS])
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    # -Rpass-analysis=kernel-resource-usage: the per-kernel register / scratch report is kept next to the object
+    # (csrc/build/<src>.resources.txt); tests/test_build_resources.py fails if a hot kernel spills (a spill in the GEMM body
+    # once cost 11 % end to end without any functional symptom)
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    with open(obj.replace(".o", ".resources.txt"), "w") as f:
+        f.write(r.stderr)
     with open(stamp, "w") as f:
         f.write(dig)
     return obj
