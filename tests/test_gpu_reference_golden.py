@@ -94,3 +94,29 @@ def test_vidi7b_against_reference_execution(dt):
     ref = torch.from_numpy(D["A_audio_embeds"])[0]
     report("7B audio_embeds vs reference execution", feats, ref, *tol(dt, ref.std().item()))
     check_case(model, D, "A", dt, n_new=5)
+
+
+def test_vidi15_token_budget_branch_against_reference_execution():
+    """case D of the goldens: 3 760 frames cross the token budget inside the reference's own encode_video_images ((10, 10) via
+    resize_by_tokens, bilinear up-sampling in Conv2DPool, 25 tokens/frame).  HIP path: same token count (bit-exact integer rule),
+    sampled embeddings and prefill logits within the bf16 tolerances."""
+    from vidi_amd.config import tiny
+    dt = torch.bfloat16
+    D = np.load(os.path.join(GOLD, "reference_dattn.npz"))
+    cfg = tiny(sliding_window=64)
+    model = build(cfg, dt)
+    T = int(D["D_n_frames"][0])
+    S, M, Fr = cfg.vis_image_size, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames
+    gd = torch.Generator().manual_seed(777)
+    px = (torch.randn((1, T, 3, S, S), generator=gd) * 0.5).clamp(-1, 1)
+    mel = torch.randn((1, 1, M, Fr), generator=gd) * 0.3
+    feats, mask = model.engine.encode_video_images(px[0].to(dt).cuda())
+    assert feats.shape[0] == int(D["D_n_tokens"][0]) == 25 * T and int(mask.sum()) == int(D["D_mask_sum"][0])
+    for name, sl in (("head", slice(0, 50)), ("mid", slice(47000, 47050)), ("tail", slice(-50, None))):
+        ref = torch.from_numpy(D[f"D_embeds_{name}"])
+        report(f"D embeds {name} vs reference execution", feats[sl], ref, *tol(dt, ref.std().item()))
+    out = model.forward(torch.from_numpy(D["D_input_ids"]), images=px.to(dt).cuda(), audios=mel.to(dt).cuda(),
+                        audio_sizes=D["D_audio_sizes"].tolist(), logits_to_keep=1)
+    ref = torch.from_numpy(D["D_prefill_logits"])
+    atol, rtol = tol(dt, ref.std().item())
+    report("D prefill logits vs reference execution", out.logits[:, -1], ref, 3 * atol, rtol)

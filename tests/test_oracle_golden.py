@@ -192,3 +192,24 @@ def test_dattn_7b_matches_reference_execution():
     _close("7B prefill logits", dbg["prefill_logits"], t7("A_prefill_logits"))
     assert toks.tolist() == D7["A_tokens"].tolist()
     _close("7B step logits", torch.stack(dbg["step_logits"], dim=1), t7("A_step_logits"))
+
+
+def test_dattn_token_budget_branch_end_to_end(dattn_setup):
+    """3 760 tiny frames cross `max_tokens = 60000 * pool^2` (multimodal.py:175-180): the reference's own encode_video_images chose
+    (10, 10) via resize_by_tokens and up-sampled inside Conv2DPool -> 25 tokens per frame; the oracle must land on the same tokens,
+    the same embeddings (sampled rows) and the same prefill logits.  Frames are regenerated from the generator's seed."""
+    cfg, ocfg, w = dattn_setup
+    T = int(D["D_n_frames"][0])
+    S, M, Fr = cfg.vis_image_size, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames
+    gd = torch.Generator().manual_seed(777)
+    px = (torch.randn((1, T, 3, S, S), generator=gd) * 0.5).clamp(-1, 1)
+    mel = torch.randn((1, 1, M, Fr), generator=gd) * 0.3
+    toks, dbg = O.generate_greedy(d("D_input_ids"), list(px), list(mel), D["D_audio_sizes"].tolist(), w, ocfg, 1, return_debug=True)
+    emb = dbg["image_embeds"]
+    assert emb.shape[1] == int(D["D_n_tokens"][0]) == 25 * T
+    assert int(dbg["image_mask"].sum()) == int(D["D_mask_sum"][0])
+    _close("D embeds head", emb[0, :50], d("D_embeds_head"))
+    _close("D embeds mid", emb[0, 47000:47050], d("D_embeds_mid"))
+    _close("D embeds tail", emb[0, -50:], d("D_embeds_tail"))
+    assert abs(float(emb.abs().mean()) - float(D["D_embeds_abs_mean"][0])) < 1e-6
+    _close("D prefill logits", dbg["prefill_logits"], d("D_prefill_logits"), 1e-4, 1e-4)
