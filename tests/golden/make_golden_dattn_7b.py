@@ -71,7 +71,7 @@ def build_reference_model(cfg):
     for k in ("mm_input_type", "mm_projector_type", "mm_image_aspect_ratio", "mm_image_pool_size", "mm_audio_pool_size",
               "mm_std", "mm_time_interval", "mm_vision_tower", "mm_audio_tower", "mm_vision_select_layer"):
         setattr(c, k, getattr(cfg, k))
-    c.mm_splits = 2
+    c.mm_splits = 32          # what eval/inference.py:87 sets before asking (inputs smaller than 32 go through split_data's repeat path)
     c.train_vis = False
     c.train_aud = False
     c._attn_implementation = "flash_attention_2"
