@@ -21,11 +21,11 @@ def tol(dt, k=1.0):
     return (5e-2 * k, 3e-2) if dt == torch.bfloat16 else (1e-2 * k, 6e-3)
 
 
-def build(cfg, dt):
+def build(cfg, dt, seed=3):
     from vidi_amd.engine import VidiEngine
     from vidi_amd.model import VidiForCausalLM
     from vidi_amd.weights import init_random_weights
-    w = init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu")        # the weights the goldens were made with
+    w = init_random_weights(cfg, seed=seed, dtype=torch.float32, device="cpu")     # the weights the goldens were made with
     eng = VidiEngine(cfg, {k: v.to(dt) if not k.count(".mm_rand_pos_") else v for k, v in w.items()}, dtype=dt, device="cuda")
     model = VidiForCausalLM.__new__(VidiForCausalLM)
     model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
@@ -120,3 +120,26 @@ def test_vidi15_token_budget_branch_against_reference_execution():
     ref = torch.from_numpy(D["D_prefill_logits"])
     atol, rtol = tol(dt, ref.std().item())
     report("D prefill logits vs reference execution", out.logits[:, -1], ref, 3 * atol, rtol)
+
+
+def test_vidi15_generate_against_reference_generate():
+    """cases E/F: the reference's own generate() (HF greedy loop threaded by gemma.py:657-687).  Ours must return the same NEW tokens
+    wherever the reference's top-2 score margin exceeds the bf16 tolerance, and stop at EOS like it does."""
+    from vidi_amd.config import tiny
+    dt = torch.bfloat16
+    D = np.load(os.path.join(GOLD, "reference_dattn.npz"))
+    cfg = tiny(sliding_window=64)
+    px = torch.from_numpy(D["A_images"]).to(dt).cuda(); mel = torch.from_numpy(D["A_audios"]).to(dt).cuda()
+    m6 = build(cfg, dt, seed=6)
+    got = m6.generate(torch.from_numpy(D["E_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=8, do_sample=False,
+                      use_cache=True, pad_token_id=0).cpu()
+    scores = torch.from_numpy(D["E_scores"])[0]
+    atol, _ = tol(dt, scores.std().item())
+    for i in range(got.shape[1]):
+        top2 = torch.topk(scores[i], 2).values
+        if float(top2[0] - top2[1]) <= 6 * atol:
+            break
+        assert int(got[0, i]) == int(D["E_tokens"][0, i]), f"step {i}: {int(got[0, i])} != reference generate() {int(D['E_tokens'][0, i])}"
+    m3 = build(cfg, dt, seed=3)
+    got = m3.generate(torch.from_numpy(D["F_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=8, do_sample=False).cpu()
+    assert got.tolist() == D["F_tokens"].tolist()                       # [[eos]]: one new token, then stop

@@ -213,3 +213,17 @@ def test_dattn_token_budget_branch_end_to_end(dattn_setup):
     _close("D embeds tail", emb[0, -50:], d("D_embeds_tail"))
     assert abs(float(emb.abs().mean()) - float(D["D_embeds_abs_mean"][0])) < 1e-6
     _close("D prefill logits", dbg["prefill_logits"], d("D_prefill_logits"), 1e-4, 1e-4)
+
+
+def test_dattn_reference_generate_loop(dattn_setup):
+    """the reference's own generate() driving HF's greedy loop (gemma.py:603-687): new tokens only, per-step scores, EOS stop"""
+    cfg, ocfg, w = dattn_setup
+    from vidi_amd.weights import init_random_weights
+    w6 = init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu")
+    images, audios = list(d("A_images")), list(d("A_audios"))
+    toks, dbg = O.generate_greedy(d("E_input_ids"), images, audios, [100], w6, ocfg, 8, return_debug=True)
+    assert toks.tolist() == D["E_tokens"].tolist() and len(set(toks[0].tolist())) > 1
+    got = torch.stack([dbg["prefill_logits"]] + dbg["step_logits"], dim=1)
+    _close("E per-step scores", got, d("E_scores"), 1e-4, 1e-4)
+    toks = O.generate_greedy(d("F_input_ids"), images, audios, [100], w, ocfg, 8)
+    assert toks.tolist() == D["F_tokens"].tolist() == [[cfg.eos_token_id]]
