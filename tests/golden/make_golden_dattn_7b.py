@@ -152,6 +152,14 @@ def main():
     res = {"A_" + k: v for k, v in a.items()}
     res["A_input_ids"] = ids.numpy(); res["A_images"] = px.numpy(); res["A_audios"] = mel.numpy()
     res["A_audio_sizes"] = np.array([100])
+    # ---- case E: the reference's OWN generate() (mistral.py:629-681 -> HF greedy loop threaded by :683-716), weights seed 6:
+    # six different greedy tokens, per-step scores
+    model.generation_config.eos_token_id = cfg.eos_token_id
+    load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
+    with torch.no_grad():
+        g = model.generate(ids, images=px, audios=mel, audio_sizes=[100], do_sample=False, max_new_tokens=6, use_cache=True,
+                           pad_token_id=0, output_scores=True, return_dict_in_generate=True)
+    res["E_tokens"] = g.sequences.numpy(); res["E_scores"] = torch.stack(g.scores, dim=1).numpy()
     np.savez_compressed(OUT, **res)
     print("wrote", OUT, f"{os.path.getsize(OUT) / 1e6:.2f} MB;", len(res), "arrays")
 

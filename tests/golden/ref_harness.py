@@ -241,6 +241,7 @@ def install_7b():
     import transformers.models.clip.modeling_clip  # noqa: F401
     import transformers.utils as tu
     import transformers.cache_utils as cu
+    _RealCache = cu.Cache
 
     fa = _stub("flash_attn", flash_attn_func=flash_attn_func, flash_attn_varlen_func=flash_attn_varlen_func)
     fa.__path__ = []
@@ -278,5 +279,6 @@ def install_7b():
         sys.path.insert(0, REF_7B)
     import model.lmm.dattn.mistral as M7
     M7.DynamicCache = ListCache
-    M7.Cache = ListCache                                               # `isinstance(past_key_values, Cache)` (mistral.py:338)
+    # `isinstance(past_key_values, Cache)` (mistral.py:338): our list cache, or the cache object HF's generate() loop creates
+    M7.Cache = (ListCache, _RealCache)
     return M7, mm

@@ -143,3 +143,24 @@ def test_vidi15_generate_against_reference_generate():
     m3 = build(cfg, dt, seed=3)
     got = m3.generate(torch.from_numpy(D["F_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=8, do_sample=False).cpu()
     assert got.tolist() == D["F_tokens"].tolist()                       # [[eos]]: one new token, then stop
+
+
+def test_vidi7b_generate_against_reference_generate():
+    """Vidi-7B case E: six different greedy tokens from the reference's own generate(); ours must agree wherever the margin allows"""
+    from vidi_amd.config import tiny_7b
+    dt = torch.bfloat16
+    D = np.load(os.path.join(GOLD, "reference_dattn_7b.npz"))
+    cfg = tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64)
+    m6 = build(cfg, dt, seed=6)
+    px = torch.from_numpy(D["A_images"]).to(dt).cuda(); mel = torch.from_numpy(D["A_audios"]).to(dt).cuda()
+    got = m6.generate(torch.from_numpy(D["A_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=6, do_sample=False).cpu()
+    scores = torch.from_numpy(D["E_scores"])[0]
+    atol, _ = tol(dt, scores.std().item())
+    agreed = 0
+    for i in range(got.shape[1]):
+        top2 = torch.topk(scores[i], 2).values
+        if float(top2[0] - top2[1]) <= 6 * atol:
+            break
+        assert int(got[0, i]) == int(D["E_tokens"][0, i]), f"step {i}: {int(got[0, i])} != reference generate() {int(D['E_tokens'][0, i])}"
+        agreed += 1
+    assert agreed >= 1

@@ -227,3 +227,18 @@ def test_dattn_reference_generate_loop(dattn_setup):
     _close("E per-step scores", got, d("E_scores"), 1e-4, 1e-4)
     toks = O.generate_greedy(d("F_input_ids"), images, audios, [100], w, ocfg, 8)
     assert toks.tolist() == D["F_tokens"].tolist() == [[cfg.eos_token_id]]
+
+
+def test_dattn_7b_reference_generate_loop():
+    """Vidi-7B: the reference's own generate() under HF's loop (mistral.py:629-716), weights seed 6 — six different greedy tokens"""
+    from vidi_amd.config import tiny_7b
+    from vidi_amd.weights import init_random_weights
+    cfg = tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64)
+    w6 = init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu")
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    ocfg = O.OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in names}, vis_select_layer=cfg.mm_vision_select_layer, arch="mistral")
+    t7 = lambda n: torch.from_numpy(D7[n])                                          # noqa: E731
+    toks, dbg = O.generate_greedy(t7("A_input_ids"), list(t7("A_images")), list(t7("A_audios")), D7["A_audio_sizes"].tolist(),
+                                  w6, ocfg, 6, return_debug=True)
+    assert toks.tolist() == D7["E_tokens"].tolist() and len(set(toks[0].tolist())) >= 4
+    _close("7B E per-step scores", torch.stack([dbg["prefill_logits"]] + dbg["step_logits"], dim=1), t7("E_scores"), 1e-4, 1e-4)
