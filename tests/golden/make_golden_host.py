@@ -64,6 +64,19 @@ def main():
         res = INF.ask(question, "video.mp4", Model(), Tok(), None, AP())
         out["ask"].append({"question": question, "answer": answer, "length": length, "result": res,
                            "input_ids": captured["input_ids"], "generate_kwargs": captured["kwargs"]})
+    # ---- process_images (dataset/img_utils.py:173-198, 'resize' mode) executed with a real SiglipImageProcessor at a small size
+    import numpy as np
+    from PIL import Image
+    from transformers import SiglipImageProcessor
+    import vidi.dataset.img_utils as IU
+    proc = SiglipImageProcessor(size={"height": 98, "width": 98}, image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+    proc.output_size = 98
+    rng = np.random.default_rng(42)
+    frames = [rng.integers(0, 256, size=(120, 213, 3), dtype=np.uint8), rng.integers(0, 256, size=(120, 213, 3), dtype=np.uint8)]
+    frames[1][:40, :100] = 255
+    cfgobj = type("C", (), {"mm_image_aspect_ratio": "resize"})()
+    pv = IU.process_images([Image.fromarray(f) for f in frames], proc, cfgobj)
+    np.savez_compressed(os.path.join(HERE, "reference_process_images.npz"), frames=np.stack(frames), pixel_values=pv.numpy())
     with open(os.path.join(HERE, "reference_host.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote reference_host.json:", {k: len(v) for k, v in out.items()})

@@ -77,3 +77,12 @@ def test_logmel_silence_and_short_clip():
     assert length == 300 and float((got + 1.5).abs().max()) <= 1e-6          # log10f(1e-10f) is one ulp off -10
     got, length = ext(synth_audio(16000, 9)[:100])
     assert length == 0 and got.shape == (1, 128, 3000) and torch.isfinite(got).all()
+
+
+def test_frames_gpu_matches_reference_process_images():
+    """GPU frame path == the reference's own process_images output (tests/golden/reference_process_images.npz), bit for bit"""
+    import os
+    from vidi_amd.preproc import FramePreprocessor
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_process_images.npz"))
+    got = FramePreprocessor(98, dtype=torch.float32)(g["frames"]).cpu().numpy()
+    assert np.array_equal(got, g["pixel_values"])

@@ -139,3 +139,20 @@ def test_ask_prompt_and_postprocessing_match_reference_execution():
         from vidi_amd.model import VidiForCausalLM
         sig = inspect.signature(VidiForCausalLM.generate)
         assert all(k in sig.parameters or any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values()) for k in case["generate_kwargs"])
+
+
+def test_process_images_matches_reference_execution():
+    """dataset/img_utils.py:process_images('resize') executed by the reference on two frames -> ours (host path) and the
+    preprocessing oracle reproduce it bit for bit"""
+    from PIL import Image
+    from transformers import SiglipImageProcessor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import preproc_oracle as PO
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_process_images.npz"))
+    proc = SiglipImageProcessor(size={"height": 98, "width": 98}, image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+    proc.output_size = 98
+    cfgobj = type("C", (), {"mm_image_aspect_ratio": "resize"})()
+    ours = P.process_images([Image.fromarray(f) for f in g["frames"]], proc, cfgobj).numpy()
+    assert np.array_equal(ours, g["pixel_values"])
+    orc = np.stack([PO.siglip_rescale_normalize(PO.pil_resize_bicubic_u8(f, 98, 98)) for f in g["frames"]])
+    assert np.array_equal(orc, g["pixel_values"])
