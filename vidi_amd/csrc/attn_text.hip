@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void attn_text_kernel(AttnTextParams p) {
         if (j <= hiK) {
             const u16* kr = kbase + (size_t)j * kvstride;
             float a0 = 0.f, a1 = 0.f;
-#pragma unroll (HD / 8 >= 16 ? 16 : HD / 8)                         // 16 row chunks in flight per lane: two L2 round trips per key row at HD = 256
+#pragma unroll 8                                                   // 8 row chunks (128 B) in flight per lane and pass
             for (int c = 0; c < HD / 8; ++c) {
                 float f[8];
                 unpack8<T>(*(const u32x4*)(kr + c * 8), f);
