@@ -17,7 +17,7 @@ static GemmParams base_params(const void* X, const void* W, const void* bias, vo
     p.rmod = rmod > 0 ? rmod : 0x7fffffff;
     {
         static int gm = -1;
-        if (gm < 0) { const char* e = getenv("VIDI_GEMM_GROUP_M"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
+        if (gm < 0) { const char* e = getenv("VIDI_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 4; }     // 4 m-tiles per group: +0.8 % over 8 on the 60-min prefill (same binary, same box)
         p.group_m = gm;
         static int dg = -1;
         if (dg < 0) { const char* e = getenv("VIDI_GEMM_EXPERIMENTAL") ? getenv("VIDI_GEMM_DIAG") : nullptr; dg = e ? atoi(e) : 0; }
