@@ -622,8 +622,6 @@ class VidiEngine:
         qr = self._buf("t_qr", (M, nqd))
         att = self._buf("t_att", (3 * M, nqd))
         oall = self._buf("t_o", (3 * M, H))
-        ssum = self._buf("t_s", (M, H))
-        yp = self._buf("t_yp", (M, 2 * cfg.intermediate_size))
         gt = self._buf("t_g", (M, cfg.intermediate_size))
         dn = self._buf("t_d", (M, H))
         sc = cfg.query_pre_attn_scalar ** -0.5
