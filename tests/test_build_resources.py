@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "vidi_amd", "csrc", "build")
 HOT = {
     "gemm.resources.txt": ["gemm_kernel", "gemv_kernel", "gemv_glu_kernel", "gemm_f32_kernel"],
+    "gemm_w4_bf16.resources.txt": ["gemm_w4_kernel"],
+    "gemm_w4_f16.resources.txt": ["gemm_w4_kernel"],
+    "gemm_w4_modes.resources.txt": ["gemm_w4_kernel"],
     "attn_self.resources.txt": ["attn_self_kernel"],
     "attn_cross.resources.txt": ["attn_cross_kernel", "attn_merge"],
     "attn_text.resources.txt": ["attn_text_kernel", "rope_cache_kernel"],
@@ -36,6 +39,9 @@ def parse(path):
 def test_hot_kernels_do_not_spill(report):
     path = os.path.join(BUILD, report)
     if not os.path.exists(path):
+        import shutil
+        if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+            pytest.skip("no resource report and no hipcc to produce one")
         from vidi_amd.build import build
         build(force=True, verbose=False)
     kernels = parse(path)
@@ -44,10 +50,10 @@ def test_hot_kernels_do_not_spill(report):
     for name, res in kernels.items():
         if not any(h in name for h in HOT[report]):
             continue
-        # experimental GEMM schedules / tile shapes that are never dispatched by default may spill; the shipped 256x256, 2x4-wave,
-        # 2-stage, 16x16x32-MFMA configuration (tile_cfg 4) and the small-M 128x128 one (tile_cfg 0) may not
-        if "gemm_kernel" in name and not (re.search(r"Li256ELi256ELi2ELi4ELi2ELi\dELb[01]ELi64ELi6ELi16EEv10GemmParams$", name)
-                                          or re.search(r"Li128ELi128ELi2ELi2ELi2ELi\dELb[01]ELi64ELi0ELi32EEv10GemmParams$", name)):
+        # tile shapes that are never dispatched by default (tile_cfg 1, 2, 11) may spill; the persistent 4-wave kernel (every
+        # instantiation), the 8-wave 256x256 16x16x32-MFMA kernel (tile_cfg 4) and the small-problem 128x128 one (tile_cfg 0) may not
+        if "gemm_kernel" in name and not (re.search(r"Li256ELi256ELi2ELi4ELi2ELi\dELb[01]ELi6ELi16E7LabNoneEv10GemmParams$", name)
+                                          or re.search(r"Li128ELi128ELi2ELi2ELi2ELi\dELb[01]ELi0ELi32E7LabNoneEv10GemmParams$", name)):
             continue
         checked += 1
         # (SGPR spills go to VGPR lanes, not to memory: tolerated)

@@ -38,7 +38,7 @@ def dev(t):
 # GEMM family
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 11, 12])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 11])
 def test_gemm_plain_tiles(hip, dt, cfg):
     """asymmetric operands, M/N not multiples of the tile, bias"""
     M, N, K = 300, 352, 192
@@ -48,7 +48,7 @@ def test_gemm_plain_tiles(hip, dt, cfg):
     report(f"gemm cfg{cfg}", y, ref, *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 11, 12])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 11])
 def test_gemm_large_k_and_auto(hip, cfg):
     dt = torch.bfloat16
     M, N, K = 1000, 1152, 4352
@@ -79,6 +79,65 @@ def test_gemm_act_residual(hip, dt, act):
     report("gemm inplace residual", res, ref2, *tol(dt, ref2.std().item()))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("bias,act,res", [(0, "", 0), (1, "", 0), (1, "", 1), (1, "", 2), (1, "tanh", 0), (1, "erf", 0), (1, "erf", 2), (0, "", 1)])
+def test_gemm_w4_epilogues(hip, dt, bias, act, res):
+    """persistent 4-wave kernel (tile_cfg 5): every instantiated epilogue combination, ragged M / N edges, 4 K slices
+    (main loop + both tail bodies); `res` 1 = row residual (in place), 2 = position table (rows repeat every rmod)"""
+    from vidi_amd import hip as H
+    M, N, K, rmod = 600, 416, 256, 100
+    x = seeded((M, K), 31, dtype=dt); w = seeded((N, K), 32, 0.1, dtype=dt)
+    b = seeded((N,), 33, dtype=dt) if bias else None
+    lin = F.linear(x.float(), w.float(), None if b is None else b.float())
+    lin = lin.to(dt).float()                                                  # module output rounds before the activation
+    a = O.gelu_tanh(lin) if act == "tanh" else O.gelu_erf(lin) if act == "erf" else lin
+    a = a.to(dt).float()
+    kw = {"act": {"": H.ACT_NONE, "tanh": H.ACT_GELU_TANH, "erf": H.ACT_GELU_ERF}[act], "tile_cfg": 5}
+    if res == 1:
+        r = seeded((M, N), 34, dtype=dt)
+        out = dev(r).clone()
+        hip.gemm(dev(x), dev(w), None if b is None else dev(b), out, residual=out, **kw)
+        ref = a + r.float()
+    elif res == 2:
+        r = seeded((rmod, N), 35, dtype=dt)
+        out = hip.gemm(dev(x), dev(w), None if b is None else dev(b), residual=dev(r), rmod=rmod, **kw)
+        ref = a + r.float().repeat(M // rmod, 1)
+    else:
+        out = hip.gemm(dev(x), dev(w), None if b is None else dev(b), **kw)
+        ref = a
+    report(f"w4 bias={bias} act={act} res={res}", out, ref, *tol(dt, ref.std().item()))
+
+
+def test_gemm_w4_tile_loop_matches_8wave_bitwise(hip):
+    """more tiles than CUs, so every persistent block walks several tiles (next-tile DMA issued before the epilogue, first
+    k32 step with C = 0): the output must equal the 8-wave kernel's bit for bit (same accumulation order), both tile orders"""
+    import os
+    dt = torch.bfloat16
+    M, N, K = 256 * 21 + 40, 256 * 15 + 96, 192
+    x = seeded((M, K), 36, dtype=dt); w = seeded((N, K), 37, 0.1, dtype=dt)
+    y4 = hip.gemm(dev(x), dev(w), None, tile_cfg=4)
+    y5 = hip.gemm(dev(x), dev(w), None, tile_cfg=5)
+    assert torch.equal(y4, y5)
+    ref = x.float() @ w.float().T
+    report("w4 tile loop", y5, ref, *tol(dt, ref.std().item()))
+
+
+def test_gemm_w4_batched_overlapping_rows(hip):
+    """conv-as-GEMM view through the persistent kernel: ldx < K (rows overlap), batch strides, GELU(erf) + position table"""
+    from vidi_amd import hip as H
+    dt = torch.bfloat16
+    C, L, nm, Da = 5, 300, 64, 320
+    buf = seeded((C, L + 2, nm), 38, dtype=dt)
+    w = seeded((Da, 3 * nm), 39, 0.1, dtype=dt); b = seeded((Da,), 40, dtype=dt); pos = seeded((L, Da), 41, dtype=dt)
+    out = torch.zeros((C, L, Da), dtype=dt).cuda()
+    hip.gemm(dev(buf)[0], dev(w), dev(b), out, act=H.ACT_GELU_ERF, residual=dev(pos), rmod=L, M=L, K=3 * nm, ldx=nm,
+             batch=C, bsX=(L + 2) * nm, bsY=L * Da, bsR=0, tile_cfg=5)
+    rows = torch.stack([buf[:, t: t + 3].reshape(C, -1) for t in range(L)], dim=1).float()
+    lin = (rows @ w.float().T + b.float()).to(dt).float()
+    ref = O.gelu_erf(lin).to(dt).float() + pos.float()
+    report("w4 batched overlap", out, ref, *tol(dt, ref.std().item()))
+
+
 def test_gemm_batched_overlapping_rows(hip):
     """conv-as-GEMM view: ldx < K (rows overlap), batch strides — the Whisper stem pattern"""
     dt = torch.bfloat16
@@ -93,7 +152,7 @@ def test_gemm_batched_overlapping_rows(hip):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 2, 4, 12])
+@pytest.mark.parametrize("cfg", [-1, 2, 4, 5])
 def test_gemm_repkv(hip, dt, cfg):
     nkv, G, hd, H, M = 2, 2, 128, 256, 150
     v = seeded((M, nkv * hd), 14, dtype=dt); wo = seeded((H, nkv * G * hd), 15, 0.05, dtype=dt)
@@ -104,7 +163,7 @@ def test_gemm_repkv(hip, dt, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 12])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5])
 def test_gemm_geglu(hip, dt, cfg):
     M, I, K = 200, 256, 128
     x = seeded((M, K), 16, dtype=dt); g = seeded((I, K), 17, 0.1, dtype=dt); u = seeded((I, K), 18, 0.1, dtype=dt)
@@ -114,7 +173,21 @@ def test_gemm_geglu(hip, dt, cfg):
     report("gemm geglu", y, ref, *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [-1, 2, 4, 12])
+@pytest.mark.parametrize("cfg", [0, 4, 5])
+def test_gemm_glu_gelu_equals_geglu(hip, cfg):
+    """vidi_gemm_glu(act = GELU_TANH) is vidi_gemm_geglu: p.act selects the gate function only (the 8-wave kernel once
+    applied it a second time in its copy-out pass)"""
+    from vidi_amd import hip as H
+    dt = torch.bfloat16
+    M, I, K = 200, 256, 128
+    x = seeded((M, K), 16, dtype=dt); g = seeded((I, K), 17, 0.1, dtype=dt); u = seeded((I, K), 18, 0.1, dtype=dt)
+    wgu = torch.stack([g.view(I // 32, 32, K), u.view(I // 32, 32, K)], dim=1).reshape(2 * I, K).contiguous()
+    y0 = hip.gemm_geglu(dev(x), dev(wgu), tile_cfg=cfg)
+    y1 = hip.gemm_glu(dev(x), dev(wgu), act=H.ACT_GELU_TANH, tile_cfg=cfg)
+    assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("cfg", [-1, 2, 4, 5])
 @pytest.mark.parametrize("hd,N,nh", [(72, 729, 4), (16, 49, 4), (64, 50, 2)])
 def test_gemm_qkv_vt(hip, hd, N, nh, cfg):
     dt = torch.bfloat16
@@ -133,7 +206,7 @@ def test_gemm_qkv_vt(hip, hd, N, nh, cfg):
     report("qkv_vt V", v, ref[:, 2 * Hd:], *tol(dt, ref.std().item()))
 
 
-@pytest.mark.parametrize("cfg", [-1, 2, 4, 12])
+@pytest.mark.parametrize("cfg", [-1, 2, 4, 5])
 def test_gemm_kv_cache(hip, cfg):
     dt = torch.bfloat16
     nkv, hd, K, M, tok0 = 2, 128, 128, 170, 64

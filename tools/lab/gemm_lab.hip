@@ -1,0 +1,209 @@
+// Bench-only GEMM lab (NOT part of libvidi_hip.so): times schedules of vidi_amd/csrc/gemm_tile.h on the 60-min workload's
+// GEMM shapes with random bf16 data, checks every variant's output checksum against the shipped schedule (all correct-result
+// variants must be bit-identical), and hosts the timing diagnostics (LAB policies: no DMA / no epilogue / phase stamps) that
+// the product library does not contain.  No torch, no Python: one hipcc binary, seconds per run on the GPU box.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vidi_amd/csrc tools/lab/gemm_lab.hip -o tools/lab/gemm_lab
+//   tools/lab/gemm_lab [set]          set: all | quick | stamps | store
+#include "gemm_w4.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct LabNoDma : LabNone { static constexpr bool no_dma = true; };
+struct LabNoEpi : LabNone { static constexpr bool no_epilogue = true; };
+struct LabNoStore : LabNone { static constexpr bool no_store = true; };
+struct LabStamps : LabNone { static constexpr bool stamps = true; };
+
+__global__ void fill_kernel(u16* p, size_t n, unsigned seed, float scale, int zero) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed ^ (unsigned)(i >> 32) * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        const float u = ((h & 0xffffff) / 8388608.0f - 1.0f) * scale;      // uniform [-scale, scale)
+        p[i] = zero ? (u16)0 : f32_to_bf16(u);
+    }
+}
+__global__ void checksum_kernel(const u16* p, size_t n, unsigned long long* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned long long s = 0, x = 0;
+    for (; i < n; i += stride) { const unsigned long long v = p[i]; s += v * (unsigned long long)((i % 1021) + 1); x ^= (v << (i % 47)); }
+    atomicAdd(out, s);
+    atomicXor(out + 1, x);
+}
+
+// store-path micro-benchmark: every block writes `bytes` with 16-byte coalesced stores
+__global__ void store_kernel(u32x4* out, int chunks_per_thread) {
+    u32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    u32x4* o = out + (size_t)blockIdx.x * blockDim.x * chunks_per_thread;
+    for (int i = 0; i < chunks_per_thread; ++i) o[(size_t)i * blockDim.x + threadIdx.x] = v;
+}
+
+typedef int (*launch_fn)(const GemmParams&, hipStream_t);
+
+template <typename T, int BN, int BM, int WN, int WM, int STAGES, int MODE, bool REPKV, int SCHED, int MI, typename LAB>
+static int lab_launch(const GemmParams& p, hipStream_t st) {
+    constexpr int RING = STAGES * (BN + BM) * 64 * 2;
+    constexpr int CTILE = BM * ((MODE == MODE_GEGLU ? BN / 2 : BN) * 2 + 16);
+    constexpr int LDS = RING > CTILE ? RING : CTILE;
+    auto kern = gemm_kernel<T, BN, BM, WN, WM, STAGES, MODE, REPKV, SCHED, MI, LAB>;
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
+    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    hipLaunchKernelGGL(kern, dim3(tiles, 1), dim3(WN * WM * 64), LDS, st, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int MODE, bool PERSIST, int WAITMODE, typename LAB>
+static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
+    auto kern = gemm_w4_kernel<T, MODE, false, PERSIST, Epi<false, ACT_NONE, 0>, WAITMODE, LAB>;
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, W4Geom::LDS_BYTES)); done = true; }
+    const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
+    const int grid = PERSIST ? (tiles < 256 ? tiles : 256) : tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W4Geom::LDS_BYTES, st, p, 1);
+    return (int)hipGetLastError();
+}
+
+struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; };
+
+#define LATE(MODE, LAB) lab_launch<BF16, 256, 256, 2, 4, 2, MODE, false, SCHED_LATE, 16, LAB>
+#define W4(MODE, PERSIST, WAITMODE, LAB) lab_launch_w4<BF16, MODE, PERSIST, WAITMODE, LAB>
+
+static std::vector<Variant> variants() {
+    return {
+        {"late", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4},
+        {"late_o1", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 1, 4},
+        {"w4s", W4(MODE_PLAIN, false, 0, LabNone), MODE_PLAIN, true, 0, 4},          // strip epilogue, one block per tile
+        {"w4p", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 0, 4},           // persistent, drain before the next tile
+        {"w4pc", W4(MODE_PLAIN, true, 1, LabNone), MODE_PLAIN, true, 0, 4},          // persistent, counted wait
+        {"w4p_o1", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 4},
+        {"w4pc_o1", W4(MODE_PLAIN, true, 1, LabNone), MODE_PLAIN, true, 1, 4},
+        {"w4p_o1_g2", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 2},
+        {"w4p_g8", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 0, 8},
+        {"w4p_o1_g8", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 8},
+        {"w4p_nodma", W4(MODE_PLAIN, true, 0, LabNoDma), MODE_PLAIN, false, 0, 4},
+        {"w4p_noepi", W4(MODE_PLAIN, true, 0, LabNoEpi), MODE_PLAIN, false, 0, 4},
+        {"w4p_nostore", W4(MODE_PLAIN, true, 0, LabNoStore), MODE_PLAIN, false, 0, 4},
+        {"late_stamps", LATE(MODE_PLAIN, LabStamps), MODE_PLAIN, true, 0, 4},
+        {"w4p_stamps", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 0, 4},
+        {"late_geglu", LATE(MODE_GEGLU, LabNone), MODE_GEGLU, true, 0, 4},
+        {"w4p_geglu", W4(MODE_GEGLU, true, 0, LabNone), MODE_GEGLU, true, 0, 4},
+    };
+}
+
+struct Shape { const char* name; int M, N, K; };
+
+int main(int argc, char** argv) {
+    const std::string set = argc > 1 ? argv[1] : "quick";
+    const int iters = argc > 2 ? atoi(argv[2]) : 5;
+    const int zero = getenv("LAB_ZERO") ? 1 : 0;
+    std::vector<Shape> shapes = {
+        {"siglip_qkv", 262440, 3456, 1152}, {"siglip_o", 262440, 1152, 1152}, {"siglip_fc1", 262440, 4352, 1152},
+        {"siglip_fc2", 262440, 1152, 4352}, {"mm_kv", 126080, 4096, 3584}, {"mm_o", 126080, 3584, 4096},
+        {"mm_down", 126080, 3584, 14336}, {"whisper_fc1", 180000, 5120, 1280}, {"sq8k", 8192, 8192, 8192}, {"mm_gateup", 126080, 28672, 3584},
+    };
+    std::vector<std::string> want;
+    if (set == "quick") want = {"late", "w4s", "w4p", "w4pc"};
+    else if (set == "order") want = {"late", "late_o1", "w4p", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8"};
+    else if (set == "diag") want = {"late", "w4p", "w4p_nodma", "w4p_noepi", "w4p_nostore"};
+    else if (set == "stamps") want = {"late_stamps", "w4p_stamps"};
+    else if (set == "geglu") want = {"late_geglu", "w4p_geglu"};
+    else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
+    else if (set == "store") want = {};
+    else { want = {set}; }
+    const char* only = getenv("LAB_SHAPE");
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    unsigned long long* dsum; CK(hipMalloc(&dsum, 16));
+    unsigned long long* dbg; CK(hipMalloc(&dbg, 1024 * 8 * 8));
+
+    if (set == "store" || set == "all") {
+        // 128 KB per block (one 256x256 bf16 tile), 1 block per CU worth of blocks x 8 rounds; 256 vs 512 threads; fewer active CUs
+        u32x4* buf; const size_t bytes = (size_t)2048 * 128 * 1024; CK(hipMalloc(&buf, bytes));
+        for (int threads : {256, 512}) for (int blocks : {32, 64, 128, 256, 2048}) {
+            const int cpt = 128 * 1024 / 16 / threads;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0));
+                for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(store_kernel, dim3(blocks), dim3(threads), 0, 0, buf, cpt);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) printf("{\"bench\": \"store\", \"threads\": %d, \"blocks\": %d, \"us_per_launch\": %.2f, \"GBps\": %.1f, \"B_per_clk_per_block_at_2GHz\": %.2f}\n",
+                                threads, blocks, ms * 250.0, 4.0 * blocks * 131072.0 / ms / 1e6, 131072.0 / (ms * 250.0 * 1e-6 * 2e9) * (blocks > 256 ? blocks / 256.0 : 1.0));
+            }
+        }
+        CK(hipFree(buf));
+        fflush(stdout);
+    }
+
+    auto vs = variants();
+    for (const Shape& sh : shapes) {
+        if (only && strcmp(only, sh.name)) continue;
+        if (want.empty()) break;
+        u16 *X, *W, *Y;
+        const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
+        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2));
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, nx, 0x1234u, 1.7f, zero);
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 0x9876u, 0.035f, zero);
+        CK(hipDeviceSynchronize());
+        unsigned long long ref[4][2] = {};
+        bool have_ref[4] = {false, false, false, false};
+        for (const std::string& wn : want) {
+            const Variant* v = nullptr;
+            for (auto& c : vs) if (wn == c.name) v = &c;
+            if (!v) { printf("unknown variant %s\n", wn.c_str()); continue; }
+            if (v->mode == MODE_GEGLU && (sh.N % 64)) continue;
+            GemmParams p; memset(&p, 0, sizeof(p));
+            p.X = X; p.W = W; p.Y = Y; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.ldx = sh.K; p.ldw = sh.K;
+            p.ldy = v->mode == MODE_GEGLU ? sh.N / 2 : sh.N; p.rmod = 0x7fffffff; p.group_m = v->group_m; p.order = v->order; p.act = ACT_GELU_TANH * (v->mode == MODE_GEGLU);
+            p.dbg = dbg;
+            CK(hipMemset(Y, 0xff, ny * 2));
+            CK(hipMemset(dbg, 0, 1024 * 64));
+            int rc = v->fn(p, 0);
+            if (rc) { printf("launch %s failed %d\n", v->name, rc); continue; }
+            CK(hipDeviceSynchronize());
+            CK(hipMemset(dsum, 0, 16));
+            const size_t nyo = v->mode == MODE_GEGLU ? ny / 2 : ny;
+            hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, Y, nyo, dsum);
+            unsigned long long cs[2]; CK(hipMemcpy(cs, dsum, 16, hipMemcpyDeviceToHost));
+            v->fn(p, 0);                                             // warm
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) v->fn(p, 0);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+            const char* verdict = "n/a";
+            if (v->correct) {
+                const int md = v->mode;
+                if (!have_ref[md]) { ref[md][0] = cs[0]; ref[md][1] = cs[1]; have_ref[md] = true; verdict = "ref"; }
+                else verdict = (cs[0] == ref[md][0] && cs[1] == ref[md][1]) ? "bit-identical" : "MISMATCH";
+            }
+            printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"variant\": \"%s\", \"ms\": %.4f, \"tflops\": %.1f, \"checksum\": \"%016llx%016llx\", \"vs_ref\": \"%s\"}\n",
+                   sh.name, sh.M, sh.N, sh.K, v->name, ms, 2.0 * sh.M * sh.N * sh.K / ms / 1e9, cs[0], cs[1], verdict);
+            if (wn.find("stamps") != std::string::npos) {
+                std::vector<unsigned long long> h(1024 * 8);
+                CK(hipMemcpy(h.data(), dbg, 1024 * 64, hipMemcpyDeviceToHost));
+                double a[4] = {0, 0, 0, 0}; int n = 0;
+                for (int b = 0; b < 1024; ++b) {
+                    const unsigned long long* d = &h[b * 8];
+                    if (!d[4]) continue;
+                    if (wn.find("w4") != std::string::npos) { a[0] += (double)d[0]; a[1] += (double)d[1]; a[2] += (double)d[2]; a[3] += (double)d[3]; }
+                    else { a[0] += (double)(d[1] - d[0]); a[1] += (double)(d[2] - d[1]); a[2] += (double)(d[3] - d[2]); a[3] += (double)(d[4] - d[3]); }
+                    ++n;
+                }
+                // late: per block (= per tile) setup / K loop / staging / copy-out; w4p: per block totals over its tiles of wait+frag reads / K loop / next-head issue / epilogue
+                if (n) printf("{\"shape\": \"%s\", \"variant\": \"%s\", \"blocks\": %d, \"cycles_0\": %.0f, \"cycles_1\": %.0f, \"cycles_2\": %.0f, \"cycles_3\": %.0f, \"k_iters\": %d, \"tiles\": %d}\n",
+                              sh.name, v->name, n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, sh.K / 64, ((sh.M + 255) / 256) * ((sh.N + 255) / 256));
+            }
+            fflush(stdout);
+        }
+        CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y));
+    }
+    return 0;
+}

@@ -49,6 +49,14 @@ struct BF16 {
     static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c, 0, 0, 0);
     }
+    // accumulator pinned to the AGPR file ("+a"): a 128x128 wave tile is 256 accumulator registers = the whole AGPR file, and
+    // left to itself hipcc splits them between the files and copies them around every MFMA (measured in the .s)
+    static __device__ __forceinline__ void mfma16_agpr(f32x4& c, const u32x4& a, const u32x4& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma16_agpr_first(f32x4& c, const u32x4& a, const u32x4& b) {      // c = a*b (C operand = 0)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    }
 };
 struct F16 {
     static constexpr int id = VIDI_DT_F16;
@@ -59,6 +67,12 @@ struct F16 {
     }
     static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mfma16_agpr(f32x4& c, const u32x4& a, const u32x4& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma16_agpr_first(f32x4& c, const u32x4& a, const u32x4& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
     }
 };
 

@@ -1,0 +1,409 @@
+// Persistent 4-wave MFMA GEMM for the large projections of the Vidi hot path (gfx950).
+//
+//   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] )        X:[M,K] activations, W:[N,K] nn.Linear weight, 256x256x64 tiles
+//
+// One workgroup per CU, 4 waves, ONE wave per SIMD (up to 512 registers): every wave owns a 128(n) x 128(m) sub-tile,
+// i.e. 256 accumulator registers = the whole AGPR file (pinned there with "+a" asm operands: left to itself hipcc splits them
+// between the two files and copies them around every MFMA).  Compared with 8 waves x (128x64) this reads one third fewer
+// fragment bytes from LDS per FLOP and frees the VGPR file for a full K slice of fragments.
+//
+// K loop (slice kt lives in LDS buffer kt & 1, 64 KB each, XOR-swizzled rows, filled by 16-byte LDS-DMA):
+//   registers hold the fragments of a whole 64-wide slice, double-buffered (set 0 = k32 step 0, set 1 = step 1), so the X / W
+//   halves of a buffer are dead half an iteration before the buffer's slice is finished and slice kt+2 is DMA'd over them:
+//     phase 1 (64 MFMAs on set 0): read set 1 of slice kt; barrier 1 -> X pieces of slice kt+2; barrier 2 -> W pieces
+//     phase 2 (64 MFMAs on set 1): remaining pieces; vmcnt(18) + barrier 3 -> read set 0 of slice kt+1 X; vmcnt(15) + barrier 4 -> W
+//   The 16 DMA pieces and 32 fragment reads of an iteration are issued one at a time BETWEEN MFMAs (sched_barrier pins the
+//   order), waits are counted (vmcnt never drains in the loop), the 4 barriers sit inside the MFMA stream.
+//
+// Persistent tile loop: block b walks tiles b, b + grid, ... (the same set of concurrently running tiles as a plain launch, so the
+// L2 sharing pattern of tile_of_block is unchanged).  Before the epilogue of a tile the first two K slices of the NEXT tile are
+// already in flight, the epilogue itself needs no block barrier (each wave stages 16-row strips of its own sub-tile through a
+// private 4 KB LDS scratch and stores whole 256-byte row segments), and a block never waits for its stores to be acknowledged
+// before the next tile starts (a plain launch pays that at s_endpgm with one block per CU).
+//
+// Roofline: MFMA-bound (2.5 PFLOP/s dense bf16/fp16).  Algorithmic FLOPs = 2*M*N*K.
+#pragma once
+#include "gemm_tile.h"
+
+struct W4Geom {
+    static constexpr int BN = 256, BM = 256, BK = 64, NT = 256, TN = 8, TM = 8, ROWB = 128;
+    static constexpr int STAGE_BYTES = (BN + BM) * ROWB, RING = 2 * STAGE_BYTES;
+    static constexpr int SCR_ROW = 128 * 2 + 16, SCR_BYTES = 16 * SCR_ROW;       // per-wave epilogue scratch: 16 rows x (128 cols + pad)
+    static constexpr int LDS_BYTES = RING + 4 * SCR_BYTES;
+};
+
+// compile-time epilogue shape of MODE_PLAIN (runtime flags made every strip a maze of scalar branches and put a vmcnt(0) —
+// i.e. a wait for the in-flight DMA and for all earlier stores — on the path without a residual): bias add, activation
+// (ACT_NONE / ACT_GELU_TANH / ACT_GELU_ERF), residual (0 none, 1 row m, 2 row m % rmod)
+template <bool BIAS, int ACT, int RES>
+struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; };
+
+template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, int WAITMODE = 0, typename LAB = LabNone>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
+    using G = W4Geom;
+    constexpr int BN = G::BN, BM = G::BM, BK = G::BK, NT = G::NT, TN = G::TN, TM = G::TM, ROWB = G::ROWB, STAGE_BYTES = G::STAGE_BYTES;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int l15 = lane & 15, hi = lane >> 4;
+    const int sw = swz(l15);
+    const int w_row_off = (wn * 128 + l15) * ROWB;
+    const int x_row_off = BN * ROWB + (wm * 128 + l15) * ROWB;
+    const int nk = p.K / BK;
+    const int tiles_1 = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    const int tiles = tiles_1 * batch;
+
+    unsigned long long t_acc[4] = {0, 0, 0, 0}, t_mark = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (LAB::stamps) { const unsigned long long t = __builtin_readcyclecounter(); t_acc[slot] += t - t_mark; t_mark = t; }
+    };
+    if constexpr (LAB::stamps) t_mark = __builtin_readcyclecounter();
+
+    // ---- per-tile state ------------------------------------------------------------------------
+    // DMA sources are buffer descriptors (SGPRs, rebuilt per tile by scalar code) + ONE tile-invariant per-lane offset per
+    // operand: piece j of a tile covers rows j*32 + (tid >> 3), and the swizzled source chunk cg = (tid & 7) ^ swz(row) does not
+    // depend on j, so  address = tile base + [(tid >> 3) * ld + cg * 8] (VGPR) + [k0 + j * 32 * ld] (SGPR).  Rows past the end
+    // of the matrix are out of the descriptor's range and read as zeros (they are masked in the epilogue anyway).
+    const int r0 = tid >> 3, cg0 = (tid & 7) ^ swz(r0);
+    const unsigned offW = (unsigned)(r0 * p.ldw + cg0 * 8) * 2u, offX = (unsigned)(r0 * p.ldx + cg0 * 8) * 2u;
+    __amdgpu_buffer_rsrc_t srdW, srdX;
+    int m0 = 0, n0 = 0, bz = 0;
+    auto make_srd = [&](const u16* base, int rows_left, int ld) {
+        // valid extent = (rows_left - 1) * ld + K elements (rows may overlap: ld < K is the conv-as-GEMM view)
+        const unsigned long long bytes = ((unsigned long long)(rows_left - 1) * (unsigned)ld + (unsigned)p.K) * 2ull;
+        const unsigned nrec = bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+    };
+    auto setup_tile = [&](int vb) {
+        const int b1 = vb % tiles_1;
+        bz = vb / tiles_1;
+        int tile_m, tile_n;
+        tile_of_block(p, BN, BM, b1, tiles_1, tile_m, tile_n);
+        n0 = tile_n * BN; m0 = tile_m * BM;
+        srdW = make_srd(p.W + (size_t)n0 * p.ldw, p.N - n0, p.ldw);
+        srdX = make_srd(p.X + (long long)bz * p.bsX + (size_t)m0 * p.ldx, p.M - m0, p.ldx);
+    };
+    // DMA piece q of K slice kt into buffer kt & 1: q < 8 -> X piece q, else W piece q - 8 (1 KB per wave each)
+    auto piece = [&](int kt, int q) {
+        if constexpr (LAB::no_dma) return;
+        char* sW = smem + (kt & 1) * STAGE_BYTES;
+        const int k0 = kt * BK;
+        if (q < 8) {
+            int kx = k0;
+            if constexpr (REPKV) kx = (k0 / (p.rep_g * p.rep_hd)) * p.rep_hd + (k0 % p.rep_hd);      // rep_hd % 64 == 0: the whole 64-wide slice maps together
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(sW + BN * ROWB + (q * NT + wave * 64) * 16), 16, offX,
+                                                     (unsigned)(kx + q * 32 * p.ldx) * 2u, 0, 0);
+        } else {
+            const int j = q - 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdW, (__attribute__((address_space(3))) void*)(sW + (j * NT + wave * 64) * 16), 16, offW,
+                                                     (unsigned)(k0 + j * 32 * p.ldw) * 2u, 0, 0);
+        }
+    };
+    auto issue_head = [&]() {                 // slices 0 and 1 of the current tile
+#pragma unroll
+        for (int q = 0; q < 16; ++q) piece(0, q);
+        if (nk > 1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) piece(1, q);
+        }
+    };
+    auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+    // accumulator element -> VGPR, exactly where it is written: the accumulators are asm operands pinned to the AGPR file, and
+    // for plain uses hipcc copies ALL 256 of them to VGPRs right after the K loop (256 live registers, spills) — seen in the .s
+    auto aread = [](float x) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x)); return v; };
+
+    f32x4 acc[TN][TM];                                   // written (not accumulated) by the first k32 step of every tile
+
+    u32x4 fW[2][TN], fX[2][TM];
+    auto rdW = [&](const char* buf, int a, int s) { return *(const u32x4*)(buf + w_row_off + a * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
+    auto rdX = [&](const char* buf, int b, int s) { return *(const u32x4*)(buf + x_row_off + b * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
+#define VIDI_PIN __builtin_amdgcn_sched_barrier(0)
+
+    auto body = [&](int kt, auto has2_t, auto has1_t, auto first_t) {
+        constexpr bool HAS2 = decltype(has2_t)::value;      // slice kt+2 exists: DMA it over slice kt's buffer
+        constexpr bool HAS1 = decltype(has1_t)::value;      // slice kt+1 exists: fetch its step-0 fragments
+        constexpr bool FIRST = decltype(first_t)::value;    // first slice of a tile: the step-0 MFMAs take C = 0 (no accumulator clearing)
+        const char* bufc = smem + (kt & 1) * STAGE_BYTES;
+        const char* bufn = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        VIDI_PIN;
+        // ---------------- phase 1: step-0 MFMAs ----------------
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int a = i >> 3, b = i & 7;
+            if constexpr (FIRST) T::mfma16_agpr_first(acc[a][b], fW[0][a], fX[0][b]);
+            else T::mfma16_agpr(acc[a][b], fW[0][a], fX[0][b]);
+            if (i < 16 && (i & 1) == 0) fX[1][i >> 1] = rdX(bufc, i >> 1, 1);                 // 8 X-fragment reads
+            if constexpr (HAS2) {
+                if (i == 19) wait_lgkm0();
+                if (i == 20) bar();                                                            // barrier 1: X part of bufc is dead
+                if (i >= 22 && i <= 38 && ((i - 22) & 3) == 0) piece(kt + 2, (i - 22) >> 2);   // X pieces 0..4
+            }
+            if (i >= 24 && i <= 40 && ((i - 24) & 3) == 0) fW[1][(i - 24) >> 2] = rdW(bufc, (i - 24) >> 2, 1);   // W reads 0..4
+            if (i == 42 || i == 44 || i == 46) fW[1][5 + ((i - 42) >> 1)] = rdW(bufc, 5 + ((i - 42) >> 1), 1); // W reads 5..7
+            if constexpr (HAS2) {
+                if (i == 51) wait_lgkm0();
+                if (i == 52) bar();                                                            // barrier 2: W part of bufc is dead
+                if (i == 53) piece(kt + 2, 5);
+                if (i == 56) piece(kt + 2, 6);
+                if (i == 58) piece(kt + 2, 7);
+                if (i == 61) piece(kt + 2, 8);
+            }
+            VIDI_PIN;
+        }
+        // ---------------- phase 2: step-1 MFMAs ----------------
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int a = i >> 3, b = i & 7;
+            T::mfma16_agpr(acc[a][b], fW[1][a], fX[1][b]);
+            if constexpr (HAS2) {
+                if (i == 1) piece(kt + 2, 9);
+                if (i == 21) piece(kt + 2, 10);
+                if (i == 23) piece(kt + 2, 11);
+                if (i == 25) piece(kt + 2, 12);
+                if (i == 32) piece(kt + 2, 13);
+                if (i == 36) piece(kt + 2, 14);
+                if (i == 60) piece(kt + 2, 15);
+            }
+            if constexpr (HAS1) {
+                // X part of slice kt+1: this iteration's 10 pieces + last iteration's 8 W pieces may stay in flight
+                if (i == 3) { if constexpr (LAB::no_dma) {} else if constexpr (HAS2) wait_vm<18>(); else wait_vm<8>(); }
+                if (i == 4) bar();                                                             // barrier 3: everybody's X pieces landed
+                if (i >= 5 && i <= 19 && ((i - 5) & 1) == 0) fX[0][(i - 5) >> 1] = rdX(bufn, (i - 5) >> 1, 0);
+                if (i == 40) { if constexpr (LAB::no_dma) {} else if constexpr (HAS2) wait_vm<15>(); else wait_vm<0>(); }
+                if (i == 41) bar();                                                            // barrier 4: W pieces landed
+                if (i >= 42 && i <= 56 && ((i - 42) & 1) == 0) fW[0][(i - 42) >> 1] = rdW(bufn, (i - 42) >> 1, 0);
+            }
+            VIDI_PIN;
+        }
+    };
+
+    // ---- epilogue of the tile at (em0, en0, ebz): strips of 16 rows through the wave's private scratch ----------------
+    char* scr = smem + G::RING + wave * G::SCR_BYTES;
+    constexpr bool act_tanh = (EPI::act == ACT_GELU_TANH), act_erf = (EPI::act == ACT_GELU_ERF);
+    const bool glu_silu = (p.act == ACT_SILU);
+    constexpr bool GLU = (MODE == MODE_GEGLU);
+    constexpr int SROW = GLU ? (64 * 2 + 16) : G::SCR_ROW;          // scratch row bytes
+    constexpr int NRD = GLU ? 2 : 4;                                 // 16-byte reads per lane per strip
+    constexpr int RPI = GLU ? 8 : 4;                                 // rows per read instruction
+    constexpr int CPRW = GLU ? 8 : 16;                               // 16-byte chunks per strip row
+    auto epilogue = [&](int em0, int en0, int ebz) {
+        u16* Yb = p.Y + (long long)ebz * p.bsY;
+        constexpr bool has_res = (MODE == MODE_PLAIN) && (EPI::res != 0);
+        const u16* Rb = has_res ? p.R + (long long)ebz * p.bsR : nullptr;
+        constexpr bool has_bias = !GLU && EPI::bias;                  // (QKV_VT always carries a bias in the callers: Epi<true, ...>)
+        constexpr bool wrap = (EPI::res == 2);
+        const int Nout = GLU ? (p.N >> 1) : p.N;
+        const int no0 = GLU ? (en0 >> 1) + wn * 64 : en0 + wn * 128;           // first output column of this wave's strips
+        u32x2 bq[TN];
+        if constexpr (has_bias) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) bq[a] = *(const u32x2*)(p.bias + min(en0 + wn * 128 + a * 16 + 4 * hi, p.N - 4));
+        }
+        const int rr = lane / CPRW, cc = lane % CPRW;                // this lane's (row in read group, chunk) of the read-back
+        const int n = no0 + cc * 8;                                  // this lane's output column in the read-back
+        // ---- registers -> scratch (lane: row l15, 4 consecutive columns per 16-column tile) ----
+        auto stage = [&](auto bt) {
+            constexpr int b = decltype(bt)::value;
+            const int mrow0 = em0 + wm * 128 + b * 16;               // first global row of the strip
+            if constexpr (GLU) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    if ((a >> 1) & 1) continue;                       // up tiles are consumed with their gate tile
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = rnd<T>(aread(acc[a][b][e]));
+                        const float u = rnd<T>(aread(acc[a + 2][b][e]));
+                        v[e] = rnd<T>(glu_silu ? silu_f(g) : gelu_tanh_f(g)) * u;
+                    }
+                    const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                    const int col = (a >> 2) * 32 + (a & 1) * 16 + 4 * hi;
+                    *(u32x2*)(scr + l15 * SROW + col * 2) = o;
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int nn = en0 + wn * 128 + a * 16 + 4 * hi;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = aread(acc[a][b][e]);
+                    if constexpr (has_bias) {
+                        const u32x2 bv = bq[a];
+                        v[0] += T::to_f32((u16)(bv[0] & 0xffff)); v[1] += T::to_f32((u16)(bv[0] >> 16));
+                        v[2] += T::to_f32((u16)(bv[1] & 0xffff)); v[3] += T::to_f32((u16)(bv[1] >> 16));
+                    }
+                    const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                    const int m = mrow0 + l15;
+                    if constexpr (MODE == MODE_QKV_VT) {
+                        if (nn >= p.vstart && nn < p.N && m < p.M) {    // V columns: transposed, perm16 key order (vidi_attn_self layout)
+                            const int c = nn - p.vstart, h = c / p.hd, d = c % p.hd;
+                            const int bi = m / p.seq, tok = m % p.seq;
+                            const int pos = (tok & ~15) | perm16(tok & 15);
+                            u16* dst = p.Vt + (((size_t)bi * p.nheads + h) * p.hd + d) * p.seqpad + pos;
+                            dst[0] = (u16)(o[0] & 0xffff); dst[(size_t)p.seqpad] = (u16)(o[0] >> 16);
+                            dst[2 * (size_t)p.seqpad] = (u16)(o[1] & 0xffff); dst[3 * (size_t)p.seqpad] = (u16)(o[1] >> 16);
+                        }
+                    } else if constexpr (MODE == MODE_KV_CACHE) {
+                        if (nn >= p.kvd && nn < p.N && m < p.M) {       // V: also the transposed, perm16 32-key sub-tile image
+                            const int tok = p.tok0 + m, tile = tok >> 5, tk = tok & 31;
+                            const int c = nn - p.kvd, kvh = c / p.hd, d = c % p.hd;
+                            const int pos = (tk & ~15) | perm16(tk & 15);
+                            u16* dst = p.Vtc + (((size_t)kvh * p.ntile64 * 2 + tile) * p.hd + d) * 32 + pos;
+                            dst[0] = (u16)(o[0] & 0xffff); dst[32] = (u16)(o[0] >> 16);
+                            dst[64] = (u16)(o[1] & 0xffff); dst[96] = (u16)(o[1] >> 16);
+                        }
+                    }
+                    *(u32x2*)(scr + l15 * SROW + (a * 16 + 4 * hi) * 2) = o;
+                }
+            }
+        };
+        // ---- scratch -> registers: whole 16-byte chunks; a row segment of the strip is contiguous.  LDS operations of one wave
+        //      execute in order: these reads see the strip's writes, and the NEXT strip's writes (issued after them) come later ----
+        u32x4 val[NRD], res[NRD];
+        auto fetch = [&](int b) {
+            const int mrow0 = em0 + wm * 128 + b * 16;
+#pragma unroll
+            for (int j = 0; j < NRD; ++j) {
+                const int r = j * RPI + rr;
+                val[j] = *(const u32x4*)(scr + r * SROW + cc * 16);
+                if constexpr (has_res) {
+                    const int mc = min(mrow0 + r, p.M - 1), mr = wrap ? mc % p.rmod : mc;
+                    res[j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
+                }
+            }
+        };
+        auto store = [&](int b) {
+            const int mrow0 = em0 + wm * 128 + b * 16;
+#pragma unroll
+            for (int j = 0; j < NRD; ++j) {
+                const int m = mrow0 + j * RPI + rr;
+                bool ok = (m < p.M) && (n < Nout);
+                if constexpr (MODE == MODE_QKV_VT) ok = ok && (n < p.vstart);
+                if constexpr (LAB::no_store) ok = ok && (p.M < 0);
+                if (!ok) continue;
+                if constexpr (MODE == MODE_KV_CACHE) {
+                    if (n < p.kvd) {
+                        const int tok = p.tok0 + m, kvh = n / p.hd, d = n % p.hd;
+                        *(u32x4*)(p.Kc + ((size_t)kvh * p.ntile64 * 64 + tok) * p.hd + d) = val[j];
+                    } else {
+                        *(u32x4*)(p.Vrow + (size_t)m * p.kvd + (n - p.kvd)) = val[j];
+                    }
+                } else {
+                    u32x4 v = val[j];
+                    if constexpr (MODE == MODE_PLAIN) {
+                        // the activation runs on the T-rounded staged values (same arithmetic as rounding first, then activating)
+                        if constexpr (act_tanh) {
+                            float x[8];
+                            unpack8<T>(v, x);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] = gelu_tanh_f(x[e]);
+                            v = pack8<T>(x);
+                        } else if constexpr (act_erf) {
+                            float x[8];
+                            unpack8<T>(v, x);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] = gelu_erf_f(x[e]);
+                            v = pack8<T>(x);
+                        }
+                        if constexpr (has_res) {
+                            float x[8], r[8];
+                            unpack8<T>(v, x);
+                            unpack8<T>(res[j], r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
+                            v = pack8<T>(x);
+                        }
+                    }
+                    *(u32x4*)(Yb + (size_t)m * p.ldy + n) = v;
+                }
+            }
+        };
+        // software pipeline over the 8 strips: the next strip's registers -> scratch pass is issued between a strip's reads and
+        // the stores that consume them (sched_barrier pins the groups; LDS order makes the single scratch buffer safe)
+        auto step = [&](auto bt) {
+            constexpr int b = decltype(bt)::value;
+            VIDI_PIN;
+            fetch(b);
+            VIDI_PIN;
+            if constexpr (b + 1 < TM) stage(std::integral_constant<int, b + 1>{});
+            VIDI_PIN;
+            store(b);
+            VIDI_PIN;
+        };
+        stage(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    };
+
+    // =========================================== tile loop ===========================================
+    int vb = blockIdx.x;
+    setup_tile(vb);
+    issue_head();
+    bool first = true;
+    while (true) {
+        // slice 0 of this tile must have landed (slice 1 may stay in flight).  After a previous tile's epilogue the vector-memory
+        // queue also holds that tile's stores, issued AFTER the 32 head pieces: WAITMODE 0 drains everything (stores included),
+        // WAITMODE 1 counts (loads and stores retire in issue order on gfx9-class counters): 16 pieces + up to 32 stores stay in flight
+        if constexpr (LAB::no_dma) {
+        } else if (first || WAITMODE == 0 || MODE == MODE_QKV_VT || MODE == MODE_KV_CACHE) {
+            if (nk > 1 && first) wait_vm<16>(); else wait_vm<0>();
+        } else {
+            if (nk > 1) wait_vm<48>(); else wait_vm<32>();
+        }
+        bar();
+#pragma unroll
+        for (int b = 0; b < TM; ++b) fX[0][b] = rdX(smem, b, 0);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) fW[0][a] = rdW(smem, a, 0);
+        stamp(0);
+        using TT = std::true_type; using FF = std::false_type;
+        if (nk >= 3) {
+            body(0, TT{}, TT{}, TT{});
+            int kt = 1;
+            for (; kt + 2 < nk; ++kt) body(kt, TT{}, TT{}, FF{});
+            body(kt, FF{}, TT{}, FF{});
+            body(kt + 1, FF{}, FF{}, FF{});
+        } else if (nk == 2) {
+            body(0, FF{}, TT{}, TT{});
+            body(1, FF{}, FF{}, FF{});
+        } else {
+            body(0, FF{}, FF{}, TT{});
+        }
+        // the MFMAs are asm statements: hipcc does not pad the MFMA-result -> reader hazard for them (12 wait states)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        stamp(1);
+        const int em0 = m0, en0 = n0, ebz = bz;
+        const int nvb = vb + gridDim.x;
+        const bool has_next = PERSIST && nvb < tiles;
+        if (has_next) {
+            bar();                                  // every wave is done reading the ring
+            setup_tile(nvb);
+            issue_head();
+        }
+        stamp(2);
+        if constexpr (LAB::no_epilogue) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) asm volatile("" ::"a"(acc[a][b]));
+        } else {
+            epilogue(em0, en0, ebz);
+        }
+        stamp(3);
+        if (!has_next) break;
+        vb = nvb;
+        first = false;
+    }
+#undef VIDI_PIN
+    if constexpr (LAB::stamps) {
+        if (p.dbg && tid == 0 && blockIdx.x < 1024) {
+            unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
+            d[0] = t_acc[0]; d[1] = t_acc[1]; d[2] = t_acc[2]; d[3] = t_acc[3]; d[4] = 1;
+        }
+    }
+}

@@ -25,7 +25,8 @@ struct GemmParams {
     long long bsX, bsY, bsR;      // batch strides (elements); W/bias shared across the batch
     int act, rmod;
     int group_m;                  // m-tiles per scheduling group (L2 reuse shape)
-    int diag;                     // timing diagnostic (VIDI_GEMM_EXPERIMENTAL + VIDI_GEMM_DIAG=2): skip the epilogue
+    int order;                    // block -> tile order: 0 = per-XCD contiguous ranges, 1 = the 8 XCDs sweep adjacent groups (gemm_tile.h)
+    unsigned long long* dbg;      // tools/lab builds only (phase time stamps); null in the product
     int rep_hd, rep_g;            // REPKV: logical k -> physical column (k/(g*hd))*hd + k%hd
     // MODE_QKV_VT: columns >= vstart go to Vt[b][h][d][seqpad] (key order permuted per 16-slab)
     int vstart, hd, seq, seqpad, nheads; u16* Vt;
