@@ -60,9 +60,9 @@ static int lab_launch(const GemmParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <typename T, int MODE, bool PERSIST, int WAITMODE, typename LAB>
+template <typename T, int MODE, bool PERSIST, typename LAB, typename EPI = Epi<false, ACT_NONE, 0>>
 static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
-    auto kern = gemm_w4_kernel<T, MODE, false, PERSIST, Epi<false, ACT_NONE, 0>, WAITMODE, LAB>;
+    auto kern = gemm_w4_kernel<T, MODE, false, PERSIST, EPI, LAB>;
     static bool done = false;
     if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, W4Geom::LDS_BYTES)); done = true; }
     const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
@@ -71,10 +71,10 @@ static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; };
+struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; };   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh)
 
 #define LATE(MODE, LAB) lab_launch<BF16, 256, 256, 2, 4, 2, MODE, false, SCHED_LATE, 16, LAB>
-#define W4(MODE, PERSIST, WAITMODE, LAB) lab_launch_w4<BF16, MODE, PERSIST, WAITMODE, LAB>
+#define W4(MODE, PERSIST, WAITMODE, LAB) lab_launch_w4<BF16, MODE, PERSIST, LAB>
 
 static std::vector<Variant> variants() {
     return {
@@ -93,6 +93,10 @@ static std::vector<Variant> variants() {
         {"w4p_nostore", W4(MODE_PLAIN, true, 0, LabNoStore), MODE_PLAIN, false, 0, 4},
         {"late_stamps", LATE(MODE_PLAIN, LabStamps), MODE_PLAIN, true, 0, 4},
         {"w4p_stamps", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 0, 4},
+        {"late_br", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 1},
+        {"w4p_br", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 0, 4, 1},
+        {"late_bt", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 2},
+        {"w4p_bt", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_TANH, 0>>, MODE_PLAIN, true, 0, 4, 2},
         {"late_geglu", LATE(MODE_GEGLU, LabNone), MODE_GEGLU, true, 0, 4},
         {"w4p_geglu", W4(MODE_GEGLU, true, 0, LabNone), MODE_GEGLU, true, 0, 4},
     };
@@ -115,6 +119,7 @@ int main(int argc, char** argv) {
     else if (set == "diag") want = {"late", "w4p", "w4p_nodma", "w4p_noepi", "w4p_nostore"};
     else if (set == "stamps") want = {"late_stamps", "w4p_stamps"};
     else if (set == "geglu") want = {"late_geglu", "w4p_geglu"};
+    else if (set == "epi") want = {"late", "w4p", "w4pc", "late_br", "w4p_br", "late_bt", "w4p_bt", "late_geglu", "w4p_geglu"};
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
     else if (set == "store") want = {};
     else { want = {set}; }
@@ -147,14 +152,16 @@ int main(int argc, char** argv) {
     for (const Shape& sh : shapes) {
         if (only && strcmp(only, sh.name)) continue;
         if (want.empty()) break;
-        u16 *X, *W, *Y;
+        u16 *X, *W, *Y, *R, *Bv;
         const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
-        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2));
+        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2)); CK(hipMalloc(&R, ny * 2)); CK(hipMalloc(&Bv, (size_t)sh.N * 2));
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, R, ny, 0x5555u, 1.0f, zero);
+        hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, Bv, (size_t)sh.N, 0x7777u, 0.5f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, nx, 0x1234u, 1.7f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 0x9876u, 0.035f, zero);
         CK(hipDeviceSynchronize());
-        unsigned long long ref[4][2] = {};
-        bool have_ref[4] = {false, false, false, false};
+        unsigned long long ref[16][2] = {};
+        bool have_ref[16] = {};
         for (const std::string& wn : want) {
             const Variant* v = nullptr;
             for (auto& c : vs) if (wn == c.name) v = &c;
@@ -164,6 +171,8 @@ int main(int argc, char** argv) {
             p.X = X; p.W = W; p.Y = Y; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.ldx = sh.K; p.ldw = sh.K;
             p.ldy = v->mode == MODE_GEGLU ? sh.N / 2 : sh.N; p.rmod = 0x7fffffff; p.group_m = v->group_m; p.order = v->order; p.act = ACT_GELU_TANH * (v->mode == MODE_GEGLU);
             p.dbg = dbg;
+            if (v->epi == 1) { p.bias = Bv; p.R = R; p.ldr = sh.N; }
+            if (v->epi == 2) { p.bias = Bv; p.act = ACT_GELU_TANH; }
             CK(hipMemset(Y, 0xff, ny * 2));
             CK(hipMemset(dbg, 0, 1024 * 64));
             int rc = v->fn(p, 0);
@@ -180,7 +189,7 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
             const char* verdict = "n/a";
             if (v->correct) {
-                const int md = v->mode;
+                const int md = v->mode * 4 + v->epi;
                 if (!have_ref[md]) { ref[md][0] = cs[0]; ref[md][1] = cs[1]; have_ref[md] = true; verdict = "ref"; }
                 else verdict = (cs[0] == ref[md][0] && cs[1] == ref[md][1]) ? "bit-identical" : "MISMATCH";
             }
@@ -203,7 +212,7 @@ int main(int argc, char** argv) {
             }
             fflush(stdout);
         }
-        CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y));
+        CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y)); CK(hipFree(R)); CK(hipFree(Bv));
     }
     return 0;
 }

@@ -280,7 +280,7 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t st) {
 // persistent 4-wave kernel (gemm_w4.h); VIDI_W4_UNSUPPORTED when this epilogue combination is not instantiated
 template <typename T, int MODE, bool REPKV>
 static int launch_w4_any(const GemmParams& p, int batch, hipStream_t st) {
-    if (p.K % 64 || (REPKV && (p.rep_hd % 64))) return VIDI_W4_UNSUPPORTED;
+    if (p.K % 64 || p.K < 192 || (REPKV && (p.rep_hd % 64))) return VIDI_W4_UNSUPPORTED;      // the K loop needs >= 3 slices
     if constexpr (MODE == MODE_PLAIN) {
         if constexpr (T::id == VIDI_DT_BF16) return vidi_w4_plain_bf16(p, batch, REPKV ? 1 : 0, st);
         else return vidi_w4_plain_f16(p, batch, REPKV ? 1 : 0, st);

@@ -16,10 +16,12 @@
 //   order), waits are counted (vmcnt never drains in the loop), the 4 barriers sit inside the MFMA stream.
 //
 // Persistent tile loop: block b walks tiles b, b + grid, ... (the same set of concurrently running tiles as a plain launch, so the
-// L2 sharing pattern of tile_of_block is unchanged).  Before the epilogue of a tile the first two K slices of the NEXT tile are
-// already in flight, the epilogue itself needs no block barrier (each wave stages 16-row strips of its own sub-tile through a
-// private 4 KB LDS scratch and stores whole 256-byte row segments), and a block never waits for its stores to be acknowledged
-// before the next tile starts (a plain launch pays that at s_endpgm with one block per CU).
+// L2 sharing pattern of tile_of_block is unchanged).  To the K loop the next tile's first two slices are simply slices nk and
+// nk + 1: the last two iterations of a tile DMA them (under MFMA cover, over the buffers they free) and the last iteration
+// already fetches the next tile's first fragments, so a tile starts its MFMAs right after the previous epilogue — no head
+// burst, no wait, no barrier.  The epilogue needs no block barrier (each wave stages 16-row strips of its own sub-tile through
+// a private 4 KB LDS scratch and stores whole 256-byte row segments), and a block never waits for its stores to be
+// acknowledged before the next tile starts (a plain launch pays that at s_endpgm with one block per CU).  K >= 192.
 //
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16/fp16).  Algorithmic FLOPs = 2*M*N*K.
 #pragma once
@@ -38,7 +40,7 @@ struct W4Geom {
 template <bool BIAS, int ACT, int RES>
 struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; };
 
-template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, int WAITMODE = 0, typename LAB = LabNone>
+template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     using G = W4Geom;
     constexpr int BN = G::BN, BM = G::BM, BK = G::BK, NT = G::NT, TN = G::TN, TM = G::TM, ROWB = G::ROWB, STAGE_BYTES = G::STAGE_BYTES;
@@ -70,45 +72,37 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     // of the matrix are out of the descriptor's range and read as zeros (they are masked in the epilogue anyway).
     const int r0 = tid >> 3, cg0 = (tid & 7) ^ swz(r0);
     const unsigned offW = (unsigned)(r0 * p.ldw + cg0 * 8) * 2u, offX = (unsigned)(r0 * p.ldx + cg0 * 8) * 2u;
-    __amdgpu_buffer_rsrc_t srdW, srdX;
-    int m0 = 0, n0 = 0, bz = 0;
+    __amdgpu_buffer_rsrc_t srdW, srdX, srdWn, srdXn;      // current tile / next tile
+    int m0 = 0, n0 = 0, bz = 0, nm0 = 0, nn0 = 0, nbz = 0;
+    int pb = 0;                                             // LDS buffer of the current tile's slice 0 (slice kt lives in buffer (pb + kt) & 1)
     auto make_srd = [&](const u16* base, int rows_left, int ld) {
         // valid extent = (rows_left - 1) * ld + K elements (rows may overlap: ld < K is the conv-as-GEMM view)
         const unsigned long long bytes = ((unsigned long long)(rows_left - 1) * (unsigned)ld + (unsigned)p.K) * 2ull;
         const unsigned nrec = bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes;
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
     };
-    auto setup_tile = [&](int vb) {
+    auto locate = [&](int vb, int& tm0, int& tn0, int& tbz) {
         const int b1 = vb % tiles_1;
-        bz = vb / tiles_1;
+        tbz = vb / tiles_1;
         int tile_m, tile_n;
         tile_of_block(p, BN, BM, b1, tiles_1, tile_m, tile_n);
-        n0 = tile_n * BN; m0 = tile_m * BM;
-        srdW = make_srd(p.W + (size_t)n0 * p.ldw, p.N - n0, p.ldw);
-        srdX = make_srd(p.X + (long long)bz * p.bsX + (size_t)m0 * p.ldx, p.M - m0, p.ldx);
+        tn0 = tile_n * BN; tm0 = tile_m * BM;
     };
-    // DMA piece q of K slice kt into buffer kt & 1: q < 8 -> X piece q, else W piece q - 8 (1 KB per wave each)
-    auto piece = [&](int kt, int q) {
+    // DMA piece q of K slice `ks` (of the current tile, or of the next one when NEXT) into `buf`: q < 8 -> X piece q, else W piece
+    // q - 8 (1 KB per wave each)
+    auto piece = [&](char* buf, int ks, int q, auto next_t) {
         if constexpr (LAB::no_dma) return;
-        char* sW = smem + (kt & 1) * STAGE_BYTES;
-        const int k0 = kt * BK;
+        constexpr bool NEXT = decltype(next_t)::value;
+        const int k0 = ks * BK;
         if (q < 8) {
             int kx = k0;
             if constexpr (REPKV) kx = (k0 / (p.rep_g * p.rep_hd)) * p.rep_hd + (k0 % p.rep_hd);      // rep_hd % 64 == 0: the whole 64-wide slice maps together
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(sW + BN * ROWB + (q * NT + wave * 64) * 16), 16, offX,
-                                                     (unsigned)(kx + q * 32 * p.ldx) * 2u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(NEXT ? srdXn : srdX, (__attribute__((address_space(3))) void*)(buf + BN * ROWB + (q * NT + wave * 64) * 16), 16,
+                                                     offX, (unsigned)(kx + q * 32 * p.ldx) * 2u, 0, 0);
         } else {
             const int j = q - 8;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdW, (__attribute__((address_space(3))) void*)(sW + (j * NT + wave * 64) * 16), 16, offW,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(NEXT ? srdWn : srdW, (__attribute__((address_space(3))) void*)(buf + (j * NT + wave * 64) * 16), 16, offW,
                                                      (unsigned)(k0 + j * 32 * p.ldw) * 2u, 0, 0);
-        }
-    };
-    auto issue_head = [&]() {                 // slices 0 and 1 of the current tile
-#pragma unroll
-        for (int q = 0; q < 16; ++q) piece(0, q);
-        if (nk > 1) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) piece(1, q);
         }
     };
     auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
@@ -123,12 +117,21 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     auto rdX = [&](const char* buf, int b, int s) { return *(const u32x4*)(buf + x_row_off + b * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
 #define VIDI_PIN __builtin_amdgcn_sched_barrier(0)
 
-    auto body = [&](int kt, auto has2_t, auto has1_t, auto first_t) {
-        constexpr bool HAS2 = decltype(has2_t)::value;      // slice kt+2 exists: DMA it over slice kt's buffer
-        constexpr bool HAS1 = decltype(has1_t)::value;      // slice kt+1 exists: fetch its step-0 fragments
-        constexpr bool FIRST = decltype(first_t)::value;    // first slice of a tile: the step-0 MFMAs take C = 0 (no accumulator clearing)
-        const char* bufc = smem + (kt & 1) * STAGE_BYTES;
-        const char* bufn = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    // one K iteration: 128 MFMAs on slice kt; slice kt+1's step-0 fragments are fetched and slice kt+2 is DMA'd over slice kt's
+    // buffer.  FIRST: first slice of a tile, the step-0 MFMAs take C = 0 (no accumulator clearing).  NEXT: the last two iterations
+    // of a tile — slices kt+1 / kt+2 are the NEXT tile's (slice kt+2-nk of its operands), issued only when `more` (a next tile
+    // exists); without one the iteration still runs the same instruction stream (fragment reads of stale LDS, never used):
+    // any control-flow merge over the 64 asm-pinned accumulators makes hipcc spill hundreds of registers
+    auto body = [&](int kt, auto first_t, auto next_t, bool more) {
+        constexpr bool FIRST = decltype(first_t)::value, NEXT = decltype(next_t)::value;
+        constexpr bool HAS2 = true, HAS1 = true;
+        char* bufc = smem + ((pb + kt) & 1) * STAGE_BYTES;
+        const char* bufn = smem + ((pb + kt + 1) & 1) * STAGE_BYTES;
+        const int ks2 = NEXT ? kt + 2 - nk : kt + 2;         // slice index (in its own tile) of the slice DMA'd this iteration
+        auto dma = [&](int q) {
+            if constexpr (NEXT) { if (more) piece(bufc, ks2, q, next_t); }
+            else piece(bufc, ks2, q, next_t);
+        };
         VIDI_PIN;
         // ---------------- phase 1: step-0 MFMAs ----------------
 #pragma unroll
@@ -140,17 +143,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             if constexpr (HAS2) {
                 if (i == 19) wait_lgkm0();
                 if (i == 20) bar();                                                            // barrier 1: X part of bufc is dead
-                if (i >= 22 && i <= 38 && ((i - 22) & 3) == 0) piece(kt + 2, (i - 22) >> 2);   // X pieces 0..4
+                if (i >= 22 && i <= 38 && ((i - 22) & 3) == 0) dma((i - 22) >> 2);   // X pieces 0..4
             }
             if (i >= 24 && i <= 40 && ((i - 24) & 3) == 0) fW[1][(i - 24) >> 2] = rdW(bufc, (i - 24) >> 2, 1);   // W reads 0..4
             if (i == 42 || i == 44 || i == 46) fW[1][5 + ((i - 42) >> 1)] = rdW(bufc, 5 + ((i - 42) >> 1), 1); // W reads 5..7
             if constexpr (HAS2) {
                 if (i == 51) wait_lgkm0();
                 if (i == 52) bar();                                                            // barrier 2: W part of bufc is dead
-                if (i == 53) piece(kt + 2, 5);
-                if (i == 56) piece(kt + 2, 6);
-                if (i == 58) piece(kt + 2, 7);
-                if (i == 61) piece(kt + 2, 8);
+                if (i == 53) dma(5);
+                if (i == 56) dma(6);
+                if (i == 58) dma(7);
+                if (i == 61) dma(8);
             }
             VIDI_PIN;
         }
@@ -160,20 +163,20 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             const int a = i >> 3, b = i & 7;
             T::mfma16_agpr(acc[a][b], fW[1][a], fX[1][b]);
             if constexpr (HAS2) {
-                if (i == 1) piece(kt + 2, 9);
-                if (i == 21) piece(kt + 2, 10);
-                if (i == 23) piece(kt + 2, 11);
-                if (i == 25) piece(kt + 2, 12);
-                if (i == 32) piece(kt + 2, 13);
-                if (i == 36) piece(kt + 2, 14);
-                if (i == 60) piece(kt + 2, 15);
+                if (i == 1) dma(9);
+                if (i == 21) dma(10);
+                if (i == 23) dma(11);
+                if (i == 25) dma(12);
+                if (i == 32) dma(13);
+                if (i == 36) dma(14);
+                if (i == 60) dma(15);
             }
             if constexpr (HAS1) {
                 // X part of slice kt+1: this iteration's 10 pieces + last iteration's 8 W pieces may stay in flight
-                if (i == 3) { if constexpr (LAB::no_dma) {} else if constexpr (HAS2) wait_vm<18>(); else wait_vm<8>(); }
+                if (i == 3) { if constexpr (LAB::no_dma) {} else if (!NEXT || more) wait_vm<18>(); else wait_vm<8>(); }
                 if (i == 4) bar();                                                             // barrier 3: everybody's X pieces landed
                 if (i >= 5 && i <= 19 && ((i - 5) & 1) == 0) fX[0][(i - 5) >> 1] = rdX(bufn, (i - 5) >> 1, 0);
-                if (i == 40) { if constexpr (LAB::no_dma) {} else if constexpr (HAS2) wait_vm<15>(); else wait_vm<0>(); }
+                if (i == 40) { if constexpr (LAB::no_dma) {} else if (!NEXT || more) wait_vm<15>(); else wait_vm<0>(); }
                 if (i == 41) bar();                                                            // barrier 4: W pieces landed
                 if (i >= 42 && i <= 56 && ((i - 42) & 1) == 0) fW[0][(i - 42) >> 1] = rdW(bufn, (i - 42) >> 1, 0);
             }
@@ -263,18 +266,25 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         };
         // ---- scratch -> registers: whole 16-byte chunks; a row segment of the strip is contiguous.  LDS operations of one wave
         //      execute in order: these reads see the strip's writes, and the NEXT strip's writes (issued after them) come later ----
-        u32x4 val[NRD], res[NRD];
-        auto fetch = [&](int b) {
-            const int mrow0 = em0 + wm * 128 + b * 16;
+        // residual chunks are requested two strips ahead (3-deep register ring, strips 0 and 1 before the first store): vector
+        // memory operations retire in issue order, so a load issued right before its use would first wait for the stores of the
+        // strips before it to be acknowledged
+        u32x4 val[NRD], res[has_res ? 3 : 1][NRD];
+        auto load_res = [&](auto bt) {
+            constexpr int b = decltype(bt)::value;
+            if constexpr (has_res && b < TM) {
 #pragma unroll
-            for (int j = 0; j < NRD; ++j) {
-                const int r = j * RPI + rr;
-                val[j] = *(const u32x4*)(scr + r * SROW + cc * 16);
-                if constexpr (has_res) {
-                    const int mc = min(mrow0 + r, p.M - 1), mr = wrap ? mc % p.rmod : mc;
-                    res[j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
+                for (int j = 0; j < NRD; ++j) {
+                    const int mc = min(em0 + wm * 128 + b * 16 + j * RPI + rr, p.M - 1), mr = wrap ? mc % p.rmod : mc;
+                    res[b % 3][j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
                 }
             }
+        };
+        load_res(std::integral_constant<int, 0>{});
+        load_res(std::integral_constant<int, 1>{});
+        auto fetch = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < NRD; ++j) val[j] = *(const u32x4*)(scr + (j * RPI + rr) * SROW + cc * 16);
         };
         auto store = [&](int b) {
             const int mrow0 = em0 + wm * 128 + b * 16;
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                         if constexpr (has_res) {
                             float x[8], r[8];
                             unpack8<T>(v, x);
-                            unpack8<T>(res[j], r);
+                            unpack8<T>(res[has_res ? b % 3 : 0][j], r);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
                             v = pack8<T>(x);
@@ -324,10 +334,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         };
         // software pipeline over the 8 strips: the next strip's registers -> scratch pass is issued between a strip's reads and
         // the stores that consume them (sched_barrier pins the groups; LDS order makes the single scratch buffer safe)
+        // software pipeline over the 8 strips: the next strip's registers -> scratch pass is issued between a strip's reads and
+        // the stores that consume them (sched_barrier pins the groups; LDS order makes the single scratch buffer safe)
         auto step = [&](auto bt) {
             constexpr int b = decltype(bt)::value;
             VIDI_PIN;
             fetch(b);
+            load_res(std::integral_constant<int, b + 2>{});
             VIDI_PIN;
             if constexpr (b + 1 < TM) stage(std::integral_constant<int, b + 1>{});
             VIDI_PIN;
@@ -341,63 +354,51 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     };
 
     // =========================================== tile loop ===========================================
+    using TT = std::true_type; using FF = std::false_type;
     int vb = blockIdx.x;
-    setup_tile(vb);
-    issue_head();
-    bool first = true;
+    locate(vb, m0, n0, bz);
+    srdW = make_srd(p.W + (size_t)n0 * p.ldw, p.N - n0, p.ldw);
+    srdX = make_srd(p.X + (long long)bz * p.bsX + (size_t)m0 * p.ldx, p.M - m0, p.ldx);
+    // head of the block's first tile: slices 0 and 1 in flight, slice 0 landed, its step-0 fragments in registers
+#pragma unroll
+    for (int q = 0; q < 16; ++q) piece(smem, 0, q, FF{});
+#pragma unroll
+    for (int q = 0; q < 16; ++q) piece(smem + STAGE_BYTES, 1, q, FF{});
+    if constexpr (!LAB::no_dma) wait_vm<16>();
+    bar();
+#pragma unroll
+    for (int b = 0; b < TM; ++b) fX[0][b] = rdX(smem, b, 0);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) fW[0][a] = rdW(smem, a, 0);
+    stamp(0);
     while (true) {
-        // slice 0 of this tile must have landed (slice 1 may stay in flight).  After a previous tile's epilogue the vector-memory
-        // queue also holds that tile's stores, issued AFTER the 32 head pieces: WAITMODE 0 drains everything (stores included),
-        // WAITMODE 1 counts (loads and stores retire in issue order on gfx9-class counters): 16 pieces + up to 32 stores stay in flight
-        if constexpr (LAB::no_dma) {
-        } else if (first || WAITMODE == 0 || MODE == MODE_QKV_VT || MODE == MODE_KV_CACHE) {
-            if (nk > 1 && first) wait_vm<16>(); else wait_vm<0>();
-        } else {
-            if (nk > 1) wait_vm<48>(); else wait_vm<32>();
-        }
-        bar();
-#pragma unroll
-        for (int b = 0; b < TM; ++b) fX[0][b] = rdX(smem, b, 0);
-#pragma unroll
-        for (int a = 0; a < TN; ++a) fW[0][a] = rdW(smem, a, 0);
-        stamp(0);
-        using TT = std::true_type; using FF = std::false_type;
-        if (nk >= 3) {
-            body(0, TT{}, TT{}, TT{});
-            int kt = 1;
-            for (; kt + 2 < nk; ++kt) body(kt, TT{}, TT{}, FF{});
-            body(kt, FF{}, TT{}, FF{});
-            body(kt + 1, FF{}, FF{}, FF{});
-        } else if (nk == 2) {
-            body(0, FF{}, TT{}, TT{});
-            body(1, FF{}, FF{}, FF{});
-        } else {
-            body(0, FF{}, FF{}, TT{});
-        }
-        // the MFMAs are asm statements: hipcc does not pad the MFMA-result -> reader hazard for them (12 wait states)
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        stamp(1);
-        const int em0 = m0, en0 = n0, ebz = bz;
         const int nvb = vb + gridDim.x;
         const bool has_next = PERSIST && nvb < tiles;
         if (has_next) {
-            bar();                                  // every wave is done reading the ring
-            setup_tile(nvb);
-            issue_head();
+            locate(nvb, nm0, nn0, nbz);
+            srdWn = make_srd(p.W + (size_t)nn0 * p.ldw, p.N - nn0, p.ldw);
+            srdXn = make_srd(p.X + (long long)nbz * p.bsX + (size_t)nm0 * p.ldx, p.M - nm0, p.ldx);
         }
-        stamp(2);
+        body(0, TT{}, FF{}, true);
+        int kt = 1;
+        for (; kt + 2 < nk; ++kt) body(kt, FF{}, FF{}, true);
+        body(kt, FF{}, TT{}, has_next);             // the next tile's slices 0, 1 are this K loop's slices nk, nk + 1
+        body(kt + 1, FF{}, TT{}, has_next);
+        // the MFMAs are asm statements: hipcc does not pad the MFMA-result -> reader hazard for them (12 wait states)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        stamp(1);
         if constexpr (LAB::no_epilogue) {
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b) asm volatile("" ::"a"(acc[a][b]));
         } else {
-            epilogue(em0, en0, ebz);
+            epilogue(m0, n0, bz);
         }
         stamp(3);
         if (!has_next) break;
-        vb = nvb;
-        first = false;
+        vb = nvb; m0 = nm0; n0 = nn0; bz = nbz; srdW = srdWn; srdX = srdXn;
+        pb = (pb + nk) & 1;
     }
 #undef VIDI_PIN
     if constexpr (LAB::stamps) {

@@ -7,7 +7,7 @@
 
 template <typename T, int MODE, bool REPKV, typename EPI>
 static int launch_w4(const GemmParams& p, int batch, hipStream_t st) {
-    auto kern = gemm_w4_kernel<T, MODE, REPKV, true, EPI, 0, LabNone>;
+    auto kern = gemm_w4_kernel<T, MODE, REPKV, true, EPI, LabNone>;
     static bool attr_done = false;
     static int ncu = 0;
     if (!attr_done) {
