@@ -1,0 +1,74 @@
+"""Test infrastructure: an object with VidiEngine's interface whose numerics are the CPU oracle (oracle/vidi_oracle.py).
+
+`vidi_amd.model.VidiForCausalLM(..., engine=OracleEngine(...))` lets the host logic of the product class — `generate()`'s greedy
+loop, EOS / padding handling, batching, `forward`, `encode_videos`, `prepare_inputs_labels_for_multimodal` — run in a container
+without a GPU, e.g. under the reference's own CLI (`tests/test_reference_cli.py`).  It is never used by the product: the product
+engine is `vidi_amd.engine.VidiEngine` (HIP kernels only, no CPU path)."""
+import dataclasses
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+import vidi_oracle as O
+
+
+def oracle_config(cfg) -> "O.OracleConfig":
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    d = {k: v for k, v in cfg.to_dict().items() if k in names}
+    d["arch"] = cfg.arch                                             # a property of VidiConfig (from model_type), a field of OracleConfig
+    return O.OracleConfig(**d, vis_select_layer=cfg.mm_vision_select_layer)
+
+
+class OracleEngine:
+    """embed_tokens / encode_* return UN-normalised rows; `O.model_forward` applies the sqrt(H) normalizer itself (gemma.py:353-356).
+    model.py treats these tensors as opaque, so the division of labour between the methods is the engine's business."""
+
+    def __init__(self, cfg, weights, dtype=torch.float32):
+        self.cfg, self.ocfg = cfg, oracle_config(cfg)
+        self.w = {k: v.float() for k, v in weights.items()}
+        self.dtype, self.dev = torch.float32, torch.device("cpu")
+        self.mistral = cfg.arch == "mistral"
+        self.normalizer = 1.0
+        self.world, self.rank, self.pg = 1, 0, None
+
+    # ---- multimodal encode ----
+    def encode_video_images(self, pixel, normalizer=None, **kw):
+        f, m = O.encode_video_images([pixel.float().cpu()], self.w, self.ocfg)
+        return f[0], m[0].to(torch.uint8)
+
+    def encode_video_audios(self, mel, audio_size, normalizer=None, **kw):
+        f, m = O.encode_video_audios([mel.float().cpu()], [int(audio_size)], self.w, self.ocfg)
+        return f[0], m[0].to(torch.uint8)
+
+    def mm_stream_prefill(self, img, img_mask, aud, aud_mask, pre_normalized=True, check_masks=True):
+        # the oracle runs the multimodal stream inside its first model_forward call (interleaved, like the reference)
+        return SimpleNamespace(img=img, imask=None if img_mask is None else img_mask.bool(), aud=aud,
+                               amask=None if aud_mask is None else aud_mask.bool(),
+                               g_img=0 if img is None else img.shape[0], g_aud=0 if aud is None else aud.shape[0])
+
+    # ---- text stream ----
+    def new_text_state(self, B, Lmax):
+        return SimpleNamespace(B=B, Lmax=Lmax, caches=O.OracleCaches(), mask=torch.zeros((B, 0), dtype=torch.bool), past_len=0, n_valid=None)
+
+    def embed_tokens(self, ids, normalize=True):
+        ids = ids.reshape(-1).long().cpu()
+        e = F.embedding(ids.clamp(min=0), self.w["model.embed_tokens.weight"])
+        return e * (ids >= 0)[:, None]
+
+    def text_forward(self, hidden, positions, ts, mm, Lq, new_mask=None, dyn=False):
+        B = ts.B
+        emb = hidden.view(B, Lq, -1)
+        pos = positions.view(B, Lq).long().cpu()
+        nm = torch.ones((B, Lq), dtype=torch.bool) if new_mask is None else new_mask.bool().cpu()
+        ts.mask = torch.cat([ts.mask, nm], dim=1)
+        ex = lambda t: None if t is None else t[None].expand(B, *t.shape)          # noqa: E731  (queries of a batch share the video)
+        img, imask, aud, amask = (None,) * 4 if mm is None else (ex(mm.img), ex(mm.imask), ex(mm.aud), ex(mm.amask))
+        h = O.model_forward(emb, pos, ts.mask, img, imask, aud, amask, self.w, self.ocfg, ts.caches, ts.past_len)
+        ts.past_len += Lq
+        return h.reshape(B * Lq, -1)
+
+    def logits_argmax(self, hn_last):
+        logits = O.lm_logits(hn_last[:, None, :], self.w, self.ocfg)[:, 0]
+        return logits, torch.argmax(logits.float(), dim=-1)

@@ -110,8 +110,33 @@ class VidiConfig:
 
     @classmethod
     def from_pretrained(cls, path: str) -> "VidiConfig":
+        """config.json of a Vidi checkpoint (a Gemma2 / Mistral config + mm_* keys).  The tower dimensions are not in it: the
+        reference builds the towers from `mm_vision_tower` / `mm_audio_tower` (multimodal.py:44-57); when those resolve to local
+        directories their config.json provides the dimensions, otherwise the published dims of the default towers apply."""
         with open(os.path.join(path, "config.json")) as f:
-            return cls.from_dict(json.load(f))
+            raw = json.load(f)
+        cfg = cls.from_dict(raw)
+        from .weights import resolve_tower_dir
+        vdir = resolve_tower_dir(cfg.mm_vision_tower, path)
+        if vdir and os.path.exists(os.path.join(vdir, "config.json")):
+            t = json.load(open(os.path.join(vdir, "config.json")))
+            t = t.get("vision_config", t)
+            for ours, theirs in (("vis_image_size", "image_size"), ("vis_patch_size", "patch_size"), ("vis_hidden_size", "hidden_size"),
+                                 ("vis_intermediate_size", "intermediate_size"), ("vis_num_layers", "num_hidden_layers"),
+                                 ("vis_num_heads", "num_attention_heads"), ("vis_ln_eps", "layer_norm_eps")):
+                if theirs in t and ours not in raw:
+                    setattr(cfg, ours, t[theirs])
+        adir = resolve_tower_dir(cfg.mm_audio_tower, path)
+        if adir and os.path.exists(os.path.join(adir, "config.json")):
+            t = json.load(open(os.path.join(adir, "config.json")))
+            for ours, theirs in (("aud_num_mel_bins", "num_mel_bins"), ("aud_d_model", "d_model"), ("aud_num_layers", "encoder_layers"),
+                                 ("aud_num_heads", "encoder_attention_heads"), ("aud_ffn_dim", "encoder_ffn_dim"),
+                                 ("aud_max_source_positions", "max_source_positions")):
+                if theirs in t and ours not in raw:
+                    setattr(cfg, ours, t[theirs])
+            if "max_source_positions" in t and "aud_nb_max_frames" not in raw:
+                cfg.aud_nb_max_frames = 2 * t["max_source_positions"]
+        return cfg
 
     def save_pretrained(self, path: str):
         os.makedirs(path, exist_ok=True)

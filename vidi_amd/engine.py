@@ -232,7 +232,10 @@ class VidiEngine:
         for s in shape:
             n *= s
         if t is None or t.numel() < n or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=self.dev)
+            # workspaces outlive the call: allocate them as normal tensors even when the caller runs under torch.inference_mode()
+            # (the reference CLI does, inference.py:40) — an inference tensor cannot be updated in place by a later call outside it
+            with torch.inference_mode(False):
+                t = (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=self.dev)
             self._ws[name] = t
         return t[:n].view(*shape)
 
@@ -515,12 +518,13 @@ class VidiEngine:
     def _rope_tables(self, max_pos: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """cos/sin rows per position, fp32 math then cast (TP gemma2:118-136); host-precomputed table."""
         if self._rope_cache is None or self._rope_cache[0].shape[0] < max_pos:
-            hd = self.cfg.head_dim
-            n = max(max_pos, 2048)
-            inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
-            fr = torch.arange(n, dtype=torch.float)[:, None] * inv[None, :]
-            emb = torch.cat((fr, fr), dim=-1)
-            self._rope_cache = (emb.cos().to(self.dtype).to(self.dev), emb.sin().to(self.dtype).to(self.dev))
+            with torch.inference_mode(False):                        # cached across calls: a normal tensor (see _buf)
+                hd = self.cfg.head_dim
+                n = max(max_pos, 2048)
+                inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+                fr = torch.arange(n, dtype=torch.float)[:, None] * inv[None, :]
+                emb = torch.cat((fr, fr), dim=-1)
+                self._rope_cache = (emb.cos().to(self.dtype).to(self.dev), emb.sin().to(self.dtype).to(self.dev))
         return self._rope_cache
 
     def _cross(self, q: torch.Tensor, li: int, mm: MMState, which: str, out: torch.Tensor, R: int, defer_merge: bool = False):
@@ -537,7 +541,8 @@ class VidiEngine:
         zsplit = max(1, min(256 // max(1, nkv * row_tiles), (nsub + 7) // 8))
         key = f"xattn_ws_{which}_{zsplit}_{Rpad}"        # one workspace per modality: both partial sets live until the merge
         if key not in self._ws:
-            self._ws[key] = hip.attn_cross_workspace(zsplit, nkv, Rpad, hd, self.dev)
+            with torch.inference_mode(False):
+                self._ws[key] = hip.attn_cross_workspace(zsplit, nkv, Rpad, hd, self.dev)
         opart, ml = self._ws[key]
         if n > 0:
             hip.attn_cross(q, mm.kc[li], mm.vtc[li], mask, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
@@ -552,6 +557,7 @@ class VidiEngine:
         import torch.distributed as dist
         pk = f"xattn_part_{Rpad}"
         if pk not in self._ws:
+          with torch.inference_mode(False):
             self._ws[pk] = (torch.zeros((nkv, Rpad, hd), dtype=torch.float32, device=self.dev),
                             torch.zeros((nkv, Rpad, 2), dtype=torch.float32, device=self.dev),
                             torch.zeros((self.world, nkv, Rpad, hd), dtype=torch.float32, device=self.dev),
@@ -752,8 +758,8 @@ class VidiEngine:
         hip.softcap_argmax(logits, idx, self.cfg.final_logit_softcapping)
         return logits, idx
 
-    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
-        """embed_tokens(ids) * normalizer; ids < 0 give zero rows (padding)."""
+    def embed_tokens(self, ids: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """embed_tokens(ids) * normalizer (normalize=False: the raw table rows); ids < 0 give zero rows (padding)."""
         ids = ids.reshape(-1).to(torch.int64).contiguous()
         out = torch.empty((ids.numel(), self.cfg.hidden_size), dtype=self.dtype, device=self.dev)
-        return hip.embed(ids, self.embed, out, normalizer=self.normalizer)
+        return hip.embed(ids, self.embed, out, normalizer=self.normalizer if normalize else 1.0)

@@ -83,11 +83,13 @@ class VidiForCausalLM:
     config_class = VidiConfig
 
     def __init__(self, config: VidiConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float16,
-                 device: str = "cuda"):
+                 device: str = "cuda", engine=None):
+        """`engine`: an object with VidiEngine's interface, built by the caller (the host-logic tests drive this class on the
+        CPU that way); by default the HIP engine is constructed here and raises without a HIP device / libvidi_hip.so."""
         self.config = config
         self.dtype = dtype
         self.device = torch.device(device)
-        self.engine = VidiEngine(config, weights, dtype=dtype, device=device)
+        self.engine = engine if engine is not None else VidiEngine(config, weights, dtype=dtype, device=device)
         self.generation_config = SimpleNamespace(eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id)
         self.model = _Inner(self)
         self._mm_cache: Optional[Tuple[Any, MMState]] = None
@@ -195,8 +197,9 @@ class VidiForCausalLM:
             raise NotImplementedError("beam search is not implemented (the reference CLI decodes greedily)")
         max_new = int(kwargs.get("max_new_tokens", 20))
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
+        eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]) if e is not None]     # HF allows a list ([1, 107] for Gemma2)
         pad = kwargs.get("pad_token_id", None)
-        pad = eos if pad is None else pad
+        pad = (eos_list[0] if eos_list else 0) if pad is None else pad
         attention_mask = kwargs.get("attention_mask", None)
         eng = self.engine
         if eng.mistral and attention_mask is not None and int(attention_mask[:, -1].sum()) != attention_mask.shape[0]:
@@ -242,6 +245,7 @@ class VidiForCausalLM:
         B = ids.shape[0]
         out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
         finished = torch.zeros(B, dtype=torch.bool, device=eng.dev)
+        eos_t = torch.tensor(eos_list, dtype=torch.int64, device=eng.dev)
         def pick(h):
             logits, idx = eng.logits_argmax(h)                          # lm_head + final softcap (in place) + argmax
             if not do_sample:
@@ -262,7 +266,7 @@ class VidiForCausalLM:
             nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
             out[:, step] = nxt
             n_done = step + 1
-            finished = finished | (nxt == eos)
+            finished = finished | torch.isin(nxt, eos_t)
             if bool(finished.all()) or step == max_new - 1:          # one D2H sync per token, like HF's stopping criteria
                 break
             if use_graph:
@@ -332,7 +336,8 @@ class VidiForCausalLM:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels, None, None
         ids, mask, pos = strip_image_token(input_ids, attention_mask)
         eng = self.engine
-        emb = eng.embed_tokens(ids.to(eng.dev)).view(ids.shape[0], ids.shape[1], -1)
+        # raw embed_tokens output like the reference (multimodal.py:372-432): the sqrt(H) normalizer is the decoder's (gemma.py:353-356)
+        emb = eng.embed_tokens(ids.to(eng.dev), normalize=False).view(ids.shape[0], ids.shape[1], -1)
         fi, mi, fa, ma = self.encode_videos(images, audios, audio_sizes)
         return (None, pos if position_ids is not None else None, mask if attention_mask is not None else None,
                 past_key_values, emb, labels, fi, mi, fa, ma)
@@ -345,7 +350,7 @@ def load_pretrained_model(model_name_or_path: str, load_8bit: bool = False, load
     names a preset.  Returns (model, tokenizer, image_processor, audio_processor)."""
     if load_8bit or load_4bit:
         raise NotImplementedError("bitsandbytes quantised loading is out of scope")
-    from .weights import init_random_weights, load_safetensors_dir
+    from .weights import init_random_weights, load_checkpoint
     dtype = kwargs.pop("torch_dtype", torch.float16)
     synthetic = kwargs.pop("synthetic", None)
     if synthetic is not None:
@@ -354,14 +359,20 @@ def load_pretrained_model(model_name_or_path: str, load_8bit: bool = False, load
         weights = init_random_weights(cfg, seed=int(kwargs.pop("seed", 3)), dtype=dtype, device=device)
     else:
         cfg = VidiConfig.from_pretrained(model_name_or_path)
-        weights = load_safetensors_dir(model_name_or_path, device="cpu")
-    model = VidiForCausalLM(cfg, weights, dtype=dtype, device=device)
+        weights = load_checkpoint(model_name_or_path, cfg)
+    engine_factory = kwargs.pop("engine_factory", None)
+    engine = engine_factory(cfg, weights, dtype) if engine_factory is not None else None
+    model = VidiForCausalLM(cfg, weights, dtype=dtype, device=device, engine=engine)
     tok = img_proc = aud_proc = None
-    try:
-        from .processors import build_processors
-        tok, img_proc, aud_proc = build_processors(model_name_or_path, cfg)
-    except Exception:                       # tokenizer files absent (synthetic runs): processors stay None
-        pass
+    from .processors import build_processors
+    if synthetic is None:
+        tok, img_proc, aud_proc = build_processors(model_name_or_path, cfg)        # a real checkpoint without its tokenizer / processor files is an error
+    else:
+        try:
+            tok, img_proc, aud_proc = build_processors(model_name_or_path, cfg)
+        except Exception as e:              # synthetic runs usually have no tokenizer files: processors stay None, say so
+            import warnings
+            warnings.warn(f"synthetic model without tokenizer/processor files ({type(e).__name__}: {e}); processors are None")
     model.get_model().text_tokenizer, model.get_model().image_processor, model.get_model().audio_processor = tok, img_proc, aud_proc
     model.generation_config.eos_token_id = cfg.eos_token_id
     return model, tok, img_proc, aud_proc

@@ -172,10 +172,25 @@ def get_media_length(file) -> float:
 
 def build_processors(model_path: str, cfg):
     """tokenizer + SigLIP image processor + Whisper feature extractor, as `DattnMMModel.__init__` gathers them
-    (multimodal.py:59-61, gemma.py:457-464).  Needs the tokenizer/processor files next to the checkpoint."""
+    (multimodal.py:44-61, gemma.py:457-464): the tokenizer comes from the checkpoint directory, the two processors from the TOWER
+    repositories (`mm_vision_tower` / `mm_audio_tower`).  Offline, a tower resolves to a local directory (weights.resolve_tower_dir);
+    when it does not, the processor is built from the config with the towers' published preprocessing (SigLIP: bicubic resize to
+    the tower's image size, 1/255 rescale, mean = std = 0.5; Whisper: 16 kHz, 25 ms window, hop 160, 30-s chunks)."""
     from transformers import AutoTokenizer, SiglipImageProcessor, WhisperFeatureExtractor
+    from .weights import resolve_tower_dir
+    import os
     tok = AutoTokenizer.from_pretrained(model_path, model_max_length=4096, padding_side="right")
-    img = SiglipImageProcessor.from_pretrained(model_path)
+    vdir, adir = resolve_tower_dir(cfg.mm_vision_tower, model_path), resolve_tower_dir(cfg.mm_audio_tower, model_path)
+    if vdir and os.path.exists(os.path.join(vdir, "preprocessor_config.json")):
+        img = SiglipImageProcessor.from_pretrained(vdir)
+    else:
+        S = cfg.vis_image_size
+        img = SiglipImageProcessor(size={"height": S, "width": S}, resample=3, rescale_factor=1 / 255, image_mean=[0.5, 0.5, 0.5],
+                                   image_std=[0.5, 0.5, 0.5])
     img.output_size = img.size["height"]
-    aud = WhisperFeatureExtractor.from_pretrained(model_path)
+    if adir and os.path.exists(os.path.join(adir, "preprocessor_config.json")):
+        aud = WhisperFeatureExtractor.from_pretrained(adir)
+    else:
+        aud = WhisperFeatureExtractor(feature_size=cfg.aud_num_mel_bins, sampling_rate=cfg.aud_sampling_rate, hop_length=cfg.aud_hop_length,
+                                      chunk_length=cfg.aud_nb_max_frames * cfg.aud_hop_length // cfg.aud_sampling_rate, n_fft=400)
     return tok, img, aud

@@ -136,3 +136,56 @@ def load_safetensors_dir(path: str, device="cpu") -> Dict[str, torch.Tensor]:
     for f in files:
         out.update(load_file(f, device=str(device)))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# real checkpoints: the reference builds both towers from their own repositories (`mm_vision_tower` / `mm_audio_tower`,
+# multimodal.py:44-57) and tolerates their absence from the Vidi checkpoint (gemma.py:469 `_keys_to_ignore_on_load_missing`)
+# ------------------------------------------------------------------------------------------------
+def resolve_tower_dir(name: str, model_path: str):
+    """A tower reference that is reachable offline: the name itself if it is a directory, else <model_path>/<name> or
+    <model_path>/<basename(name)>; None otherwise (hub names cannot be fetched here)."""
+    if not name:
+        return None
+    for cand in (name, os.path.join(model_path, name), os.path.join(model_path, os.path.basename(name.rstrip("/")))):
+        if os.path.isdir(cand):
+            return cand
+    return None
+
+
+def _tower_state(tower_dir: str, kind: str) -> Dict[str, torch.Tensor]:
+    """HF tower checkpoint -> the names the Vidi state dict uses.  SigLIP: `vision_model.*` -> `model.mm_vis.vision_model.*`;
+    Whisper: `model.encoder.*` or `encoder.*` -> `model.mm_aud.encoder.*`."""
+    sd = load_safetensors_dir(tower_dir)
+    out = {}
+    for k, v in sd.items():
+        if kind == "vis":
+            if k.startswith("vision_model."):
+                out["model.mm_vis." + k] = v
+        else:
+            kk = k[len("model."):] if k.startswith("model.") else k
+            if kk.startswith("encoder."):
+                out["model.mm_aud." + kk] = v
+    return out
+
+
+def load_checkpoint(path: str, cfg: VidiConfig) -> Dict[str, torch.Tensor]:
+    """State dict of a Vidi checkpoint directory with the reference's parameter names; tower weights missing from it are taken
+    from the tower directories named by the config.  Raises with the list of absent parameters otherwise (shapes are checked)."""
+    sd = load_safetensors_dir(path)
+    shapes = weight_shapes(cfg)
+    for kind, prefix, name in (("vis", "model.mm_vis.", cfg.mm_vision_tower), ("aud", "model.mm_aud.", cfg.mm_audio_tower)):
+        if any(k.startswith(prefix) and k not in sd for k in shapes):
+            tdir = resolve_tower_dir(name, path)
+            if tdir is not None:
+                for k, v in _tower_state(tdir, kind).items():
+                    sd.setdefault(k, v)
+    missing = [k for k in shapes if k not in sd]
+    if missing:
+        raise KeyError(f"{len(missing)} parameters absent from {path} (first: {missing[:6]}).  Tower weights may live in a local copy of "
+                       f"config.mm_vision_tower={cfg.mm_vision_tower!r} / mm_audio_tower={cfg.mm_audio_tower!r}: a directory of that name "
+                       f"(absolute, or under the checkpoint directory) with HF-format *.safetensors")
+    bad = [(k, tuple(sd[k].shape), shapes[k]) for k in shapes if tuple(sd[k].shape) != tuple(shapes[k])]
+    if bad:
+        raise ValueError(f"{len(bad)} parameters with unexpected shapes, e.g. {bad[:4]} (checkpoint vs config)")
+    return sd
