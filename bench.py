@@ -51,51 +51,102 @@ def parse():
     return ap.parse_args()
 
 
-def shard(n, world, rank):
-    base, extra = divmod(n, world)
-    s = rank * base + min(rank, extra)
-    return s, s + base + (1 if rank < extra else 0)
+from vidi_amd.shard import shard          # noqa: E402  (the product's frame / window partition; host integer logic)
 
 
-def cpu_baseline(cfg, T, Nv, Na, prompt_len):
-    """The CPU oracle (oracle/vidi_oracle.py, fp32 eager PyTorch) timed on a bounded slice of the same
-    workload and extrapolated linearly in (frames x layers), (tokens x layers), (windows x layers)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False):
+    """The reference has no CPU path (FA2 is hard-required), so the baseline is the CPU oracle (oracle/vidi_oracle.py, eager
+    PyTorch) on the host cores, timed on the slices SURVEY 8(d) prescribes and extrapolated linearly in (frames x layers),
+    (tokens x layers), (windows x layers):  SigLIP 32 frames x 2 layers, LLM mm-stream 4 096 tokens x 2 layers, text->mm cross-attention
+    of the prompt over ALL Nv keys x 2 layer-modality calls, Whisper 2 windows x 2 layers — in fp32 and bf16.  The thread count is swept
+    on a GEMM probe of the stream's gate/up shape and the best one is used for every leg."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dataclasses
     import vidi_oracle as O
     from vidi_amd.weights import init_random_weights
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    small = dataclasses.replace(cfg, num_hidden_layers=1, vis_num_layers=3, aud_num_layers=1, vocab_size=1024)
-    w = init_random_weights(small, seed=3, dtype=torch.float32, device="cpu")
+    nf, ntok, nwin, vis_l, llm_l, aud_l, x_calls = (4, 512, 1, 1, 1, 1, 1) if quick else (32, 4096, 2, 2, 2, 2, 2)
+    # ---- thread sweep on one GEMM of the dominant shape (tokens x H) . (H x 2I) ----
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn((ntok, cfg.hidden_size), generator=g)
+    b = torch.randn((cfg.hidden_size, 2 * cfg.intermediate_size if not quick else 1024), generator=g)
+    probe = {}
+    cands = sorted({c for c in (8, 16, 32, 64, 128, 256, cores) if c <= cores})
+    for dt in (torch.float32, torch.bfloat16):
+        aa, bb = a.to(dt), b.to(dt)
+        for n in cands:
+            torch.set_num_threads(n)
+            torch.matmul(aa, bb)
+            t0 = time.perf_counter(); torch.matmul(aa, bb); dtm = time.perf_counter() - t0
+            probe[(str(dt).split(".")[-1], n)] = 2.0 * aa.shape[0] * aa.shape[1] * bb.shape[1] / dtm / 1e12
+    del a, b
+    small = dataclasses.replace(cfg, num_hidden_layers=max(1, llm_l), vis_num_layers=vis_l + 1, aud_num_layers=aud_l, vocab_size=1024)
+    w32 = init_random_weights(small, seed=3, dtype=torch.float32, device="cpu")
     names = {f.name for f in dataclasses.fields(O.OracleConfig)}
     ocfg = O.OracleConfig(**{k: v for k, v in small.to_dict().items() if k in names}, vis_select_layer=small.mm_vision_select_layer)
-    g = torch.Generator().manual_seed(0)
-    with torch.no_grad():
-        nf = 8
-        px = (torch.randn((nf, 3, cfg.vis_image_size, cfg.vis_image_size), generator=g) * 0.5).clamp(-1, 1)
-        O.siglip_forward(px[:1], w, ocfg)
-        t0 = time.time(); O.siglip_forward(px, w, ocfg); t_vis = (time.time() - t0) / (nf * 2)        # per frame-layer
-        ntok = 2048
-        x = torch.randn((1, ntok, cfg.hidden_size), generator=g) * 0.03 * cfg.hidden_size ** 0.5
-        t0 = time.time(); O.mm_stream_layer(x, w, "model.layers.0.", ocfg); t_llm = (time.time() - t0) / ntok   # per token-layer
-        mel = torch.randn((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g) * 0.3
-        t0 = time.time(); O.whisper_encoder_forward(mel, w, ocfg); t_aud = time.time() - t0            # per window-layer (+stem)
-        # cross attention of the text prefill over a slice of the keys, one layer-modality
-        nk = 8192
-        q = torch.randn((1, cfg.num_attention_heads, prompt_len, cfg.head_dim), generator=g)
-        k = torch.randn((1, cfg.num_attention_heads, nk, cfg.head_dim), generator=g)
-        t0 = time.time(); O.sdpa_reference(q, k, k, cfg.head_dim ** -0.5, 50.0); t_x = (time.time() - t0) / nk
     C = math.ceil(T / 30)
-    t_total = (T * cfg.vis_select_layers * t_vis + (Nv + Na) * cfg.num_hidden_layers * t_llm +
-               C * cfg.aud_num_layers * t_aud + (Nv + Na) * cfg.num_hidden_layers * t_x)
-    return {"value": Nv / t_total, "unit": "video-tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 on {nf} frames x 2 SigLIP layers, {ntok} tokens x 1 LLM stream layer, 1 Whisper window x 1 layer, "
-                      f"x-attn Lq={prompt_len} over {nk} keys; extrapolated linearly to {T} frames / {Nv + Na} tokens / "
+    # algorithmic FLOPs of the slices (SURVEY 8d per-unit figures)
+    Hv, Iv, Ns = cfg.vis_hidden_size, cfg.vis_intermediate_size, cfg.vis_side ** 2
+    f_vis = (8 * Hv * Hv + 4 * Hv * Iv + 4 * Ns * Hv) * Ns                       # per frame-layer
+    f_llm = 4 * cfg.hidden_size * 2 * cfg.num_key_value_heads * cfg.head_dim / 2 * 2 + 2 * cfg.num_attention_heads * cfg.head_dim * cfg.hidden_size \
+        + 6 * cfg.hidden_size * cfg.intermediate_size                             # per token-layer (K,V proj + o_proj(V) + GeGLU MLP)
+    Da, Fa, Nw = cfg.aud_d_model, cfg.aud_ffn_dim, cfg.aud_max_source_positions
+    f_aud = (8 * Da * Da + 4 * Da * Fa + 4 * Nw * Da) * Nw                        # per window-layer
+    f_x = 4.0 * prompt_len * cfg.num_attention_heads * cfg.head_dim               # per key per layer-modality call
+    legs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        name = str(dt).split(".")[-1]
+        nthr = max(cands, key=lambda n: probe[(name, n)])
+        torch.set_num_threads(nthr)
+        w = w32 if dt == torch.float32 else {k: (v.to(dt) if v.is_floating_point() else v) for k, v in w32.items()}
+        g = torch.Generator().manual_seed(0)
+        with torch.no_grad():
+            px = ((torch.randn((nf, 3, cfg.vis_image_size, cfg.vis_image_size), generator=g) * 0.5).clamp(-1, 1)).to(dt)
+            O.siglip_forward(px[:1], w, ocfg)
+            t0 = time.perf_counter(); O.siglip_forward(px, w, ocfg); t_vis = (time.perf_counter() - t0) / (nf * vis_l)
+            x = (torch.randn((1, ntok, cfg.hidden_size), generator=g) * 0.03 * cfg.hidden_size ** 0.5).to(dt)
+            t0 = time.perf_counter()
+            for li in range(llm_l):
+                O.mm_stream_layer(x, w, f"model.layers.{li}.", ocfg)
+            t_llm = (time.perf_counter() - t0) / (ntok * llm_l)
+            mel = (torch.randn((nwin, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g) * 0.3).to(dt)
+            t0 = time.perf_counter(); O.whisper_encoder_forward(mel, w, ocfg); t_aud = (time.perf_counter() - t0) / (nwin * aud_l)
+            # cross attention of the text prefill over ALL video keys (GQA-expanded like repeat_kv, gemma.py:74-75)
+            nk = Nv if not quick else 4096
+            q = torch.randn((1, cfg.num_attention_heads, prompt_len, cfg.head_dim), generator=g).to(dt)
+            k = torch.randn((1, cfg.num_attention_heads, nk, cfg.head_dim), generator=g).to(dt)
+            t0 = time.perf_counter()
+            for _ in range(x_calls):
+                O.sdpa_reference(q, k, k, cfg.head_dim ** -0.5, 50.0)
+            t_x = (time.perf_counter() - t0) / (nk * x_calls)
+            del px, x, mel, q, k
+        parts = {"siglip": T * cfg.vis_select_layers * t_vis, "llm_stream": (Nv + Na) * cfg.num_hidden_layers * t_llm,
+                 "whisper": C * cfg.aud_num_layers * t_aud, "xattn": (Nv + Na) * cfg.num_hidden_layers * t_x}
+        t_total = sum(parts.values())
+        legs[name] = {"value": Nv / t_total, "threads": nthr, "t_prefill_extrapolated_s": t_total, "breakdown_s": parts,
+                      "cpu_tflops": {"gemm_probe": probe[(name, nthr)], "siglip": f_vis / t_vis / 1e12, "llm_stream": f_llm / t_llm / 1e12,
+                                     "whisper": f_aud / t_aud / 1e12, "xattn": f_x / t_x / 1e12},
+                      "effective_tflops": (T * cfg.vis_select_layers * f_vis + (Nv + Na) * cfg.num_hidden_layers * f_llm +
+                                           C * cfg.aud_num_layers * f_aud + (Nv + Na) * cfg.num_hidden_layers * f_x) / t_total / 1e12}
+    best = max(legs, key=lambda n: legs[n]["value"])
+    return {"value": legs[best]["value"], "unit": "video-tokens/s", "cores": cores, "threads": legs[best]["threads"], "kind": "port",
+            "dtype": best, "cpu_model": _cpu_model(),
+            "sample": f"oracle (eager PyTorch, fp32 and bf16; the faster one is `value`) on {nf} frames x {vis_l} SigLIP layers, {ntok} tokens x "
+                      f"{llm_l} LLM stream layers, {nwin} Whisper windows x {aud_l} layers, x-attn Lq={prompt_len} over {nk} keys x {x_calls} calls; "
+                      f"extrapolated linearly to {T} frames / {Nv + Na} tokens / {C} windows / "
                       f"{cfg.vis_select_layers}+{cfg.num_hidden_layers}+{cfg.aud_num_layers} layers",
-            "t_prefill_extrapolated_s": t_total,
-            "breakdown_s": {"siglip": T * cfg.vis_select_layers * t_vis, "llm_stream": (Nv + Na) * cfg.num_hidden_layers * t_llm,
-                            "whisper": C * cfg.aud_num_layers * t_aud, "xattn": (Nv + Na) * cfg.num_hidden_layers * t_x}}
+            "t_prefill_extrapolated_s": legs[best]["t_prefill_extrapolated_s"], "by_dtype": legs,
+            "thread_sweep_gemm_tflops": {f"{d}@{n}": v for (d, n), v in probe.items()}}
 
 
 def main():
@@ -156,6 +207,7 @@ def main():
     from vidi_amd.model import strip_image_token
     idt, mask, pos = strip_image_token(ids)
     stage_ms = {}
+    checks = []            # (first-token logits, argmax) of every timed step: verified after the timed region (finite, identical)
 
     def ev():
         e = torch.cuda.Event(enable_timing=True)
@@ -171,8 +223,9 @@ def main():
         mm = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
         e3 = ev()
         ts, last = model._prefill(idt, mask, pos, mm, a.decode_steps + 1)
-        _, nxt = eng.logits_argmax(last)
+        logits, nxt = eng.logits_argmax(last)
         e4 = ev()
+        checks.append((logits, nxt))
         if record:
             torch.cuda.synchronize()
             for k, (x, y) in {"vision_encode": (e0, e1), "audio_encode": (e1, e2), "mm_stream": (e2, e3), "text_prefill": (e3, e4)}.items():
@@ -196,21 +249,47 @@ def main():
         wmm, wts, wnxt = step()
         decode_eager(wts, wmm, wnxt, min(2, a.decode_steps))   # warm the decode kernels too (code objects, workspaces)
         del wmm, wts, wnxt
-    timer = None if a.no_kernel_timer else hip.KernelTimer()
+    # ---- timed region: K steps with NO per-launch instrumentation (the headline number) ----
+    checks.clear()
     barrier(); torch.cuda.synchronize()
-    hip.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(a.steps):
         mm, ts, nxt = step(record=True)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    hip.TIMER = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
     value = Nv * a.steps / dt
+    # every timed step must have produced finite first-token logits and the same greedy token (same inputs, deterministic kernels)
+    lg0, tk0 = checks[0]
+    for lg, tk in checks:
+        if not bool(torch.isfinite(lg.float()).all()):
+            raise RuntimeError("bench: non-finite first-token logits in a timed step")
+        if not torch.equal(tk, tk0):
+            raise RuntimeError(f"bench: first-token argmax differs between timed steps ({tk.tolist()} vs {tk0.tolist()})")
+    first_token = [int(x) for x in tk0.tolist()]
+    logit_checksum = float(lg0.float().abs().sum())
+    checks.clear()
+
+    # ---- second pass (untimed in `value`): every C-ABI launch bracketed with HIP events on the launch stream -> kernel families ----
+    timer = None if a.no_kernel_timer else hip.KernelTimer()
+    timer_steps = 0
+    if timer is not None:
+        timer_steps = min(a.steps, 2)
+        saved = dict(stage_ms)
+        barrier(); torch.cuda.synchronize()
+        hip.TIMER = timer
+        for _ in range(timer_steps):
+            mm, ts, nxt = step()
+        torch.cuda.synchronize(); barrier()
+        hip.TIMER = None
+        stage_ms.clear(); stage_ms.update(saved)
+        if not torch.equal(checks[-1][1], tk0):
+            raise RuntimeError("bench: instrumented pass disagrees with the timed pass")
+        checks.clear()
 
     # ---- decode leg (s/query = prefill + n_new decode steps on the resident caches) ----
     # --decode-graph: the step is captured once in a hipGraph (vidi_amd/engine.py:make_decode_graph) and replayed;
@@ -238,21 +317,30 @@ def main():
     if "gemm" in fam:
         gm = fam["gemm"]
         ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12
-        roof = {"kernel": "gemm_kernel (MFMA 16x16x32 bf16, 256x256x64 tiles; all GEMM launches of the timed steps)", "bound": "mfma",
-                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+        roof = {"kernel": "gemm_w4_kernel / gemm_kernel (MFMA 16x16x32, 256x256x64 tiles, persistent 4-wave; all GEMM launches of the instrumented steps)",
+                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
                 "launches": gm["launches"], "avg_launch_ms": gm["ms"] / gm["launches"],
                 "algorithmic_flop_per_launch_avg": gm["work"] / gm["launches"],
                 "algorithmic_bytes_per_launch_avg": gm["bytes"] / gm["launches"]}
-        # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-        # command (tools/traffic_from_pmc.py -> profiles/); PMC passes cannot run inside the timed region, so the
-        # committed summary is attached when it was taken on this workload (same GEMM launch count per step).
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        # L2-miss bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+        # (tools/traffic_from_pmc.py -> profiles/); PMC passes cannot run inside the timed region.  The committed summary is attached
+        # ONLY when it was taken on this exact GEMM source (digest of the kernel sources + flags), workload and launch mix.
+        from vidi_amd.build import source_digest
+        dig = source_digest("gemm")
+        roof["gemm_source_digest"] = dig
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        roof["traffic_note"] = "no PMC summary for this build (profiles/traffic.json absent)"
         if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
-            if tj.get("frames") == T and tj.get("launches_fetch_pass") == gm["launches"] // a.steps:
+            if tj.get("gemm_source_digest") != dig:
+                roof["traffic_note"] = f"profiles/traffic.json was collected on GEMM source {tj.get('gemm_source_digest')}, not this build: not attached"
+            elif tj.get("frames") != T or tj.get("launches_fetch_pass") != gm["launches"] // max(1, timer_steps) or tj.get("preset") != a.preset:
+                roof["traffic_note"] = "profiles/traffic.json was collected on another workload / launch mix: not attached"
+            else:
                 roof["traffic"] = tj["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per GEMM launch)"
-    fams = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
+                roof["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per GEMM launch, " + tj.get("file", "profiles/traffic.json") +
+                                        "; the counters sit at the L2's fabric side, so Infinity-Cache hits are included: an upper bound on HBM bytes")
+    fams = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / max(1, timer_steps),
                 ("TFLOP/s" if v["unit"] == "flop" else "GB/s"): (v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9)) if v["ms"] > 0 else 0.0}
             for k, v in fam.items()}
 
@@ -269,7 +357,8 @@ def main():
         "queries": a.queries, "decode_tokens": a.decode_steps, "decode_graph": bool(use_graph), "decode_graph_capture_ms": t_capture * 1e3,
         "decode_replay_ms_per_token": t_replay * 1e3, "frames_per_s": T * a.steps / dt,
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
-        "kernel_families": fams,
+        "first_token": first_token, "first_token_logit_abs_sum": logit_checksum,
+        "kernel_families": fams, "kernel_family_steps": timer_steps,
         "roofline": roof,
     }
     if world == 1 and not a.no_preproc:

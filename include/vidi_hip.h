@@ -124,6 +124,18 @@ int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF3
 int vidi_attn_merge2(const float* OpartA, const float* MLA, void* OutA, int WA, int zeroA,
                      const float* OpartB, const float* MLB, void* OutB, int WB, int zeroB,
                      int nkv, int R, int Rpad, int G, int HD, int ldo, int dtype, void* stream);
+/* Frame-sharded (multi-GPU) form of the two merges, SURVEY 8(e): the keys of a video are sharded over ranks, so what the
+ * reference gets from ONE flash_attn_func call over all keys (gemma.py:81-91) is assembled from per-rank partials.
+ * Every set (A = T2V, B = T2A) reads W partials whose slices are wsO / wsML floats apart (a rank's own zsplit partials:
+ * nkv*Rpad*HD / nkv*Rpad*2; the all-gathered packed buffers of all ranks: the packed per-rank length), rows Rpad apart
+ * inside a slice, and writes Out (model dtype, may be null) and/or the partial form OutF32 [nkv][rpo][HD] + OutML
+ * [nkv][rpo][2] (rpo >= R: row stride of the packed buffer).  W == 0 emits the neutral partial (m = -inf, l = 0) of a
+ * rank that holds no key of the modality; a set with neither Out nor OutF32 is skipped. */
+int vidi_attn_merge2_sharded(const float* OpartA, const float* MLA, long long wsOA, long long wsMLA, void* OutA, float* OutF32A,
+                             float* OutMLA, int WA, int zeroA,
+                             const float* OpartB, const float* MLB, long long wsOB, long long wsMLB, void* OutB, float* OutF32B,
+                             float* OutMLB, int WB, int zeroB,
+                             int nkv, int R, int Rpad, int rpo, int G, int HD, int ldo, int dtype, void* stream);
 
 /* Text causal self-attention with softcap / sliding window / key mask (gemma.py:165-175 ->
  * TP gemma2:248-288 under FA2) over the text KV cache [B,Lmax,nkv*HD]. */

@@ -33,12 +33,49 @@ class OracleEngine:
         self.normalizer = 1.0
         self.world, self.rank, self.pg = 1, 0, None
 
+    # ---- multi-rank test mode (tests/test_shard.py): the product class (vidi_amd/model.py) shards the video; this engine checks
+    #      that the shards tile it with the right global offsets, reassembles them over the process group (the north-star's literal
+    #      "all-gather of visual tokens") and runs the oracle on the whole — so every rank must reproduce the single-rank answer ----
+    def set_dist(self, group=None):
+        import torch.distributed as dist
+        self.pg, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+
+    def sample_flag(self, x):
+        return torch.tensor([int(bool((x != 0).any()))], dtype=torch.int32)
+
+    def _gather_shards(self, rec):
+        import torch.distributed as dist
+        allr = [None] * self.world
+        dist.all_gather_object(allr, rec, group=self.pg)
+        return allr
+
     # ---- multimodal encode ----
-    def encode_video_images(self, pixel, normalizer=None, **kw):
+    def encode_video_images(self, pixel, normalizer=None, frame_offset=0, total_frames=None, sample_flag=None, **kw):
+        if self.world > 1:
+            allr = self._gather_shards(dict(x=pixel.float().cpu(), off=int(frame_offset), tot=total_frames, flag=int(sample_flag[0])))
+            full = torch.cat([r["x"] for r in allr], dim=0)
+            off = 0
+            for r in allr:                                            # contiguous, ordered, complete; every rank knows the global T
+                assert r["off"] == off and r["tot"] == full.shape[0], (r["off"], off, r["tot"], full.shape[0])
+                assert r["flag"] == int(bool((full != 0).any()))      # the "sample is not all zeros" flag is the WHOLE sample's
+                off += r["x"].shape[0]
+            f, m = O.encode_video_images([full], self.w, self.ocfg)
+            self.last_shard = dict(kind="img", local=int(pixel.shape[0]), off=int(frame_offset), total=int(full.shape[0]))
+            return f[0], m[0].to(torch.uint8)
         f, m = O.encode_video_images([pixel.float().cpu()], self.w, self.ocfg)
         return f[0], m[0].to(torch.uint8)
 
-    def encode_video_audios(self, mel, audio_size, normalizer=None, **kw):
+    def encode_video_audios(self, mel, audio_size, normalizer=None, chunk_offset=0, sample_flag=None, **kw):
+        if self.world > 1:
+            allr = self._gather_shards(dict(x=mel.float().cpu(), off=int(chunk_offset), size=int(audio_size), flag=int(sample_flag[0])))
+            full = torch.cat([r["x"] for r in allr], dim=0)
+            off = 0
+            for r in allr:
+                assert r["off"] == off and r["size"] == int(audio_size)   # audio_size stays the GLOBAL mel-frame count
+                assert r["flag"] == int(bool((full != 0).any()))
+                off += r["x"].shape[0]
+            f, m = O.encode_video_audios([full], [int(audio_size)], self.w, self.ocfg)
+            return f[0], m[0].to(torch.uint8)
         f, m = O.encode_video_audios([mel.float().cpu()], [int(audio_size)], self.w, self.ocfg)
         return f[0], m[0].to(torch.uint8)
 

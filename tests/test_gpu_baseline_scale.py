@@ -1,0 +1,94 @@
+"""Parity AT THE 60-MIN CONFIG'S SIZES (BASELINE configs[2]: Nv = 90 000 image keys + Na = 36 000 audio keys = 126 080 stream rows,
+Gemma2-9B layer dims), not only on the tiny goldens.
+
+The diagonal multimodal stream never mixes tokens (gemma.py:183-202: norm -> k/v proj -> o_proj(repeat_kv(V)) -> post norm ->
+residual -> GeGLU MLP -> residual, all row-wise), so a SAMPLE of rows can be checked exactly: the oracle evaluates
+`mm_stream_layer` on the sampled rows only and must reproduce what the full-size GPU run left in the K/V caches for those rows —
+layer 0 (first projection), layer 1 and layer 2 (which see one and two full stream updates).  The cross-attention kernel is then
+run over ALL 90 000 image keys (a few hundred masked out) and over the 36 000 audio keys against `sdpa_reference` on the caches the GPU
+itself wrote.  bf16; tolerances written at each check."""
+import numpy as np
+import pytest
+import torch
+
+import vidi_oracle as O
+from util import perm_positions, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _unpack_rows(mm, li, rows, nkv, hd):
+    """K and V rows `rows` (global key indices) of layer li from the tiled caches -> [n, nkv*hd] float (K), same (V)"""
+    rows_t = torch.as_tensor(rows, dtype=torch.int64, device=mm.kc.device)
+    kc = mm.kc[li].reshape(nkv, -1, hd)                                        # [nkv, ntile*64, hd]
+    k = kc[:, rows_t].permute(1, 0, 2).reshape(len(rows), nkv * hd)
+    vt = mm.vtc[li]                                                            # [nkv, 2*ntile, hd, 32 (perm16)]
+    tile = rows_t >> 5
+    pos = torch.as_tensor(perm_positions(32)[np.asarray(rows) & 31], dtype=torch.int64, device=mm.kc.device)
+    v = vt[:, tile, :, pos]                                                    # advanced indices separated by a slice -> [n, nkv, hd]
+    return k.float().cpu(), v.reshape(len(rows), nkv * hd).float().cpu()
+
+
+def test_stream_and_cross_attention_at_the_60_min_sizes():
+    from test_gpu_model import make, oracle_cfg
+    from vidi_amd.config import tiny
+    from vidi_amd.engine import _round_up
+    dt = torch.bfloat16
+    cfg = tiny(hidden_size=3584, intermediate_size=14336, num_attention_heads=16, num_key_value_heads=8, head_dim=256,
+               query_pre_attn_scalar=256.0, sliding_window=4096, num_hidden_layers=3, vocab_size=1024)
+    eng, w32 = make(cfg, dt, seed=5)
+    ocfg = oracle_cfg(cfg)
+    H, nkv, hd, nq = cfg.hidden_size, cfg.num_key_value_heads, cfg.head_dim, cfg.num_attention_heads
+    Nv, Na = 90000, 36000
+    g = torch.Generator(device="cuda").manual_seed(123)
+    scale_in = cfg.mm_std * eng.normalizer                                     # the magnitude the stream sees (features x sqrt(H))
+    img = (torch.randn((Nv, H), generator=g, device="cuda") * scale_in).to(dt)
+    aud = (torch.randn((Na, H), generator=g, device="cuda") * scale_in).to(dt)
+    imask = torch.ones(Nv, dtype=torch.uint8, device="cuda")
+    dead = torch.arange(1000, 90000, 173, device="cuda")                       # 515 masked image keys, spread over the tiles
+    imask[dead] = 0
+    amask = torch.ones(Na, dtype=torch.uint8, device="cuda")
+    mm = eng.mm_stream_prefill(img, imask, aud, amask, pre_normalized=True)
+    aud_start = _round_up(Nv, 64)
+    assert (mm.ntile64, mm.aud_start, mm.n_img, mm.n_aud) == ((aud_start + _round_up(Na, 64)) // 64, aud_start, Nv, Na)
+    assert mm.ntile64 * 64 == 126080 and mm.img_mask is not None and mm.aud_mask is None
+
+    # ---- sampled rows of the diagonal stream: first/last rows, 64-row tile edges, the modality boundary ----
+    rs = np.random.RandomState(7)
+    img_rows = sorted(set([0, 1, 31, 32, 63, 64, 65, 4095, 4096, 44999, 89983, 89984, 89998, 89999] + rs.randint(0, Nv, 34).tolist()))
+    aud_rows = sorted(set([0, 1, 63, 64, 35967, 35968, 35998, 35999] + rs.randint(0, Na, 8).tolist()))
+    x = torch.cat([img[torch.as_tensor(img_rows, device="cuda")], aud[torch.as_tensor(aud_rows, device="cuda")]]).float().cpu()[None]
+    keys = img_rows + [aud_start + r for r in aud_rows]
+    for li in range(cfg.num_hidden_layers):
+        x_next, kref, vref = O.mm_stream_layer(x, w32, f"model.layers.{li}.", ocfg)
+        kg, vg = _unpack_rows(mm, li, keys, nkv, hd)
+        # K/V of layer li are one bf16 GEMM of the (li times updated) stream rows: 2 % of rms + 2 % (layer 0), growing by the bf16
+        # rounding of the stream state per update
+        k = 1.0 + 0.5 * li
+        report(f"60-min-size stream: layer {li} K cache rows", kg, kref[0], 2e-2 * k * kref.std().item(), 2e-2)
+        report(f"60-min-size stream: layer {li} V cache rows", vg, vref[0], 2e-2 * k * vref.std().item(), 2e-2)
+        x = x_next
+
+    # ---- cross-attention over ALL keys of both modalities (layer 1's caches), prompt-sized query block ----
+    Lq, G = 39, nq // nkv
+    q = (torch.randn((Lq, nq * hd), generator=g, device="cuda")).to(dt)
+    sc, cap = cfg.query_pre_attn_scalar ** -0.5, cfg.attn_logit_softcapping
+    for which, n, start, mask in (("img", Nv, 0, imask), ("aud", Na, aud_start, None)):
+        out = torch.empty((Lq, nq * hd), dtype=dt, device="cuda")
+        eng._cross(q, 1, mm, which, out, R=Lq * G)
+        rows = list(range(start, start + n))
+        kk, vv = _unpack_rows(mm, 1, rows, nkv, hd)                            # [n, nkv*hd] fp32 on the host
+        add = None
+        if mask is not None:
+            add = torch.zeros((1, 1, 1, n))
+            add[..., mask.cpu() == 0] = float("-inf")
+        ref = torch.empty((Lq, nq, hd))
+        qh = q.float().cpu().view(Lq, nq, hd)
+        for h in range(nkv):                                                   # GQA: query heads h*G .. h*G+G-1 share kv head h
+            kh = kk.view(n, nkv, hd)[:, h][None, None]
+            vh = vv.view(n, nkv, hd)[:, h][None, None]
+            o = O.sdpa_reference(qh[:, h * G:(h + 1) * G].permute(1, 0, 2)[None], kh.expand(1, G, n, hd), vh.expand(1, G, n, hd), sc, cap, add)
+            ref[:, h * G:(h + 1) * G] = o[0].permute(1, 0, 2)
+        ref = ref.reshape(Lq, nq * hd)
+        # fp32 accumulation over up to 90 000 keys, bf16 P and output: 2 % of rms + 2 %
+        report(f"60-min-size cross-attention over all {n} {which} keys", out, ref, 2e-2 * ref.std().item(), 2e-2)

@@ -35,3 +35,10 @@ def test_two_rank_sharded_prefill_matches_single_rank():
     assert b["n_img_local"] == 2 * 16 and b["n_aud_local"] == 10            # rank 0 holds frames 0-1 and window 0
     report("sharded prefill hidden", b["prefill"], a["prefill"], 5e-2 * a["prefill"].std().item(), 3e-2)   # merge order differs in fp32 -> 1 bf16 ulp at the attention output
     report("sharded decode hidden", b["decode"], a["decode"], 5e-2 * a["decode"].std().item(), 3e-2)
+    # ONE packed all-gather per decoder layer per forward (numerator + (m, l) of both modalities), none on a single rank
+    assert a["collectives_per_forward"] == 0 and b["collectives_per_forward"] == b["layers"]
+    # the public API: generate() over the sharded video gives the single-rank tokens; so does a query against the resident shards
+    assert torch.equal(b["tokens_cached"], b["tokens"])
+    assert torch.equal(a["tokens"], a["tokens_cached"])
+    assert torch.equal(a["tokens"][:, :1], b["tokens"][:, :1])                # first token: margin-independent in this seeded case
+    print("greedy tokens single-rank", a["tokens"].tolist(), "two ranks", b["tokens"].tolist())   # later tokens may flip on a 1-ulp tie

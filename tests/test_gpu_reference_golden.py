@@ -1,9 +1,12 @@
 """HIP path vs golden vectors produced by EXECUTING the reference's own model code on CPU/fp32
 (tests/golden/make_golden_dattn.py, make_golden_dattn_7b.py — third-party stand-ins only).  No oracle in between:
 `VidiForCausalLM.forward/generate` on the GPU against what `DattnGemma2ForCausalLM` / `DattnMistralForCausalLM` returned.
-Tolerances: the GPU model computes in bf16/fp16 with the reference's rounding points, the goldens are fp32 — 5 % of the
-tensor's rms + 3 % relative for bf16 (1 % / 0.6 % fp16) on activations, 3x that on logits; masks bit-exact; greedy tokens
-equal wherever the golden top-2 margin exceeds the tolerance."""
+Tolerances: the GPU model computes in bf16/fp16 with the reference's rounding points, the goldens are fp32.  Activations: 5 % of
+the tensor's rms + 3 % relative for bf16 (1 % / 0.6 % fp16).  Logits: max |err| <= LOGIT_TOL x std(logits) with no relative part —
+7 % (bf16) / 1.2 % (fp16), i.e. about 2x what the kernels achieve (3.3 % observed for bf16; audited per call through
+VIDI_TEST_REPORT, tests/util.py).  Masks bit-exact.  Greedy tokens: |err| <= tol on every logit implies the same argmax wherever the
+reference's top-2 margin exceeds 2 x tol, so free-running generate() must reproduce the reference's tokens up to the first step below
+that margin (and at least 4 of them), and a teacher-forced decode (the reference's tokens fed back) must reproduce EVERY step's scores."""
 import os
 from types import SimpleNamespace
 
@@ -21,6 +24,41 @@ def tol(dt, k=1.0):
     return (5e-2 * k, 3e-2) if dt == torch.bfloat16 else (1e-2 * k, 6e-3)
 
 
+def logit_tol(dt, ref):
+    """absolute tolerance on logits: a fraction of their spread"""
+    return (7e-2 if dt == torch.bfloat16 else 1.2e-2) * float(ref.float().std())
+
+
+def check_free_running(got, ref_tok, step_logits, atol, min_agree, what):
+    """free-running greedy tokens against the reference's, up to the first step whose reference margin does not exceed 2 x atol"""
+    agreed = 0
+    for i in range(min(got.shape[1], ref_tok.shape[1])):
+        top2 = torch.topk(step_logits[i].float(), 2).values
+        if float(top2[0] - top2[1]) <= 2 * atol:
+            break                                                                # a tie within tolerance: later tokens may diverge
+        assert int(got[0, i]) == int(ref_tok[0, i]), f"{what}: token {i}: {int(got[0, i])} != reference {int(ref_tok[0, i])}"
+        agreed += 1
+    assert agreed >= min_agree, f"{what}: only {agreed} comparable greedy steps (need {min_agree})"
+    return agreed
+
+
+def teacher_forced_scores(model, ids, px, mel, sizes, ref_tok):
+    """prefill + decode with the REFERENCE's tokens fed back: returns our logits of every step [n_steps, V]"""
+    from vidi_amd.model import strip_image_token
+    eng = model.engine
+    mm = model.encode_mm_state(px, mel, sizes)
+    idt, mask, pos = strip_image_token(ids)
+    n = ref_tok.shape[1]
+    ts, last = model._prefill(idt, mask, pos, mm, n + 1)
+    out = [eng.logits_argmax(last)[0].float().cpu()[0]]
+    for i in range(n - 1):
+        emb = eng.embed_tokens(torch.tensor([int(ref_tok[0, i])], dtype=torch.int64).cuda())
+        posn = ts.n_valid.clone(); ts.n_valid += 1
+        hn = eng.text_forward(emb, posn, ts, mm, Lq=1)
+        out.append(eng.logits_argmax(hn)[0].float().cpu()[0])
+    return torch.stack(out)
+
+
 def build(cfg, dt, seed=3):
     from vidi_amd.engine import VidiEngine
     from vidi_amd.model import VidiForCausalLM
@@ -34,7 +72,7 @@ def build(cfg, dt, seed=3):
     return model
 
 
-def check_case(model, D, case, dt, n_new, with_mask=False):
+def check_case(model, D, case, dt, n_new, with_mask=False, min_agree=0):
     cfg = model.config
     t = lambda n: torch.from_numpy(D[f"{case}_{n}"])                                 # noqa: E731
     ids = t("input_ids")
@@ -44,25 +82,24 @@ def check_case(model, D, case, dt, n_new, with_mask=False):
     kw = {} if am is None else {"attention_mask": am}
     # the golden inputs are fp32; the GPU model sees them rounded to its dtype (as inference.py does with `.to(dtype)`)
     ref = t("prefill_logits")
-    atol, rtol = tol(dt, ref.std().item())
+    ltol = logit_tol(dt, ref)
     if with_mask:                                    # padded batch: each row's last VALID position, all positions checked too
         out = model.forward(ids, images=px, audios=mel, audio_sizes=sizes, logits_to_keep=0, **kw)
         tm = t("text_mask").bool()
         lens = tm.sum(-1)
         got = out.logits[torch.arange(ids.shape[0]), (lens - 1).cuda()]
-        report(f"{case} all valid positions' logits", out.logits.cpu()[tm], t("prefill_logits_all")[tm], 3 * atol, rtol)
+        report(f"{case} all valid positions' logits", out.logits.cpu()[tm], t("prefill_logits_all")[tm], ltol, 0.0)
     else:
         got = model.forward(ids, images=px, audios=mel, audio_sizes=sizes, logits_to_keep=1, **kw).logits[:, -1]
-    report(f"{case} prefill logits vs reference execution", got, ref, 3 * atol, rtol)
+    report(f"{case} prefill logits vs reference execution", got, ref, ltol, 0.0)
     if n_new:
         got = model.generate(ids, images=px, audios=mel, audio_sizes=sizes, max_new_tokens=n_new, do_sample=False).cpu()
         ref_tok = D[f"{case}_tokens"]
         logits = [ref[0]] + [x for x in torch.from_numpy(D[f"{case}_step_logits"])[0]]
-        for i in range(min(got.shape[1], ref_tok.shape[1])):
-            top2 = torch.topk(logits[i].float(), 2).values
-            if float(top2[0] - top2[1]) <= 6 * atol:
-                break                                                                # low-margin step: later tokens may diverge
-            assert int(got[0, i]) == int(ref_tok[0, i]), f"{case}: token {i}: {int(got[0, i])} != reference {int(ref_tok[0, i])}"
+        check_free_running(got, ref_tok, logits, ltol, min_agree, f"case {case}")
+        # every decode step's logits with the reference's own tokens fed back (served from the three caches like gemma.py:646-687)
+        tf = teacher_forced_scores(model, ids, px, mel, sizes, torch.from_numpy(ref_tok))
+        report(f"{case} teacher-forced step logits vs reference execution", tf, torch.stack([x.float() for x in logits[: tf.shape[0]]]), ltol, 0.0)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -77,7 +114,7 @@ def test_vidi15_against_reference_execution(dt):
     assert torch.equal(mask.bool().cpu(), torch.from_numpy(D["A_image_mask"])[0])
     ref = torch.from_numpy(D["A_image_embeds"])[0]
     report("A image_embeds vs reference execution", feats, ref, *tol(dt, ref.std().item()))
-    check_case(model, D, "A", dt, n_new=6)
+    check_case(model, D, "A", dt, n_new=6, min_agree=5)          # step 0 margin 0.19 std, steps 1-5 0.44-0.76 std: all comparable
     check_case(model, D, "B", dt, n_new=0, with_mask=True)
     check_case(model, D, "C", dt, n_new=2)
 
@@ -118,49 +155,58 @@ def test_vidi15_token_budget_branch_against_reference_execution():
     out = model.forward(torch.from_numpy(D["D_input_ids"]), images=px.to(dt).cuda(), audios=mel.to(dt).cuda(),
                         audio_sizes=D["D_audio_sizes"].tolist(), logits_to_keep=1)
     ref = torch.from_numpy(D["D_prefill_logits"])
-    atol, rtol = tol(dt, ref.std().item())
-    report("D prefill logits vs reference execution", out.logits[:, -1], ref, 3 * atol, rtol)
+    report("D prefill logits vs reference execution", out.logits[:, -1], ref, logit_tol(dt, ref), 0.0)
 
 
 def test_vidi15_generate_against_reference_generate():
-    """cases E/F: the reference's own generate() (HF greedy loop threaded by gemma.py:657-687).  Ours must return the same NEW tokens
-    wherever the reference's top-2 score margin exceeds the bf16 tolerance, and stop at EOS like it does."""
+    """cases E/F: the reference's own generate() (HF greedy loop threaded by gemma.py:657-687).  Free-running, ours must return the same
+    NEW tokens up to the first step whose top-2 margin is inside the tolerance (steps 0-4: margins 0.19-0.85 std; step 5, where the
+    reference switches 301 -> 214, has margin 0.007 std) and stop at EOS like it does; teacher-forced, ALL 8 steps' scores must match,
+    including the steps after the token change."""
     from vidi_amd.config import tiny
     dt = torch.bfloat16
     D = np.load(os.path.join(GOLD, "reference_dattn.npz"))
     cfg = tiny(sliding_window=64)
     px = torch.from_numpy(D["A_images"]).to(dt).cuda(); mel = torch.from_numpy(D["A_audios"]).to(dt).cuda()
     m6 = build(cfg, dt, seed=6)
-    got = m6.generate(torch.from_numpy(D["E_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=8, do_sample=False,
-                      use_cache=True, pad_token_id=0).cpu()
+    ids = torch.from_numpy(D["E_input_ids"])
+    got = m6.generate(ids, images=px, audios=mel, audio_sizes=[100], max_new_tokens=8, do_sample=False, use_cache=True, pad_token_id=0).cpu()
     scores = torch.from_numpy(D["E_scores"])[0]
-    atol, _ = tol(dt, scores.std().item())
-    for i in range(got.shape[1]):
+    ltol = logit_tol(dt, scores)
+    assert check_free_running(got, D["E_tokens"], scores, ltol, 5, "E generate()") >= 5
+    tf = teacher_forced_scores(m6, ids, px, mel, [100], torch.from_numpy(D["E_tokens"]))
+    report("E teacher-forced scores vs reference generate()", tf, scores, ltol, 0.0)
+    assert len(set(D["E_tokens"][0].tolist())) > 1                                   # the golden sequence is not degenerate
+    for i in range(scores.shape[0]):                                                 # same argmax wherever the margin allows: 7 of 8 steps
         top2 = torch.topk(scores[i], 2).values
-        if float(top2[0] - top2[1]) <= 6 * atol:
-            break
-        assert int(got[0, i]) == int(D["E_tokens"][0, i]), f"step {i}: {int(got[0, i])} != reference generate() {int(D['E_tokens'][0, i])}"
+        if float(top2[0] - top2[1]) > 2 * ltol:
+            assert int(tf[i].argmax()) == int(D["E_tokens"][0, i])
     m3 = build(cfg, dt, seed=3)
     got = m3.generate(torch.from_numpy(D["F_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=8, do_sample=False).cpu()
     assert got.tolist() == D["F_tokens"].tolist()                       # [[eos]]: one new token, then stop
 
 
 def test_vidi7b_generate_against_reference_generate():
-    """Vidi-7B case E: six different greedy tokens from the reference's own generate(); ours must agree wherever the margin allows"""
+    """Vidi-7B case E: six DIFFERENT greedy tokens from the reference's own generate().  Step 1's margin (0.01 std) is inside any
+    tolerance, so the free-running comparison ends there; the teacher-forced decode holds all six steps' scores to the tolerance and the
+    argmax of the five steps whose margin allows it."""
     from vidi_amd.config import tiny_7b
     dt = torch.bfloat16
     D = np.load(os.path.join(GOLD, "reference_dattn_7b.npz"))
     cfg = tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64)
     m6 = build(cfg, dt, seed=6)
     px = torch.from_numpy(D["A_images"]).to(dt).cuda(); mel = torch.from_numpy(D["A_audios"]).to(dt).cuda()
-    got = m6.generate(torch.from_numpy(D["A_input_ids"]), images=px, audios=mel, audio_sizes=[100], max_new_tokens=6, do_sample=False).cpu()
+    ids = torch.from_numpy(D["A_input_ids"])
+    got = m6.generate(ids, images=px, audios=mel, audio_sizes=[100], max_new_tokens=6, do_sample=False).cpu()
     scores = torch.from_numpy(D["E_scores"])[0]
-    atol, _ = tol(dt, scores.std().item())
+    ltol = logit_tol(dt, scores)
+    check_free_running(got, D["E_tokens"], scores, ltol, 1, "7B E generate()")
+    tf = teacher_forced_scores(m6, ids, px, mel, [100], torch.from_numpy(D["E_tokens"]))
+    report("7B E teacher-forced scores vs reference generate()", tf, scores, ltol, 0.0)
     agreed = 0
-    for i in range(got.shape[1]):
+    for i in range(scores.shape[0]):
         top2 = torch.topk(scores[i], 2).values
-        if float(top2[0] - top2[1]) <= 6 * atol:
-            break
-        assert int(got[0, i]) == int(D["E_tokens"][0, i]), f"step {i}: {int(got[0, i])} != reference generate() {int(D['E_tokens'][0, i])}"
-        agreed += 1
-    assert agreed >= 1
+        if float(top2[0] - top2[1]) > 2 * ltol:
+            assert int(tf[i].argmax()) == int(D["E_tokens"][0, i])
+            agreed += 1
+    assert agreed >= 4 and len(set(D["E_tokens"][0].tolist())) >= 4

@@ -1,0 +1,123 @@
+"""Frame/window sharding of one video over ranks — the host bookkeeping of the PRODUCT code on CPU:
+
+* vidi_amd/shard.py: frame / window ranges, the audio-token range a window shard owns, the packed all-gather layout;
+* vidi_amd/model.py `VidiForCausalLM.encode_mm_state / generate` under `engine.set_dist()` with world 2 and 3 over gloo: every rank
+  is handed the same video, keeps its share, and must produce the single-rank answer.  The numerics engine of this CPU test is the
+  oracle behind VidiEngine's interface (tests/oracle_engine.py), which also asserts the offsets / totals / whole-sample flags the
+  product passes; the HIP engine runs the same product path in tests/test_gpu_dist.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from vidi_amd import shard as S
+
+
+def test_shards_tile_the_range():
+    for n, world in [(3600, 8), (3600, 1), (120, 8), (7, 8), (300, 4), (0, 2), (1, 2)]:
+        cuts = [S.shard(n, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sizes = [e - s for s, e in cuts]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        S.shard(4, 2, 2)
+
+
+@pytest.mark.parametrize("audio_size,world", [(360000, 8), (173, 2), (173, 3), (2999, 2), (3001, 2), (90000, 7), (100, 4)])
+def test_audio_window_shards_tile_the_global_token_range(audio_size, world):
+    """rank shards of 30-s windows own disjoint, ordered, complete ranges of the GLOBAL pooled audio tokens
+    (floor(floor(size * 1500 / 3000) / 5), multimodal.py:226-235), including the clipped last window and empty shards."""
+    rows, pool = 1500, 5
+    C = -(-audio_size // 3000)
+    s1 = int(np.floor(np.array([audio_size]) * (1500 / 3000)).astype(int)[0])
+    total = int(np.floor(np.array([s1]) / pool).astype(int)[0])
+    nxt = 0
+    for r in range(world):
+        sh = S.video_shard(0, C, world, r)
+        tok0, n = S.audio_shard_tokens(sh.c0, sh.windows, rows, pool, total)
+        assert n >= 0
+        if n:
+            assert tok0 == nxt
+            nxt = tok0 + n
+    assert nxt == total
+    with pytest.raises(ValueError):
+        S.audio_shard_tokens(0, 1, 1501, 5, 10)
+
+
+def test_packed_partial_layout():
+    nkv, R, hd = 8, 78, 256
+    tot = S.packed_partial_floats(2, nkv, R, hd)
+    o0, m0 = S.packed_offsets(0, nkv, R, hd)
+    o1, m1 = S.packed_offsets(1, nkv, R, hd)
+    assert (o0, m0, o1, m1) == (0, nkv * R * hd, nkv * R * (hd + 2), nkv * R * (hd + 2) + nkv * R * hd)
+    assert m1 + nkv * R * 2 == tot
+    assert tot * 4 == 2 * 8 * 78 * 258 * 4                      # 1.29 MB per rank per layer at the 39-token prefill; 33 KB at decode
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, frames, windows, audio_size, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from oracle_engine import OracleEngine
+    from util import seeded
+    from vidi_amd.config import tiny
+    from vidi_amd.model import VidiForCausalLM
+    from vidi_amd.weights import init_random_weights
+    torch.set_num_threads(2)
+    cfg = tiny()
+    w = init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu")
+    eng = OracleEngine(cfg, w)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        eng.set_dist(None)
+    model = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=eng)
+    px = seeded((frames, 3, cfg.vis_image_size, cfg.vis_image_size), 200, 0.5).clamp(-1, 1)
+    mel = seeded((windows, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 201, 0.3)
+    ids = torch.tensor([[2, 21, 22, -200, 23, 24, 25]], dtype=torch.int64)
+    out = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=5, do_sample=False)
+    ret.put((rank, out.tolist(), getattr(eng, "last_shard", None)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world, frames, windows, audio_size):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frames, windows, audio_size, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(ret.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("world,frames", [(2, 5), (3, 2)])
+def test_generate_under_set_dist_shards_the_video_and_reproduces_single_rank(world, frames):
+    """world 3 with 2 frames leaves rank 2 without a frame (empty shard); 2 windows over 3 ranks likewise"""
+    windows, audio_size = 2, 173
+    ref = _run(1, frames, windows, audio_size)[0][1]
+    got = _run(world, frames, windows, audio_size)
+    for rank, toks, sh in got:
+        assert toks == ref, (rank, toks, ref)
+        f0, f1 = S.shard(frames, world, rank)
+        assert sh == dict(kind="img", local=f1 - f0, off=f0, total=frames)          # what the product handed this rank's engine

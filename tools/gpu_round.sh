@@ -1,0 +1,32 @@
+#!/bin/bash
+# One GPU-box session: GPU parity suite (with the tolerance-slack audit), smoke, bench, rocprofv3 kernel stats, PMC traffic passes.
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tests|bench|prof|pmc|smoke ...]   (default: all)
+set -u
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+what=${@:-tests smoke bench prof pmc}
+for w in $what; do
+case $w in
+tests)
+  rm -f $OUT/tol_audit.jsonl
+  VIDI_TEST_REPORT=$OUT/tol_audit.jsonl timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest.log 2>&1
+  echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
+smoke)
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $OUT/smoke.log ;;
+bench)
+  timeout 1200 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; python tools/show_bench.py $OUT/bench.json 2>/dev/null | head -40 ;;
+prof)
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r2 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc > $OUT/prof_bench.json 2> $OUT/prof.err)
+  echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3 ;;
+pmc)
+  CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc"
+  (cd /tmp && timeout 1200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err); echo "fetch rc=$?"
+  (cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err); echo "write rc=$?"
+  F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
+  python tools/traffic_from_pmc.py "$F" "$W" $OUT/traffic.json 3600 vidi15_9b | head -c 1500
+  # keep only the small summaries (the raw per-dispatch CSVs are tens of MB)
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write ;;
+esac
+done

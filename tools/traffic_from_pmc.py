@@ -1,21 +1,46 @@
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into HBM bytes per GEMM launch.
-FETCH_SIZE/WRITE_SIZE are in KiB-ish units of 1024 B? (rocprofv3 reports kilobytes); on gfx950 FETCH_SIZE under-reports
-wide coalesced streaming reads by exactly 2x (MI355X_MICROARCH.md §HBM) -> corrected here.
-usage: traffic_from_pmc.py fetch_counter_collection.csv write_counter_collection.csv out.json"""
-import csv, json, sys
-def agg(path, counter, pat="gemm_kernel"):
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into fabric-side bytes per GEMM launch.
+
+rocprofv3 reports both counters in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x
+(MI355X_MICROARCH.md, HBM section) -> corrected here.  Both counters sit on the L2's memory side: Infinity-Cache hits are counted,
+so the sum is an UPPER bound on HBM traffic (same guide).  The output is keyed by the digest of the GEMM sources it was collected
+on; bench.py refuses to attach it to any other build.
+
+usage: traffic_from_pmc.py fetch_counter_collection.csv write_counter_collection.csv out.json [frames] [preset] [command]"""
+import csv
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PAT = re.compile(r"gemm_w4_kernel|gemm_kernel<|gemm_kernel\(")
+
+
+def agg(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and pat in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and PAT.search(r["Kernel_Name"]):
             tot += float(r["Counter_Value"]); n += 1
     return tot, n
-f, nf = agg(sys.argv[1], "FETCH_SIZE")
-w, nw = agg(sys.argv[2], "WRITE_SIZE")
-out = {"kernel_family": "gemm_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
-       "fetch_bytes_per_launch_raw": f * 1024 / max(nf, 1), "fetch_bytes_per_launch_corrected_x2": 2 * f * 1024 / max(nf, 1),
-       "write_bytes_per_launch": w * 1024 / max(nw, 1),
-       "hbm_bytes_per_launch": (2 * f + w) * 1024 / max(nf, 1),
-       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline`; "
-               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out))
+
+
+def main():
+    from vidi_amd.build import source_digest
+    f, nf = agg(sys.argv[1], "FETCH_SIZE")
+    w, nw = agg(sys.argv[2], "WRITE_SIZE")
+    out = {"kernel_family": "gemm_w4_kernel + gemm_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
+           "fetch_bytes_per_launch_raw": f * 1024 / max(nf, 1), "fetch_bytes_per_launch_corrected_x2": 2 * f * 1024 / max(nf, 1),
+           "write_bytes_per_launch": w * 1024 / max(nw, 1),
+           "hbm_bytes_per_launch": (2 * f * 1024 / max(nf, 1)) + (w * 1024 / max(nw, 1)),
+           "gemm_source_digest": source_digest("gemm"),
+           "frames": int(sys.argv[4]) if len(sys.argv) > 4 else 3600, "preset": sys.argv[5] if len(sys.argv) > 5 else "vidi15_9b",
+           "command": sys.argv[6] if len(sys.argv) > 6 else "python bench.py --no-cpu-baseline --no-kernel-timer --no-preproc --steps 1 --warmup 0 --decode-steps 2",
+           "file": "profiles/traffic.json",
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
+                   "counts 128-B requests at 64 B); fabric-side counters: Infinity-Cache hits included (upper bound on HBM bytes)"}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

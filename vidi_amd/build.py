@@ -39,6 +39,16 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
+GEMM_FILES = ["gemm.hip", "gemm_w4_bf16.hip", "gemm_w4_f16.hip", "gemm_w4_modes.hip", "gemm_tile.h", "gemm_w4.h", "gemm_w4_launch.h", "common.h", "kernels.h"]
+
+
+def source_digest(which: str = "all") -> str:
+    """Short digest of the kernel sources + compile flags: identifies a build's code independently of when it was compiled.
+    `gemm`: only the files the GEMM family is built from — profiles/traffic.json (PMC passes) is keyed by it (bench.py)."""
+    files = GEMM_FILES if which == "gemm" else sorted(set(SOURCES) | {h for h in HEADERS if not h.startswith("..")})
+    return _digest([os.path.join(CSRC, f) for f in files])[:16]
+
+
 def _compile(src: str, force: bool) -> str:
     os.makedirs(OBJ, exist_ok=True)
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))

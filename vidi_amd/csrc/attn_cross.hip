@@ -276,9 +276,9 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
         __syncthreads();
         const int nw = min(256, p.W - w0);
         for (int w = d; w < nw; w += HD) {
-            const size_t base = ((size_t)(w0 + w) * p.nkv + kvh) * p.Rpad + r;
-            s_m[w] = p.ML[base * 2];
-            s_l[w] = p.ML[base * 2 + 1];
+            const size_t base = (size_t)(w0 + w) * p.wsML + ((size_t)kvh * p.Rpad + r) * 2;
+            s_m[w] = p.ML[base];
+            s_l[w] = p.ML[base + 1];
         }
         __syncthreads();
         for (int w = 0; w < nw; ++w) m = fmaxf(m, s_m[w]);
@@ -290,9 +290,9 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
             if (p.W > 256) {                                            // re-stage this window (single window: still resident)
                 __syncthreads();
                 for (int w = d; w < nw; w += HD) {
-                    const size_t base = ((size_t)(w0 + w) * p.nkv + kvh) * p.Rpad + r;
-                    s_m[w] = p.ML[base * 2];
-                    s_l[w] = p.ML[base * 2 + 1];
+                    const size_t base = (size_t)(w0 + w) * p.wsML + ((size_t)kvh * p.Rpad + r) * 2;
+                    s_m[w] = p.ML[base];
+                    s_l[w] = p.ML[base + 1];
                 }
                 __syncthreads();
             }
@@ -301,7 +301,7 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
                 const float mw = s_m[w];
                 const float sc = (mw == -INFINITY) ? 0.f : fast_exp2(mw - m);
                 den += sc * s_l[w];
-                const float v = p.Opart[(((size_t)(w0 + w) * p.nkv + kvh) * p.Rpad + r) * HD + d];
+                const float v = p.Opart[(size_t)(w0 + w) * p.wsO + ((size_t)kvh * p.Rpad + r) * HD + d];
                 num += (mw == -INFINITY) ? 0.f : sc * v;                // a skipped partial may hold stale (even non-finite) data
             }
         }
@@ -311,7 +311,7 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
     float out = (den > 0.f && !p.zero_out) ? num / den : 0.f;
     if (p.Out) p.Out[oidx] = T::from_f32(out);
     // partial form (same layout as one slice of Opart/ML): lets a second merge combine per-GPU results
-    const size_t pbase = (size_t)kvh * p.Rpad + r;
+    const size_t pbase = (size_t)kvh * p.rpo + r;
     if (p.OutF32) p.OutF32[pbase * HD + d] = num;
     if (p.OutML && d == 0) {
         p.OutML[pbase * 2] = m;
@@ -325,11 +325,14 @@ __global__ __launch_bounds__(HD) void attn_merge_kernel(AttnMergeParams p) { att
 // two independent merges (the T2V and the T2A partials of one layer) in one launch: blockIdx.z picks the set
 template <typename T, int HD>
 __global__ __launch_bounds__(HD) void attn_merge2_kernel(AttnMergeParams a, AttnMergeParams b) {
-    if (blockIdx.z == 0) attn_merge_body<T, HD>(a); else attn_merge_body<T, HD>(b);
+    const AttnMergeParams& p = blockIdx.z == 0 ? a : b;
+    if (!p.Out && !p.OutF32) return;                        // absent set (a modality the sample does not have)
+    attn_merge_body<T, HD>(p);
 }
 
 int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b, int HD, int dtype, hipStream_t st) {
-    if (a.R <= 0 || a.W <= 0 || b.W <= 0 || a.R != b.R || a.nkv != b.nkv) return VIDI_ERR_SHAPE;
+    // W == 0: a rank that holds no key of the modality emits the neutral partial (m = -inf, l = 0, numerator 0)
+    if (a.R <= 0 || a.W < 0 || b.W < 0 || a.R != b.R || a.nkv != b.nkv) return VIDI_ERR_SHAPE;
     const dim3 grid(a.R, a.nkv, 2);
     if (dtype == VIDI_DT_BF16) {
         if (HD == 256) hipLaunchKernelGGL((attn_merge2_kernel<BF16, 256>), grid, dim3(256), 0, st, a, b);

@@ -146,6 +146,7 @@ int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF3
     AttnMergeParams p;
     p.Opart = Opart; p.ML = ML; p.Out = (u16*)Out; p.OutF32 = OutF32; p.OutML = OutML;
     p.W = W; p.nkv = nkv; p.R = R; p.Rpad = Rpad; p.G = G; p.ldo = ldo; p.zero_out = zero_out;
+    p.wsO = (long long)nkv * Rpad * HD; p.wsML = (long long)nkv * Rpad * 2; p.rpo = Rpad;
     return vidi_attn_merge_dispatch(p, HD, dtype, (hipStream_t)stream);
 }
 
@@ -157,8 +158,29 @@ int vidi_attn_merge2(const float* OpartA, const float* MLA, void* OutA, int WA, 
     AttnMergeParams a, b;
     a.Opart = OpartA; a.ML = MLA; a.Out = (u16*)OutA; a.OutF32 = nullptr; a.OutML = nullptr;
     a.W = WA; a.nkv = nkv; a.R = R; a.Rpad = Rpad; a.G = G; a.ldo = ldo; a.zero_out = zeroA;
+    a.wsO = (long long)nkv * Rpad * HD; a.wsML = (long long)nkv * Rpad * 2; a.rpo = Rpad;
     b = a;
     b.Opart = OpartB; b.ML = MLB; b.Out = (u16*)OutB; b.W = WB; b.zero_out = zeroB;
+    if (WA <= 0 || WB <= 0) return VIDI_ERR_SHAPE;
+    return vidi_attn_merge2_dispatch(a, b, HD, dtype, (hipStream_t)stream);
+}
+
+int vidi_attn_merge2_sharded(const float* OpartA, const float* MLA, long long wsOA, long long wsMLA, void* OutA, float* OutF32A,
+                             float* OutMLA, int WA, int zeroA,
+                             const float* OpartB, const float* MLB, long long wsOB, long long wsMLB, void* OutB, float* OutF32B,
+                             float* OutMLB, int WB, int zeroB,
+                             int nkv, int R, int Rpad, int rpo, int G, int HD, int ldo, int dtype, void* stream) {
+    (void)hipGetLastError();
+    const bool hasA = OutA || OutF32A, hasB = OutB || OutF32B;
+    if (!hasA && !hasB) return VIDI_ERR_ARG;
+    if ((hasA && WA > 0 && (!OpartA || !MLA)) || (hasB && WB > 0 && (!OpartB || !MLB))) return VIDI_ERR_ARG;
+    if ((OutF32A && !OutMLA) || (OutF32B && !OutMLB) || rpo < R) return VIDI_ERR_ARG;
+    AttnMergeParams a, b;
+    a.Opart = OpartA; a.ML = MLA; a.Out = (u16*)OutA; a.OutF32 = OutF32A; a.OutML = OutMLA;
+    a.W = WA; a.nkv = nkv; a.R = R; a.Rpad = Rpad; a.G = G; a.ldo = ldo; a.zero_out = zeroA; a.wsO = wsOA; a.wsML = wsMLA; a.rpo = rpo;
+    b = a;
+    b.Opart = OpartB; b.ML = MLB; b.Out = (u16*)OutB; b.OutF32 = OutF32B; b.OutML = OutMLB;
+    b.W = WB; b.zero_out = zeroB; b.wsO = wsOB; b.wsML = wsMLB;
     return vidi_attn_merge2_dispatch(a, b, HD, dtype, (hipStream_t)stream);
 }
 

@@ -58,6 +58,8 @@ struct AttnMergeParams {
     const float* Opart; const float* ML; u16* Out; float* OutF32; float* OutML;
     int W, nkv, R, Rpad, G, ldo;
     int zero_out;            // 1: sample has no valid key at all -> output zeros (gemma.py:180-192)
+    long long wsO, wsML;     // floats between successive partials w in Opart / ML (nkv*Rpad*HD and nkv*Rpad*2 when contiguous)
+    int rpo;                 // row stride of the partial-form outputs OutF32 / OutML (Rpad, or a tighter packing for the all-gather)
 };
 
 struct AttnTextParams {

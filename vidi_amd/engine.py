@@ -109,6 +109,7 @@ class VidiEngine:
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._ws: Dict[str, torch.Tensor] = {}
         self.pg, self.world, self.rank = None, 1, 0
+        self.n_collectives = 0                          # data-path all-gathers issued (one per decoder layer per forward when sharded)
 
     # -----------------------------------------------------------------------------------------
     # weight packing (one-time repack into kernel-preferred layouts; owned by this module)
@@ -245,6 +246,16 @@ class VidiEngine:
             return hip.gemv(x, w, out)
         return hip.gemm(x, w, None, out)
 
+    def sample_flag(self, x: torch.Tensor) -> torch.Tensor:
+        """int32[1] device flag "the sample holds any non-zero value" (`torch.sum(torch.abs(x)) != 0`, multimodal.py:202, 246) of a
+        WHOLE sample; the sharded encode passes it in because a rank only sees its own frames / windows."""
+        flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if x.is_cuda:
+            hip.any_nonzero(x.to(self.dtype).contiguous().view(-1), flag)
+        elif bool((x != 0).any()):                  # host tensor (the CLI hands over CPU frames): a host reduction, no full-video upload
+            flag.fill_(1)
+        return flag
+
     def pos_table(self, which: str, l: int, N: int, i0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
         """rms_norm(LearnablePosEmbd(...)) rows [i0, i0+rows) of l — pos.py:41-65, multimodal.py:194-197."""
         rows = l if rows is None else rows
@@ -302,6 +313,8 @@ class VidiEngine:
         T = pixel.shape[0]
         Ttot = total_frames if total_frames is not None else T
         side, pool, Hv, H = cfg.vis_side, cfg.mm_image_pool_size, cfg.vis_hidden_size, cfg.hidden_size
+        if T == 0:                                  # a rank whose frame shard is empty (more ranks than frames)
+            return (torch.empty((0, H), dtype=self.dtype, device=self.dev), torch.empty((0,), dtype=torch.uint8, device=self.dev))
         f = self.siglip_forward(pixel) if vis_features is None else vis_features
         if self.mistral:
             # Vidi-7B: learned conv (k = ceil(side/pool), stride 1) -> bilinear(align_corners=True) to pool x pool
@@ -400,16 +413,17 @@ class VidiEngine:
         `audio_size` is always the GLOBAL mel-frame count (the floors of multimodal.py:226-235 are global)."""
         cfg = self.cfg
         H, Da, pool = cfg.hidden_size, cfg.aud_d_model, cfg.mm_audio_pool_size
+        if mel.shape[0] == 0 and aud_features is None:          # a rank whose window shard is empty
+            if audio_token_counts(audio_size, cfg)[1] < 2:
+                raise ValueError("LearnablePosEmbd requires more than one audio token (pos.py:42)")
+            return (torch.empty((0, H), dtype=self.dtype, device=self.dev), torch.empty((0,), dtype=torch.uint8, device=self.dev))
         f = self.whisper_forward(mel) if aud_features is None else aud_features              # [C, 1500, Da]
         s1, s2_total = audio_token_counts(audio_size, cfg)
         flat = f.reshape(-1, Da)
         if s2_total < 2:
             raise ValueError("LearnablePosEmbd requires more than one audio token (pos.py:42)")
-        N = f.shape[1]
-        if N % pool:
-            raise ValueError("encoder rows per window must be a multiple of the audio pool size to shard by window")
-        tok0 = chunk_offset * (N // pool)                          # first global token of this shard
-        s2 = max(0, min(s2_total - tok0, f.shape[0] * (N // pool)))
+        from .shard import audio_shard_tokens
+        tok0, s2 = audio_shard_tokens(chunk_offset, f.shape[0], f.shape[1], pool, s2_total)   # first global token / count of this shard
         if s2 == 0:
             return (torch.empty((0, H), dtype=self.dtype, device=self.dev), torch.empty((0,), dtype=torch.uint8, device=self.dev))
         # Conv1d(k=pool, s=pool, no bias) over the first s1 rows == GEMM on a [s2, pool*Da] view
@@ -527,14 +541,14 @@ class VidiEngine:
                 self._rope_cache = (emb.cos().to(self.dtype).to(self.dev), emb.sin().to(self.dtype).to(self.dev))
         return self._rope_cache
 
-    def _cross(self, q: torch.Tensor, li: int, mm: MMState, which: str, out: torch.Tensor, R: int, defer_merge: bool = False):
+    def _cross_local(self, q: torch.Tensor, li: int, mm: MMState, which: str, R: int):
+        """Split-KV cross-attention of R query rows over this rank's keys of one modality -> (Opart, ML, zsplit, n_local_keys)."""
         cfg = self.cfg
         nkv, hd = cfg.num_key_value_heads, cfg.head_dim
         G = cfg.num_attention_heads // nkv
         n = mm.n_img if which == "img" else mm.n_aud
         start = mm.img_start if which == "img" else mm.aud_start
         mask = mm.img_mask if which == "img" else mm.aud_mask
-        any_valid = mm.img_any_valid if which == "img" else mm.aud_any_valid
         Rpad = _round_up(R, 32)
         nsub = (n + 31) // 32
         row_tiles = Rpad // 32
@@ -548,31 +562,58 @@ class VidiEngine:
             hip.attn_cross(q, mm.kc[li], mm.vtc[li], mask, opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
                            key_start=start, n_keys=n, scale=cfg.query_pre_attn_scalar ** -0.5,
                            softcap=cfg.attn_logit_softcapping, zsplit=zsplit)
-        if self.world == 1:
-            if defer_merge and n > 0:
-                return (opart, ml, out, zsplit, not any_valid)      # merged together with the other modality (attn_merge2)
-            hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
-            return None
-        # ---- keys are sharded over ranks: local merge -> partial form -> all-gather -> exact LSE merge ----
-        import torch.distributed as dist
-        pk = f"xattn_part_{Rpad}"
+        return opart, ml, zsplit, n
+
+    def _cross(self, q: torch.Tensor, li: int, mm: MMState, which: str, out: torch.Tensor, R: int, defer_merge: bool = False):
+        """single-GPU T2V / T2A: all keys are local"""
+        cfg = self.cfg
+        nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+        G = cfg.num_attention_heads // nkv
+        any_valid = mm.img_any_valid if which == "img" else mm.aud_any_valid
+        Rpad = _round_up(R, 32)
+        opart, ml, zsplit, n = self._cross_local(q, li, mm, which, R)
+        if defer_merge and n > 0:
+            return (opart, ml, out, zsplit, not any_valid)      # merged together with the other modality (attn_merge2)
+        hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+        return None
+
+    def _cross_sharded(self, q: torch.Tensor, li: int, mm: MMState, outs: Dict[str, torch.Tensor], R: int):
+        """T2V + T2A of one layer with the keys sharded over ranks.  Per rank: split-KV partials over the local keys ->
+        ONE launch folds them into the partial form (numerator, m, l) of both modalities, written straight into a packed send
+        buffer -> ONE all-gather (RCCL) per layer -> ONE launch merges the world's partials of both modalities (exact: the tanh
+        softcap is per logit, the merge is the LSE identity flash-attn itself uses between key blocks).
+        `outs`: {"img": [M, nq*hd] slice, "aud": ...} for the modalities the SAMPLE has (a global property)."""
+        from .shard import packed_offsets, packed_partial_floats
+        cfg = self.cfg
+        nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+        G = cfg.num_attention_heads // nkv
+        Rpad = _round_up(R, 32)
+        mods = [w for w in ("img", "aud") if w in outs]
+        total = packed_partial_floats(len(mods), nkv, R, hd)
+        pk = f"xattn_pack_{len(mods)}_{R}"
         if pk not in self._ws:
-          with torch.inference_mode(False):
-            self._ws[pk] = (torch.zeros((nkv, Rpad, hd), dtype=torch.float32, device=self.dev),
-                            torch.zeros((nkv, Rpad, 2), dtype=torch.float32, device=self.dev),
-                            torch.zeros((self.world, nkv, Rpad, hd), dtype=torch.float32, device=self.dev),
-                            torch.zeros((self.world, nkv, Rpad, 2), dtype=torch.float32, device=self.dev))
-        po, pml, gpo, gpml = self._ws[pk]
-        if n > 0:
-            hip.attn_merge(opart, ml, None, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, out_f32=po, out_ml=pml,
-                           dtype=hip._dt(out))
-        else:                                   # this rank holds no key of the modality: neutral partial
-            po.zero_()
-            pml[..., 0] = float("-inf")
-            pml[..., 1] = 0.0
-        self._all_gather(gpo, po)
-        self._all_gather(gpml, pml)
-        hip.attn_merge(gpo, gpml, out, W=self.world, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
+            with torch.inference_mode(False):
+                self._ws[pk] = (torch.zeros((total,), dtype=torch.float32, device=self.dev),
+                                torch.zeros((self.world, total), dtype=torch.float32, device=self.dev))
+        send, recv = self._ws[pk]
+        flat = recv.view(-1)
+        local_sets, final_sets = [None, None], [None, None]
+        ldo = None
+        for slot, which in enumerate(mods):
+            opart, ml, zsplit, n = self._cross_local(q, li, mm, which, R)
+            o_off, ml_off = packed_offsets(slot, nkv, R, hd)
+            any_valid = mm.img_any_valid if which == "img" else mm.aud_any_valid
+            # a rank that holds no key of the modality contributes the neutral partial (W = 0 -> m = -inf, l = 0)
+            local_sets[slot] = dict(opart=opart if n > 0 else None, ml=ml if n > 0 else None, ws_o=nkv * Rpad * hd, ws_ml=nkv * Rpad * 2,
+                                    W=zsplit if n > 0 else 0, out_f32=send[o_off:], out_ml=send[ml_off:])
+            final_sets[slot] = dict(opart=flat[o_off:], ml=flat[ml_off:], ws_o=total, ws_ml=total, W=self.world, out=outs[which],
+                                    zero=not any_valid)
+            ldo = outs[which].stride(0)
+        dt = hip._dt(outs[mods[0]])
+        hip.attn_merge2_sharded(local_sets, nkv=nkv, R=R, Rpad=Rpad, rpo=R, G=G, HD=hd, ldo=ldo, dtype=dt)
+        self._all_gather(recv, send)
+        self.n_collectives += 1
+        hip.attn_merge2_sharded(final_sets, nkv=nkv, R=R, Rpad=R, rpo=R, G=G, HD=hd, ldo=ldo, dtype=dt)
 
     # -----------------------------------------------------------------------------------------
     # multi-GPU (one process per GPU, RCCL): frame/chunk-sharded keys, replicated text stream
@@ -653,20 +694,29 @@ class VidiEngine:
             k = 1
             qraw = qkv[:, :nqd]
             G = nq // nkv
-            both = has_img and has_aud and self.world == 1
-            pend = []
-            if has_img:
-                pend.append(self._cross(qraw, li, mm, "img", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
-            if has_aud:
-                pend.append(self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
-            if both:
-                if pend[0] is not None and pend[1] is not None:     # T2V and T2A partials merged by one launch
-                    (oa, mla, outa, wa, za), (ob, mlb, outb, wb, zb) = pend
-                    hip.attn_merge2(oa, mla, outa, wa, za, ob, mlb, outb, wb, zb, nkv=nkv, R=M * G, Rpad=_round_up(M * G, 32), G=G, HD=hd)
-                else:
-                    for pd in pend:
-                        if pd is not None:
-                            hip.attn_merge(pd[0], pd[1], pd[2], W=pd[3], nkv=nkv, R=M * G, Rpad=_round_up(M * G, 32), G=G, HD=hd, zero_out=pd[4])
+            if self.world > 1:
+                outs = {}
+                if has_img:
+                    outs["img"] = att[k * M: (k + 1) * M]; k += 1
+                if has_aud:
+                    outs["aud"] = att[k * M: (k + 1) * M]; k += 1
+                if outs:
+                    self._cross_sharded(qraw, li, mm, outs, R=M * G)
+            else:
+                both = has_img and has_aud
+                pend = []
+                if has_img:
+                    pend.append(self._cross(qraw, li, mm, "img", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
+                if has_aud:
+                    pend.append(self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
+                if both:
+                    if pend[0] is not None and pend[1] is not None:     # T2V and T2A partials merged by one launch
+                        (oa, mla, outa, wa, za), (ob, mlb, outb, wb, zb) = pend
+                        hip.attn_merge2(oa, mla, outa, wa, za, ob, mlb, outb, wb, zb, nkv=nkv, R=M * G, Rpad=_round_up(M * G, 32), G=G, HD=hd)
+                    else:
+                        for pd in pend:
+                            if pd is not None:
+                                hip.attn_merge(pd[0], pd[1], pd[2], W=pd[3], nkv=nkv, R=M * G, Rpad=_round_up(M * G, 32), G=G, HD=hd, zero_out=pd[4])
             # one o_proj pass over the stacked [text; image; audio] attention outputs (gemma.py:94 x3)
             self.proj(att[: nstream * M], L["wo"], oall[: nstream * M])
             if self.mistral:

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_merge2": [_c_vp] * 3 + [_c_int] * 2 + [_c_vp] * 3 + [_c_int] * 2 + [_c_int] * 7 + [_c_vp],
+    "vidi_attn_merge2_sharded": ([_c_vp] * 2 + [_c_ll] * 2 + [_c_vp] * 3 + [_c_int] * 2) * 2 + [_c_int] * 8 + [_c_vp],
     "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text_dyn": [_c_vp] * 5 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
@@ -353,6 +354,24 @@ def attn_merge2(opart_a, ml_a, out_a, W_a, zero_a, opart_b, ml_b, out_b, W_b, ze
     assert out_a.stride(0) == out_b.stride(0)
     _check(lib.vidi_attn_merge2(_p(opart_a), _p(ml_a), _p(out_a), W_a, 1 if zero_a else 0, _p(opart_b), _p(ml_b), _p(out_b), W_b,
                                 1 if zero_b else 0, nkv, R, Rpad, G, HD, out_a.stride(0), _dt(out_a), _stream()), "vidi_attn_merge2")
+
+
+def attn_merge2_sharded(sets, *, nkv, R, Rpad, rpo, G, HD, ldo, dtype):
+    """Both modalities' merges of one layer in one launch, with explicit partial strides (frame-sharded keys).
+    `sets`: two entries (T2V, T2A), each None (modality absent) or a dict with
+       opart, ml     fp32 partial buffers (may be None when W == 0: the neutral partial of a rank without keys)
+       ws_o, ws_ml   floats between successive partials;  W: number of partials
+       out           [tokens, ldo] model-dtype output or None;  out_f32 / out_ml: partial-form outputs (row stride rpo) or None
+       zero          sample has no valid key (gemma.py:180-192)"""
+    lib = load_library()
+    args = []
+    for s_ in sets:
+        if s_ is None:
+            args += [None, None, 0, 0, None, None, None, 0, 0]
+        else:
+            args += [_p(s_.get("opart")), _p(s_.get("ml")), int(s_["ws_o"]), int(s_["ws_ml"]), _p(s_.get("out")), _p(s_.get("out_f32")),
+                     _p(s_.get("out_ml")), int(s_["W"]), 1 if s_.get("zero") else 0]
+    _check(lib.vidi_attn_merge2_sharded(*args, nkv, R, Rpad, rpo, G, HD, ldo, dtype, _stream()), "vidi_attn_merge2_sharded")
 
 
 def attn_text(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len, window, scale, softcap):

@@ -156,16 +156,32 @@ class VidiForCausalLM:
         return fi, mi, fa, ma
 
     def encode_mm_state(self, images, audios, audio_sizes) -> MMState:
-        """encode + run the query-independent multimodal stream through all layers (caches)."""
+        """encode + run the query-independent multimodal stream through all layers (caches).
+
+        Under `engine.set_dist(...)` (one process per GPU) every rank is handed the SAME video and keeps only its share: a
+        contiguous range of frames and of 30-s audio windows (vidi_amd/shard.py), encoded with the global positions, streamed
+        through the 42 layers locally (the diagonal stream never mixes tokens) and left resident as this rank's K/V shard.
+        The flags the reference derives from the whole sample (`images.sum() != 0`, multimodal.py:203-206, 247-250) are taken
+        from the whole sample here too."""
         eng = self.engine
         img = self._single(images, "images")
         aud = self._single(audios, "audios")
         fi = mi = fa = ma = None
         nz = eng.normalizer
+        kw_i, kw_a = {}, {}
+        if eng.world > 1:
+            from .shard import video_shard
+            sh = video_shard(0 if img is None else int(img.shape[0]), 0 if aud is None else int(aud.shape[0]), eng.world, eng.rank)
+            if img is not None:
+                kw_i = dict(frame_offset=sh.f0, total_frames=sh.total_frames, sample_flag=eng.sample_flag(img))
+                img = img[sh.f0: sh.f1]
+            if aud is not None:
+                kw_a = dict(chunk_offset=sh.c0, sample_flag=eng.sample_flag(aud))
+                aud = aud[sh.c0: sh.c1]
         if img is not None:
-            fi, mi = eng.encode_video_images(img.to(eng.dev), normalizer=nz)
+            fi, mi = eng.encode_video_images(img.to(eng.dev), normalizer=nz, **kw_i)
         if aud is not None:
-            fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]), normalizer=nz)
+            fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]), normalizer=nz, **kw_a)
         st = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
         st.image_attention_mask, st.audio_attention_mask = mi, ma
         return st
