@@ -62,11 +62,11 @@ def test_stream_and_cross_attention_at_the_60_min_sizes():
     for li in range(cfg.num_hidden_layers):
         x_next, kref, vref = O.mm_stream_layer(x, w32, f"model.layers.{li}.", ocfg)
         kg, vg = _unpack_rows(mm, li, keys, nkv, hd)
-        # K/V of layer li are one bf16 GEMM of the (li times updated) stream rows: 2 % of rms + 2 % (layer 0), growing by the bf16
-        # rounding of the stream state per update
-        k = 1.0 + 0.5 * li
-        report(f"60-min-size stream: layer {li} K cache rows", kg, kref[0], 2e-2 * k * kref.std().item(), 2e-2)
-        report(f"60-min-size stream: layer {li} V cache rows", vg, vref[0], 2e-2 * k * vref.std().item(), 2e-2)
+        # K/V of layer li are one bf16 GEMM of the (li times updated, bf16-rounded) stream rows: 1.2 % of the spread + 1.5 % relative at
+        # layer 0, +1.3 % of the spread per stream update (the kernels use 0.5-0.8 of these bounds, VIDI_TEST_REPORT audit)
+        a = 1.2e-2 + 1.3e-2 * li
+        report(f"60-min-size stream: layer {li} K cache rows", kg, kref[0], a * kref.std().item(), 1.5e-2)
+        report(f"60-min-size stream: layer {li} V cache rows", vg, vref[0], a * vref.std().item(), 1.5e-2)
         x = x_next
 
     # ---- cross-attention over ALL keys of both modalities (layer 1's caches), prompt-sized query block ----
@@ -90,5 +90,5 @@ def test_stream_and_cross_attention_at_the_60_min_sizes():
             o = O.sdpa_reference(qh[:, h * G:(h + 1) * G].permute(1, 0, 2)[None], kh.expand(1, G, n, hd), vh.expand(1, G, n, hd), sc, cap, add)
             ref[:, h * G:(h + 1) * G] = o[0].permute(1, 0, 2)
         ref = ref.reshape(Lq, nq * hd)
-        # fp32 accumulation over up to 90 000 keys, bf16 P and output: 2 % of rms + 2 %
-        report(f"60-min-size cross-attention over all {n} {which} keys", out, ref, 2e-2 * ref.std().item(), 2e-2)
+        # fp32 accumulation over up to 90 000 keys, bf16 P and output: 0.5 % of the spread + 0.5 % relative (about 2x what the kernel uses)
+        report(f"60-min-size cross-attention over all {n} {which} keys", out, ref, 5e-3 * ref.std().item(), 5e-3)

@@ -2,8 +2,8 @@
 inputs.  Inputs are rounded to the storage dtype first, the oracle then runs in fp32 on those values.
 
 Tolerances (stated per test): a kernel output is one rounding (bf16: 2^-8 rel, fp16: 2^-11 rel) away
-from the fp32 result plus accumulation-order noise, so  atol = 1e-2*rms(ref)-ish, rtol = 2e-2 (bf16) /
-4e-3 (fp16) unless noted.  Integer / index outputs are bit-exact."""
+from the fp32 result plus accumulation-order noise, so  atol = 1e-2*rms(ref)-ish, rtol = 1e-2 (bf16) /
+2e-3 (fp16) unless noted (`tol`).  Integer / index outputs are bit-exact."""
 import math
 
 import numpy as np
@@ -19,8 +19,11 @@ pytestmark = pytest.mark.gpu
 DTYPES = [torch.bfloat16, torch.float16]
 
 
-def tol(dt, scale=1.0):
-    return (2e-2 * scale, 2e-2) if dt == torch.bfloat16 else (4e-3 * scale, 4e-3)
+def tol(dt, scale=1.0, k=1.0):
+    """(atol, rtol): 1 % of `scale` + 1 % relative for bf16 (0.2 % / 0.2 % fp16) — about 2x what the kernels use (audited through
+    VIDI_TEST_REPORT, tests/util.py: 0.25-0.5 of this bound); k=2 for the kernels with a second rounding inside (fused activations,
+    softmax probabilities rounded to the dtype before PV)"""
+    return (1e-2 * scale * k, 1e-2 * k) if dt == torch.bfloat16 else (2e-3 * scale * k, 2e-3 * k)
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +74,7 @@ def test_gemm_act_residual(hip, dt, act):
     a = O.gelu_tanh(lin) if act == "tanh" else O.gelu_erf(lin)
     ref = a + r.float().repeat(M // rmod, 1)
     y = hip.gemm(dev(x), dev(w), dev(b), act=H.ACT_GELU_TANH if act == "tanh" else H.ACT_GELU_ERF, residual=dev(r), rmod=rmod)
-    report("gemm act+res", y, ref, *tol(dt, ref.std().item()))
+    report("gemm act+res", y, ref, *tol(dt, ref.std().item(), k=2))
     # in-place residual (out aliases residual), as the encoder layers use it
     res = dev(seeded((M, N), 10, dtype=dt))
     ref2 = lin + res.float().cpu()
@@ -170,7 +173,7 @@ def test_gemm_geglu(hip, dt, cfg):
     wgu = torch.stack([g.view(I // 32, 32, K), u.view(I // 32, 32, K)], dim=1).reshape(2 * I, K).contiguous()
     ref = O.gelu_tanh(x.float() @ g.float().T) * (x.float() @ u.float().T)
     y = hip.gemm_geglu(dev(x), dev(wgu), tile_cfg=cfg)
-    report("gemm geglu", y, ref, *tol(dt, ref.std().item()))
+    report("gemm geglu", y, ref, *tol(dt, ref.std().item(), k=2))
 
 
 @pytest.mark.parametrize("cfg", [0, 4, 5])
@@ -260,7 +263,7 @@ def test_attn_self(hip, dt, D, N, H, B):
     vt = pack_vt(v, Npad)
     out = torch.zeros((B * N, Hd), dtype=dt).cuda()
     hip.attn_self(dev(qk), dev(vt), out, B=B, N=N, Npad=Npad, H=H, D=D, koff=Hd, scale=scale)
-    report(f"attn_self D{D} N{N}", out, ref, *tol(dt, 0.05))
+    report(f"attn_self D{D} N{N}", out, ref, *tol(dt, 0.05, k=2))
 
 
 def _cross_ref(q, k, v, mask, scale, softcap, G):
@@ -300,7 +303,7 @@ def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
                    ntile64=ntile, key_start=start, n_keys=N, scale=scale, softcap=softcap, zsplit=zsplit)
     out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
     hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
-    report("attn_cross", out, ref, *tol(dt, 0.05))
+    report("attn_cross", out, ref, *tol(dt, 0.05, k=2))
 
 
 def test_attn_cross_split_invariance(hip):

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import vidi_oracle as O
-from util import report, seeded, unpack_vt, perm_positions
+from util import logit_tol, report, seeded, unpack_vt, perm_positions
 
 pytestmark = pytest.mark.gpu
 
@@ -38,8 +38,11 @@ def tiny_setup(request):
     return cfg, eng, w32, request.param
 
 
-def tol(dt, k=1.0):
-    """activations after several bf16 layers: |err| <= 5% of the tensor's rms + 3% relative (fp16: 1% / 0.6%)"""
+def tol(dt, k=1.0, tight=False):
+    """activations after several bf16 layers: |err| <= 5% of the tensor's rms + 3% relative (fp16: 1% / 0.6%); tight (towers, encode
+    pipelines, K/V caches, which use less than half of that — VIDI_TEST_REPORT audit): 3% + 2% (fp16: 0.6% / 0.4%)"""
+    if tight:
+        return (3e-2 * k, 2e-2) if dt == torch.bfloat16 else (6e-3 * k, 4e-3)
     return (5e-2 * k, 3e-2) if dt == torch.bfloat16 else (1e-2 * k, 6e-3)
 
 
@@ -49,7 +52,7 @@ def test_siglip_tower(tiny_setup):
     px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 100, 0.5).clamp(-1, 1).to(dt)
     ref = O.siglip_forward(px.float(), w32, oracle_cfg(cfg))
     got = eng.siglip_forward(px.cuda())
-    report("siglip", got, ref, *tol(dt, ref.std().item()))
+    report("siglip", got, ref, *tol(dt, ref.std().item(), tight=True))
 
 
 def test_whisper_tower(tiny_setup):
@@ -58,7 +61,7 @@ def test_whisper_tower(tiny_setup):
     mel = seeded((C, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 101, 0.3).to(dt)
     ref = O.whisper_encoder_forward(mel.float(), w32, oracle_cfg(cfg))
     got = eng.whisper_forward(mel.cuda())
-    report("whisper", got, ref, *tol(dt, ref.std().item()))
+    report("whisper", got, ref, *tol(dt, ref.std().item(), tight=True))
 
 
 @pytest.mark.parametrize("base", [60000, 50])
@@ -75,7 +78,7 @@ def test_encode_video_images(tiny_setup, base):
         feats_ref, mask_ref = O.encode_video_images([px.float()], w32, ocfg)
         feats, mask = eng.encode_video_images(px.cuda())
         assert torch.equal(mask.cpu().bool(), mask_ref[0]), "token mask must be bit-exact"
-        report("encode_video_images", feats, feats_ref[0], *tol(dt, feats_ref.std().item()))
+        report("encode_video_images", feats, feats_ref[0], *tol(dt, feats_ref.std().item(), tight=True))
         # frame-axis sharding: two shards with global (offset,total) == the full encode, bit for bit
         vis = eng.siglip_forward(px.cuda())
         fa, ma = eng.encode_video_images(px[:2].cuda(), frame_offset=0, total_frames=T, vis_features=vis[:2])
@@ -94,7 +97,7 @@ def test_encode_video_audios(tiny_setup):
     feats, mask = eng.encode_video_audios(mel.cuda(), audio_size)
     assert feats.shape[0] == feats_ref.shape[1] == 17
     assert torch.equal(mask.cpu().bool(), mask_ref[0])
-    report("encode_video_audios", feats, feats_ref[0], *tol(dt, feats_ref.std().item()))
+    report("encode_video_audios", feats, feats_ref[0], *tol(dt, feats_ref.std().item(), tight=True))
 
 
 def _run_oracle_prefill(w32, ocfg, ids, img, imask, aud, amask):
@@ -126,14 +129,14 @@ def test_decoder_prefill_and_caches(tiny_setup):
     for li in range(cfg.num_hidden_layers):
         kref, vref = caches.image[li]
         kc = mm.kc[li].reshape(nkv, -1, hd)[:, :Nv].permute(1, 0, 2).reshape(Nv, -1)
-        report(f"image K cache L{li}", kc, kref[0], *tol(dt, kref.std().item()))
+        report(f"image K cache L{li}", kc, kref[0], *tol(dt, kref.std().item(), tight=True))
         pos = torch.from_numpy(perm_positions(32))
         vt = mm.vtc[li].cpu()[:, :, :, pos]                   # undo perm16 inside each 32-key sub-tile
         v = vt.permute(1, 3, 0, 2).reshape(-1, nkv * hd)[:Nv]
-        report(f"image V cache L{li}", v, vref[0], *tol(dt, vref.std().item()))
+        report(f"image V cache L{li}", v, vref[0], *tol(dt, vref.std().item(), tight=True))
         karef, _ = caches.audio[li]
         ka = mm.kc[li].reshape(nkv, -1, hd)[:, mm.aud_start: mm.aud_start + Na].permute(1, 0, 2).reshape(Na, -1)
-        report(f"audio K cache L{li}", ka, karef[0], *tol(dt, karef.std().item()))
+        report(f"audio K cache L{li}", ka, karef[0], *tol(dt, karef.std().item(), tight=True))
     idt, mask, pos_ids = strip_image_token(ids)
     ts = eng.new_text_state(1, 16)
     emb = eng.embed_tokens(idt.cuda())
@@ -160,13 +163,13 @@ def test_generate_matches_oracle(tiny_setup):
     model.model = None
     out = model.forward(ids, images=px[None].cuda(), audios=mel[None].cuda(), audio_sizes=[100], logits_to_keep=1)
     ref_logits = dbg["prefill_logits"]
-    atol, rtol = tol(dt, ref_logits.std().item())
-    report("prefill logits", out.logits[:, -1], ref_logits, 3 * atol, rtol)
+    ltol = logit_tol(dt, ref_logits)
+    report("prefill logits", out.logits[:, -1], ref_logits, ltol, 0.0)
     got = model.generate(ids, images=px[None].cuda(), audios=mel[None].cuda(), audio_sizes=[100], max_new_tokens=n_new,
                          do_sample=False, use_cache=True).cpu()
     # compare token by token until the first low-margin step
     top2 = torch.topk(ref_logits[0].float(), 2).values
-    if float(top2[0] - top2[1]) > 6 * atol:
+    if float(top2[0] - top2[1]) > 2 * ltol:
         assert int(got[0, 0]) == int(ref_ids[0, 0]), f"first token {int(got[0,0])} != oracle {int(ref_ids[0,0])}"
     assert got.shape[1] <= n_new and got.dtype == torch.int64
 

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import report
+from util import logit_tol, report
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -22,11 +22,6 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def tol(dt, k=1.0):
     return (5e-2 * k, 3e-2) if dt == torch.bfloat16 else (1e-2 * k, 6e-3)
-
-
-def logit_tol(dt, ref):
-    """absolute tolerance on logits: a fraction of their spread"""
-    return (7e-2 if dt == torch.bfloat16 else 1.2e-2) * float(ref.float().std())
 
 
 def check_free_running(got, ref_tok, step_logits, atol, min_agree, what):

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import vidi_oracle as O
-from util import report, seeded
+from util import logit_tol, report, seeded
 from test_gpu_model import make, oracle_cfg, tol as mtol
 
 pytestmark = pytest.mark.gpu
@@ -14,7 +14,8 @@ DTYPES = [torch.bfloat16, torch.float16]
 
 
 def ktol(dt, scale):
-    return ((2e-2 if dt == torch.bfloat16 else 4e-3) * scale, 2e-2 if dt == torch.bfloat16 else 4e-3)
+    """single kernels: 1 % of the spread + 1 % relative (bf16), 0.2 % / 0.2 % (fp16) — see test_gpu_kernels.tol"""
+    return ((1e-2 if dt == torch.bfloat16 else 2e-3) * scale, 1e-2 if dt == torch.bfloat16 else 2e-3)
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +37,7 @@ def test_glu_silu(hip, dt, M):
     else:                                                        # decode path: GEMV + unpack
         yp = hip.gemv(x.cuda(), wgu.cuda())
         y = hip.glu_unpack(yp, torch.empty((M, I), dtype=dt, device="cuda"), hip.ACT_SILU)
-    report("glu silu", y, ref, *ktol(dt, ref.std().item()))
+    report("glu silu", y, ref, *[2 * t for t in ktol(dt, ref.std().item())])    # fused activation: a second rounding inside
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -101,18 +102,18 @@ def test_7b_prefill_logits_and_generate(setup7b):
     model.model = None
     out = model.forward(ids, images=px[None].cuda(), audios=mel[None].cuda(), audio_sizes=[100], logits_to_keep=1)
     ref_logits = dbg["prefill_logits"]
-    atol, rtol = mtol(dt, ref_logits.std().item())
-    report("7b prefill logits", out.logits[:, -1], ref_logits, 3 * atol, rtol)
+    ltol = logit_tol(dt, ref_logits)
+    report("7b prefill logits", out.logits[:, -1], ref_logits, ltol, 0.0)
     got = model.generate(ids, images=px[None].cuda(), audios=mel[None].cuda(), audio_sizes=[100], max_new_tokens=n_new,
                          do_sample=False, use_cache=True).cpu()
     top2 = torch.topk(ref_logits[0].float(), 2).values
-    if float(top2[0] - top2[1]) > 6 * atol:
+    if float(top2[0] - top2[1]) > 2 * ltol:
         assert int(got[0, 0]) == int(ref_ids[0, 0])
     assert got.shape[1] <= n_new and got.dtype == torch.int64
     # text-only query (no video): plain Mistral path, mistral.py:169-174
     ref_t = O.generate_greedy(torch.tensor([[1, 21, 22, 23]]), None, None, None, w32, ocfg, 1, return_debug=True)[1]["prefill_logits"]
     out_t = model.forward(torch.tensor([[1, 21, 22, 23]]), logits_to_keep=1)
-    report("7b text-only logits", out_t.logits[:, -1], ref_t, 3 * atol, rtol)
+    report("7b text-only logits", out_t.logits[:, -1], ref_t, logit_tol(dt, ref_t), 0.0)
     # batched right padding is rejected like the reference does (mistral.py:366-373)
     with pytest.raises(ValueError):
         model.generate(torch.tensor([[1, 5, -200, 6], [1, -200, 7, 0]]), attention_mask=torch.tensor([[1, 1, 1, 1], [1, 1, 1, 0]]),

@@ -20,6 +20,13 @@ def seeded(shape, seed, scale=1.0, dtype=torch.float32):
     return (torch.randn(shape, generator=g) * scale).to(dtype)
 
 
+def logit_tol(dt, ref):
+    """Absolute tolerance on logits, a fraction of their spread: 7 % (bf16) / 1.2 % (fp16) of std(ref), no relative part — about 2x what
+    the HIP path achieves against fp32 references (3.3 % observed for bf16).  |err| <= tol on every logit implies the same argmax
+    wherever the reference's top-2 margin exceeds 2 x tol."""
+    return (7e-2 if dt == torch.bfloat16 else 1.2e-2) * float(ref.float().std())
+
+
 def report(name, got, ref, atol, rtol):
     """assert closeness with a diagnostic that says WHERE and HOW the mismatch looks."""
     got = got.detach().float().cpu()

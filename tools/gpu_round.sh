@@ -18,12 +18,16 @@ smoke)
 bench)
   timeout 1200 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; python tools/show_bench.py $OUT/bench.json 2>/dev/null | head -40 ;;
 prof)
-  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r2 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc > $OUT/prof_bench.json 2> $OUT/prof.err)
-  echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3 ;;
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r2 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc > $OUT/prof_bench.json 2> $OUT/prof.err)
+  echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
+  # keep the summary, drop the per-dispatch trace (tens of MB)
+  find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
+chunk)
+  timeout 900 python tools/bench_vis_chunk.py 3600 > $OUT/vis_chunk.jsonl 2> $OUT/vis_chunk.err; echo "chunk rc=$?"; cat $OUT/vis_chunk.jsonl ;;
 pmc)
   CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc"
-  (cd /tmp && timeout 1200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err); echo "fetch rc=$?"
-  (cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err); echo "write rc=$?"
+  (cd /tmp && timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err); echo "fetch rc=$?"
+  (cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err); echo "write rc=$?"
   F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
   python tools/traffic_from_pmc.py "$F" "$W" $OUT/traffic.json 3600 vidi15_9b | head -c 1500
   # keep only the small summaries (the raw per-dispatch CSVs are tens of MB)

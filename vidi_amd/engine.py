@@ -482,7 +482,8 @@ class VidiEngine:
         gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
         eps = cfg.rms_norm_eps
         for li, L in enumerate(self.layers if ntot > 0 else []):
-            hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184 / mistral.py:204-205
+            if self.mistral or li == 0:                                                              # Gemma2 wiring, li > 0: produced by the previous layer's fused pass
+                hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                           # gemma.py:183-184 / mistral.py:204-205
             hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
             if li == Lr - 1:
                 break                                                                                # dead update on the last layer
@@ -492,12 +493,13 @@ class VidiEngine:
                 hip.gemm_glu(hbuf, L["wgu"], gt, act=hip.ACT_SILU)
                 hip.gemm(gt, L["wdown"], None, X, residual=X)                                        # :135
                 continue
+            # residual + post-norm and the following pre-norm run as ONE pass over the rows (vidi_resid_norm2: the arithmetic and
+            # rounding points of NORM_GEMMA_ADD followed by NORM_GEMMA, bit-identical; 8 instead of 10 row passes per layer)
             hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)                               # :196-197 o_proj(repeat_kv(V))
-            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_attn"], eps=eps, residual=X, out=X)           # :198-201
-            hip.norm(hip.NORM_GEMMA, X, L["ln_pre_ffn"], eps=eps, out=hbuf)                          # :118
+            hip.resid_norm2(u, None, None, X, L["ln_post_attn"], L["ln_pre_ffn"], X, hbuf, eps=eps)  # :198-201 + :118
             hip.gemm_geglu(hbuf, L["wgu"], gt)                                                       # :119 gate/up + GeGLU
             hip.gemm(gt, L["wdown"], None, u)                                                        # :119 down_proj
-            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_ffn"], eps=eps, residual=X, out=X)            # :120-121
+            hip.resid_norm2(u, None, None, X, L["ln_post_ffn"], self.layers[li + 1]["ln_in"], X, hbuf, eps=eps)   # :120-121 + next layer's :183
         if check_masks:
             # one host sync per VIDEO (the reference syncs per layer per step: xattn.py:214-215)
             for name, m in (("img", img_mask), ("aud", aud_mask)):
