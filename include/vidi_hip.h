@@ -75,6 +75,21 @@ int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, 
                      int M, int N, int K, int ldx, int ldw, int ldy,
                      int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream);
 
+/* LayerNorm folded into the projection that consumes it (the encoder towers: HF SiglipEncoderLayer layer_norm1 -> q/k/v_proj and
+ * layer_norm2 -> mlp.fc1, TP siglip:305-357; WhisperEncoderLayer self_attn_layer_norm / final_layer_norm, TP whisper:386-411):
+ *   vidi_row_stats   stats[m] = (mean_m, rsqrt(var_m + eps)) of row m of X (fp32, two-pass variance) — ONE read of X;
+ *   vidi_gemm_ln / vidi_gemm_qkv_vt_ln   take the UN-normalised X, the weight with the LayerNorm gain folded in (Wf[n][k] =
+ *   T(W[n][k] * gamma[k])) and two fp32 vectors colsum[n] = sum_k Wf[n][k], shift[n] = sum_k W[n][k] * beta[k] + bias[n], and
+ *   compute  Y[m][n] = act( rstd_m * (sum_k X[m][k] Wf[n][k] - mean_m * colsum[n]) + shift[n] )  in the fp32 epilogue ==
+ *   act(Linear(LayerNorm(x))) without ever writing LayerNorm(x) (one row pass instead of a read + a write per LayerNorm).
+ * act: VIDI_ACT_NONE / GELU_TANH / GELU_ERF.  Layout of the qkv variant as vidi_gemm_qkv_vt. */
+int vidi_row_stats(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, void* stream);
+int vidi_gemm_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,
+                 int M, int N, int K, int ldx, int ldw, int ldy, int act, int tile_cfg, int dtype, void* stream);
+int vidi_gemm_qkv_vt_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Yqk, void* Vt,
+                        int M, int N, int K, int ldx, int ldw, int ldy,
+                        int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream);
+
 /* LLM K/V projection of the multimodal stream straight into the cross-attention caches
  * (gemma.py:59-65: k_proj, v_proj, DynamicCache.update).  W:[2*kvd,K] = [Wk;Wv].
  * Kc[kvh][tile64][64][hd], Vtc[kvh][tile32][hd][32 (perm16)] (2*ntile64 sub-tiles), Vrow:[M,kvd] row-major copy of V for the

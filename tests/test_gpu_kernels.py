@@ -209,6 +209,74 @@ def test_gemm_qkv_vt(hip, hd, N, nh, cfg):
     report("qkv_vt V", v, ref[:, 2 * Hd:], *tol(dt, ref.std().item()))
 
 
+def _fold_ln(w, b, gamma, beta, dt):
+    """host-side folding as vidi_amd/engine.py does it (include/vidi_hip.h: vidi_gemm_ln)"""
+    wf = (w.float() * gamma.float()[None, :]).to(dt)
+    return wf, wf.float().sum(1).contiguous(), (w.float() @ beta.float() + b.float()).contiguous()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,H", [(7, 64), (300, 1152), (130, 1280), (5, 3584)])
+def test_row_stats(hip, dt, rows, H):
+    x = (seeded((rows, H), 60, 2.0) + seeded((rows, 1), 61, 3.0)).to(dt)          # rows with a non-zero mean
+    st = torch.zeros(2 * rows, dtype=torch.float32).cuda()
+    hip.row_stats(dev(x), st, 1e-6)
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = torch.rsqrt(xf.var(1, unbiased=False) + 1e-6)
+    got = st.cpu().view(rows, 2)
+    report("row_stats mean", got[:, 0], mean, 1e-5, 1e-5)
+    report("row_stats rstd", got[:, 1], rstd, 1e-6, 1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("act", ["none", "tanh", "erf"])
+@pytest.mark.parametrize("M,N,K,cfg", [(300, 352, 192, 0), (12800, 1152, 1152, -1), (9000, 4352, 1152, 5), (70, 192, 64, -1)])
+def test_gemm_ln_equals_layernorm_then_linear(hip, dt, act, M, N, K, cfg):
+    """LayerNorm folded into the projection (vidi_row_stats + vidi_gemm_ln) against LayerNorm -> Linear -> act evaluated in fp32 on the
+    same rounded inputs; rows carry a mean of the order of their spread and a few outlier channels (what the towers' residual streams
+    look like), gamma/beta are non-trivial.  Both the small-problem 128x128 tile and the persistent 4-wave kernel."""
+    from vidi_amd import hip as H
+    x = seeded((M, K), 62, 1.0) + seeded((M, 1), 63, 1.5)
+    x[:, 5] *= 20.0; x[:, K // 2] *= -12.0
+    x = x.to(dt)
+    w = seeded((N, K), 64, 0.05, dtype=dt); b = seeded((N,), 65, 0.3, dtype=dt)
+    gamma = (1.0 + seeded((K,), 66, 0.2)).to(dt); beta = seeded((K,), 67, 0.2, dtype=dt)
+    h = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-6)
+    ref = F.linear(h, w.float(), b.float())
+    ref = {"none": ref, "tanh": O.gelu_tanh(ref), "erf": O.gelu_erf(ref)}[act]
+    wf, cs, sh = _fold_ln(w, b, gamma, beta, dt)
+    st = torch.zeros(2 * M, dtype=torch.float32).cuda()
+    hip.row_stats(dev(x), st, 1e-6)
+    y = hip.gemm_ln(dev(x), dev(wf), st, dev(cs), dev(sh), act={"none": H.ACT_NONE, "tanh": H.ACT_GELU_TANH, "erf": H.ACT_GELU_ERF}[act], tile_cfg=cfg)
+    # one output rounding + the rounding of the folded weight (the reference rounds LayerNorm(x) instead): the usual single-kernel bound
+    report(f"gemm_ln act={act}", y, ref, *tol(dt, ref.std().item(), k=2 if act != "none" else 1))
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 5])
+@pytest.mark.parametrize("hd,N,nh,B", [(72, 729, 4, 2), (16, 49, 4, 2), (64, 1500, 4, 12)])
+def test_gemm_qkv_vt_ln(hip, hd, N, nh, B, cfg):
+    dt = torch.bfloat16
+    Hd = nh * hd
+    K = 192
+    Npad = (N + 63) // 64 * 64
+    if (3 * Hd) % 32:
+        pytest.skip("N must be a multiple of 32")
+    x = (seeded((B * N, K), 68, 1.0) + seeded((B * N, 1), 69, 1.0)).to(dt)
+    w = seeded((3 * Hd, K), 70, 0.1, dtype=dt); b = seeded((3 * Hd,), 71, dtype=dt)
+    gamma = (1.0 + seeded((K,), 72, 0.2)).to(dt); beta = seeded((K,), 73, 0.2, dtype=dt)
+    ref = F.linear(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5), w.float(), b.float())
+    wf, cs, sh = _fold_ln(w, b, gamma, beta, dt)
+    st = torch.zeros(2 * B * N, dtype=torch.float32).cuda()
+    hip.row_stats(dev(x), st, 1e-5)
+    yqk = torch.zeros((B * N, 2 * Hd), dtype=dt).cuda()
+    vt = torch.zeros((B, nh, hd, Npad), dtype=dt).cuda()
+    hip.gemm_qkv_vt_ln(dev(x), dev(wf), st, dev(cs), dev(sh), yqk, vt, vstart=2 * Hd, hd=hd, seq=N, seqpad=Npad, nheads=nh, tile_cfg=cfg)
+    report("qkv_vt_ln QK", yqk, ref[:, : 2 * Hd], *tol(dt, ref.std().item()))
+    v = unpack_vt(vt.cpu(), N).reshape(B * N, Hd)
+    report("qkv_vt_ln V", v, ref[:, 2 * Hd:], *tol(dt, ref.std().item()))
+
+
 @pytest.mark.parametrize("cfg", [-1, 2, 4, 5])
 def test_gemm_kv_cache(hip, cfg):
     dt = torch.bfloat16

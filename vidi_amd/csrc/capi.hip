@@ -78,6 +78,39 @@ int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, 
     return vidi_gemm_dispatch(p, 1, MODE_QKV_VT, 0, tile_cfg, dtype, (hipStream_t)stream);
 }
 
+int vidi_row_stats(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !stats) return VIDI_ERR_ARG;
+    return vidi_row_stats_dispatch(X, stats, rows, H, ldx, eps, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemm_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,
+                 int M, int N, int K, int ldx, int ldw, int ldy, int act, int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wf || !stats || !colsum || !shift || !Y) return VIDI_ERR_ARG;
+    if (((uintptr_t)colsum & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)stats & 7)) return VIDI_ERR_ALIGN;
+    if (act != ACT_NONE && act != ACT_GELU_TANH && act != ACT_GELU_ERF) return VIDI_ERR_ARG;
+    GemmParams p = base_params(X, Wf, nullptr, Y, nullptr, M, N, K, ldx, ldw, ldy, 0, 0);
+    p.act = act; p.ln_stats = stats; p.ln_s = colsum; p.ln_c = shift;
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemm_qkv_vt_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Yqk, void* Vt,
+                        int M, int N, int K, int ldx, int ldw, int ldy,
+                        int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wf || !stats || !colsum || !shift || !Yqk || !Vt) return VIDI_ERR_ARG;
+    if (((uintptr_t)colsum & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)stats & 7)) return VIDI_ERR_ALIGN;
+    if (vstart % 4 || hd % 4 || seq <= 0 || seqpad % 16 || seqpad < ((seq + 15) / 16) * 16 || M % seq) return VIDI_ERR_SHAPE;
+    if ((N - vstart) != nheads * hd) return VIDI_ERR_SHAPE;
+    GemmParams p = base_params(X, Wf, nullptr, Yqk, nullptr, M, N, K, ldx, ldw, ldy, 0, 0);
+    p.vstart = vstart; p.hd = hd; p.seq = seq; p.seqpad = seqpad; p.nheads = nheads; p.Vt = (u16*)Vt;
+    p.ln_stats = stats; p.ln_s = colsum; p.ln_c = shift;
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_QKV_VT, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* Vrow,
                        int M, int kvd, int K, int ldx, int ldw, int hd, int ntile64, int tok0,
                        int tile_cfg, int dtype, void* stream) {

@@ -292,6 +292,7 @@ static int launch_w4_any(const GemmParams& p, int batch, hipStream_t st) {
 template <typename T, int MODE, bool REPKV>
 static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t st) {
     if (tile_cfg == 3) {
+        if (p.ln_stats) return VIDI_ERR_ARG;
         if constexpr (MODE == MODE_PLAIN) {
             const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);
             hipLaunchKernelGGL((gemm_kernel_regstage<T, MODE, REPKV>), dim3(tiles, batch), dim3(256), 0, st, p);
@@ -306,12 +307,13 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         const long long t256 = (long long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
         static int big = -1;                      // VIDI_GEMM_CFG: 4 or 5 (A/B of the two large-tile kernels; same results)
         if (big < 0) { const char* e = getenv("VIDI_GEMM_CFG"); big = e ? atoi(e) : 5; if (big != 4 && big != 5) big = 5; }
-        if (t256 >= 192 && big == 5) {            // persistent 4-wave kernel; the 8-wave kernel covers epilogue combinations it lacks
+        if (t256 >= 192 && (big == 5 || p.ln_stats)) {            // persistent 4-wave kernel; the 8-wave kernel covers epilogue combinations it lacks
             const int rc = launch_w4_any<T, MODE, REPKV>(p, batch, st);
             if (rc != VIDI_W4_UNSUPPORTED) return rc;
         }
-        tile_cfg = (t256 >= 192) ? 4 : 0;
+        tile_cfg = (t256 >= 192 && !p.ln_stats) ? 4 : 0;
     }
+    if (p.ln_stats && tile_cfg != 0 && tile_cfg != 5) return VIDI_ERR_ARG;       // folded LayerNorm: persistent kernel or the 128x128 tile
     switch (tile_cfg) {
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV, SCHED_RING, 32>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV, SCHED_RING, 32>(p, batch, st);

@@ -339,7 +339,15 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * j + e];
-                    if (has_bias) {
+                    // folded LayerNorm (see GemmParams): replaces the bias add.  Only the small-problem 128x128 tile carries it (large
+                    // problems run on the persistent kernel; the 8-wave 256x256 body has no registers to spare — it spilled with it)
+                    if (BN == 128 && BM == 128 && p.ln_stats) {
+                        const size_t mr = (size_t)min(m, p.M - 1);
+                        const float mu = p.ln_stats[2 * mr], rs = p.ln_stats[2 * mr + 1];
+                        const f32x4 sv = *(const f32x4*)(p.ln_s + min(n, p.N - 4)), cv = *(const f32x4*)(p.ln_c + min(n, p.N - 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rs, v[e] - mu * sv[e], cv[e]);
+                    } else if (has_bias) {
                         const u32x2 bv = bq[a][j];
                         v[0] += T::to_f32((u16)(bv[0] & 0xffff)); v[1] += T::to_f32((u16)(bv[0] >> 16));
                         v[2] += T::to_f32((u16)(bv[1] & 0xffff)); v[3] += T::to_f32((u16)(bv[1] >> 16));

@@ -37,8 +37,10 @@ struct W4Geom {
 // compile-time epilogue shape of MODE_PLAIN (runtime flags made every strip a maze of scalar branches and put a vmcnt(0) —
 // i.e. a wait for the in-flight DMA and for all earlier stores — on the path without a residual): bias add, activation
 // (ACT_NONE / ACT_GELU_TANH / ACT_GELU_ERF), residual (0 none, 1 row m, 2 row m % rmod)
-template <bool BIAS, int ACT, int RES>
-struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; };
+// LNF: LayerNorm folded into the projection (GemmParams::ln_stats / ln_s / ln_c): y = rstd_m * (acc - mean_m * s_n) + c_n replaces
+// the bias add (c carries the bias)
+template <bool BIAS, int ACT, int RES, bool LNF = false>
+struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF; };
 
 template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         u16* Yb = p.Y + (long long)ebz * p.bsY;
         constexpr bool has_res = (MODE == MODE_PLAIN) && (EPI::res != 0);
         const u16* Rb = has_res ? p.R + (long long)ebz * p.bsR : nullptr;
-        constexpr bool has_bias = !GLU && EPI::bias;                  // (QKV_VT always carries a bias in the callers: Epi<true, ...>)
+        constexpr bool lnf = !GLU && EPI::lnf;
+        constexpr bool has_bias = !GLU && EPI::bias && !lnf;          // (QKV_VT always carries a bias in the callers: Epi<true, ...>)
         constexpr bool wrap = (EPI::res == 2);
         const int Nout = GLU ? (p.N >> 1) : p.N;
         const int no0 = GLU ? (en0 >> 1) + wn * 64 : en0 + wn * 128;           // first output column of this wave's strips
@@ -205,6 +208,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if constexpr (has_bias) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) bq[a] = *(const u32x2*)(p.bias + min(en0 + wn * 128 + a * 16 + 4 * hi, p.N - 4));
+        }
+        // folded LayerNorm: this lane's column sums / shifts (4 consecutive columns per tile) and the (mean, rstd) of its 8 rows
+        f32x4 lnS[lnf ? TN : 1], lnC[lnf ? TN : 1];
+        float lnMu[lnf ? TM : 1], lnRs[lnf ? TM : 1];
+        if constexpr (lnf) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int nc = min(en0 + wn * 128 + a * 16 + 4 * hi, p.N - 4);
+                lnS[a] = *(const f32x4*)(p.ln_s + nc);
+                lnC[a] = *(const f32x4*)(p.ln_c + nc);
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int mr = min(em0 + wm * 128 + b * 16 + l15, p.M - 1);
+                lnMu[b] = p.ln_stats[2 * (size_t)mr];
+                lnRs[b] = p.ln_stats[2 * (size_t)mr + 1];
+            }
         }
         const int rr = lane / CPRW, cc = lane % CPRW;                // this lane's (row in read group, chunk) of the read-back
         const int n = no0 + cc * 8;                                  // this lane's output column in the read-back
@@ -238,6 +258,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                         const u32x2 bv = bq[a];
                         v[0] += T::to_f32((u16)(bv[0] & 0xffff)); v[1] += T::to_f32((u16)(bv[0] >> 16));
                         v[2] += T::to_f32((u16)(bv[1] & 0xffff)); v[3] += T::to_f32((u16)(bv[1] >> 16));
+                    }
+                    if constexpr (lnf) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(lnRs[b], v[e] - lnMu[b] * lnS[a][e], lnC[a][e]);
                     }
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                     const int m = mrow0 + l15;

@@ -26,6 +26,7 @@ static int launch_w4(const GemmParams& p, int batch, hipStream_t st) {
 // MODE_PLAIN: (bias, act, residual kind) combinations the Vidi engines use; others return VIDI_W4_UNSUPPORTED
 template <typename T>
 static int w4_plain_dispatch(const GemmParams& p, int batch, int repkv, hipStream_t st) {
+    if (p.ln_stats) return vidi_w4_lnf(p, batch, MODE_PLAIN, T::id, st);       // LayerNorm folded into the projection (gemm_w4_lnf.hip)
     const bool bias = p.bias != nullptr;
     const int res = p.R ? (p.rmod < p.M ? 2 : 1) : 0;
     const int act = p.act;
@@ -56,6 +57,7 @@ static int w4_plain_dispatch(const GemmParams& p, int batch, int repkv, hipStrea
     return VIDI_W4_UNSUPPORTED;
 }
 
+int vidi_w4_lnf(const GemmParams& p, int batch, int mode, int dtype, hipStream_t st);          // LayerNorm-folded epilogues (PLAIN + act, QKV_VT)
 int vidi_w4_plain_bf16(const GemmParams& p, int batch, int repkv, hipStream_t st);
 int vidi_w4_plain_f16(const GemmParams& p, int batch, int repkv, hipStream_t st);
 int vidi_w4_modes(const GemmParams& p, int batch, int mode, int dtype, hipStream_t st);       // GEGLU / QKV_VT / KV_CACHE

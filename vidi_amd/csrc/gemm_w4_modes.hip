@@ -4,7 +4,8 @@ template <typename T>
 static int modes(const GemmParams& p, int batch, int mode, hipStream_t st) {
     switch (mode) {
         case MODE_GEGLU: return launch_w4<T, MODE_GEGLU, false, Epi<false, ACT_NONE, 0>>(p, batch, st);
-        case MODE_QKV_VT: return p.bias ? launch_w4<T, MODE_QKV_VT, false, Epi<true, ACT_NONE, 0>>(p, batch, st)
+        case MODE_QKV_VT: if (p.ln_stats) return vidi_w4_lnf(p, batch, MODE_QKV_VT, T::id, st);
+                          return p.bias ? launch_w4<T, MODE_QKV_VT, false, Epi<true, ACT_NONE, 0>>(p, batch, st)
                                         : launch_w4<T, MODE_QKV_VT, false, Epi<false, ACT_NONE, 0>>(p, batch, st);
         case MODE_KV_CACHE: return launch_w4<T, MODE_KV_CACHE, false, Epi<false, ACT_NONE, 0>>(p, batch, st);
         default: return VIDI_W4_UNSUPPORTED;

@@ -32,6 +32,11 @@ struct GemmParams {
     int vstart, hd, seq, seqpad, nheads; u16* Vt;
     // MODE_KV_CACHE: N = 2*kvd; K half -> Kc tiled, V half -> Vrow row-major + Vtc tiled
     u16* Kc; u16* Vtc; u16* Vrow; int kvd, ntile64, tok0;
+    // LayerNorm folded into the projection (encoder towers): X holds the UN-normalised rows, W the weight with the LayerNorm gain
+    // folded in (W' = W * gamma), and the epilogue applies  y = rstd_m * (acc - mean_m * s_n) + c_n  with
+    //   ln_stats[m] = (mean_m, rstd_m)  (vidi_row_stats),  ln_s[n] = sum_k W'[n][k],  ln_c[n] = sum_k W[n][k] * beta[k] + bias[n]   (fp32)
+    // == Linear(LayerNorm(x)) without materialising LayerNorm(x).  Null ln_stats: plain bias epilogue.
+    const float* ln_stats; const float* ln_s; const float* ln_c;
 };
 
 struct AttnSelfParams {
@@ -96,5 +101,6 @@ int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int row
 int vidi_rope_cache_dispatch(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cs, const void* sn, int B, int Lq,
                              int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, hipStream_t st);
 int vidi_norm_dispatch(const NormParams& p, int mode, int dtype, hipStream_t st);
+int vidi_row_stats_dispatch(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, hipStream_t st);
 int vidi_ew_dispatch(int op, void** a, const long long* i, const float* f, int dtype, hipStream_t st);
 int vidi_sinusoid_dispatch(float* pe, const float* div, int rows, int i0, int l, int N, int d, hipStream_t st);

@@ -183,6 +183,55 @@ __global__ __launch_bounds__(256) void resid_norm2_kernel(const u16* __restrict_
     }
 }
 
+// ---- LayerNorm statistics only: stats[row] = (mean, rsqrt(var + eps)), two-pass variance on the register-resident row ------
+//   The consuming projection applies them in its epilogue (GemmParams::ln_stats): LayerNorm(x) is never written.
+//   One read of the row: algorithmic bytes = rows * H * 2 B.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ X, float* __restrict__ stats, long long rows, int H,
+                                                        long long ldx, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = H / 8;
+    float x[MAXC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            unpack8<T>(*(const u32x4*)(X + row * ldx + ch * 8), x[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 += x[c][e];
+        }
+    }
+    const float mean = wave_sum(s1) / H;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + c * 64 < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v += (x[c][e] - mean) * (x[c][e] - mean);
+    const float rs = rsqrtf(wave_sum(v) / H + eps);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rs;
+    }
+}
+
+int vidi_row_stats_dispatch(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, hipStream_t st) {
+    if (rows <= 0 || H <= 0 || H % 8 || ldx % 8) return VIDI_ERR_SHAPE;
+    const int nchunk = H / 8;
+    const int grid = (int)((rows + 3) / 4);
+#define VIDI_RS(TT, MC) hipLaunchKernelGGL((row_stats_kernel<TT, MC>), dim3(grid), dim3(256), 0, st, (const u16*)X, stats, rows, H, ldx, eps)
+    if (dtype == VIDI_DT_BF16) {
+        if (nchunk <= 64) VIDI_RS(BF16, 1); else if (nchunk <= 192) VIDI_RS(BF16, 3); else if (nchunk <= 512) VIDI_RS(BF16, 8); else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (nchunk <= 64) VIDI_RS(F16, 1); else if (nchunk <= 192) VIDI_RS(F16, 3); else if (nchunk <= 512) VIDI_RS(F16, 8); else return VIDI_ERR_SHAPE;
+    } else return VIDI_ERR_DTYPE;
+#undef VIDI_RS
+    return (int)hipGetLastError();
+}
+
 int vidi_resid_norm2_dispatch(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1,
                               void* Y2, int rows, int H, long long ld, float eps, int dtype, hipStream_t st) {
     if (rows <= 0 || H <= 0 || H % 8 || ld % 8) return VIDI_ERR_SHAPE;

@@ -126,6 +126,15 @@ class VidiEngine:
             if free_source:
                 w.pop(name, None)
 
+        def fold_ln(W, b, gamma, beta):
+            """LayerNorm folded into the projection that consumes it (include/vidi_hip.h: vidi_gemm_ln): returns
+            (Wf = T(W * gamma), colsum[n] = sum_k Wf[n, k] of the ROUNDED Wf (so the mean term cancels exactly against the MFMA
+            products), shift[n] = sum_k W[n, k] * beta[k] + b[n]) — fp32 vectors, computed once at load time."""
+            Wf = (W.float() * gamma.float()[None, :]).to(dt).contiguous()
+            colsum = Wf.float().sum(dim=1).contiguous()
+            shift = (W.float() @ beta.float() + (b.float() if b is not None else 0.0)).contiguous()
+            return Wf, colsum, shift
+
         H, I = cfg.hidden_size, cfg.intermediate_size
         self.embed = g("model.embed_tokens.weight")
         self.lm_head = self.embed if cfg.tie_word_embeddings or "lm_head.weight" not in w else g("lm_head.weight")
@@ -175,6 +184,9 @@ class VidiEngine:
             L["fc1"], L["b1"], L["fc2"], L["b2"] = fc1, b1, fc2, g(p + "mlp.fc2.bias")
             for n, k in (("layer_norm1", "ln1"), ("layer_norm2", "ln2")):
                 L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
+            # layer_norm1 -> q/k/v_proj and layer_norm2 -> fc1 with the LayerNorm folded in (the plain weights are dropped)
+            L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
+            L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
             self.vis["layers"].append(L)
 
         # ---- Whisper encoder ----
@@ -197,6 +209,8 @@ class VidiEngine:
             L["fc1"], L["b1"], L["fc2"], L["b2"] = g(p + "fc1.weight"), g(p + "fc1.bias"), g(p + "fc2.weight"), g(p + "fc2.bias")
             for n, k in (("self_attn_layer_norm", "ln1"), ("final_layer_norm", "ln2")):
                 L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
+            L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
+            L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
             self.aud["layers"].append(L)
 
         # ---- multimodal glue ----
@@ -281,7 +295,7 @@ class VidiEngine:
         fc = max(1, cfg.vis_frames_per_chunk)
         Mmax = min(T, fc) * N
         A = self._buf("vis_A", (Mmax, V["kpad"]))
-        h = self._buf("vis_h", (Mmax, Hv))
+        st = self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32)
         yqk = self._buf("vis_qk", (Mmax, 2 * Hv))
         vt = self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True)
         ao = self._buf("vis_ao", (Mmax, Hv))
@@ -294,12 +308,14 @@ class VidiEngine:
             hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
             hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
             for L in V["layers"]:
-                hip.norm(hip.NORM_LAYER, x, L["ln1w"], eps=cfg.vis_ln_eps, bias=L["ln1b"], out=h[:M])
-                hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+                # LayerNorm(x) is never written: one read-only pass leaves (mean, rstd) per row and the projection's epilogue
+                # applies them (vidi_gemm_ln: Linear(LayerNorm(x)) == rstd * (x Wf^T - mean * colsum) + shift)
+                hip.row_stats(x, st, cfg.vis_ln_eps)
+                hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh)
                 hip.attn_self(yqk[:M], vt, ao[:M], B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=hd ** -0.5)
                 hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-                hip.norm(hip.NORM_LAYER, x, L["ln2w"], eps=cfg.vis_ln_eps, bias=L["ln2b"], out=h[:M])
-                hip.gemm(h[:M], L["fc1"], L["b1"], f1[:M], act=hip.ACT_GELU_TANH)
+                hip.row_stats(x, st, cfg.vis_ln_eps)
+                hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=hip.ACT_GELU_TANH)
                 hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
         return out.view(T, N, Hv)
 
@@ -372,7 +388,7 @@ class VidiEngine:
         melT = self._buf("aud_melT", (nb * (Lm + 2) + 4, nm), zero=True)[: nb * (Lm + 2)].view(nb, Lm + 2, nm)
         y1 = self._buf("aud_y1", (nb, Lm + 1, Da), zero=True)              # row 0 = left zero pad of conv2
         y1[:, 0].zero_()
-        h = self._buf("aud_h", (nb * N, Da))
+        st = self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32)
         yqk = self._buf("aud_qk", (nb * N, 2 * Da))
         vt = self._buf("aud_vt", (nb, nh, hd, Npad), zero=True)
         ao = self._buf("aud_ao", (nb * N, Da))
@@ -390,12 +406,12 @@ class VidiEngine:
             hip.gemm(y1[0], A["conv2_w"], A["conv2_b"], x.view(Cc, N, Da), act=hip.ACT_GELU_ERF, residual=A["pos"], rmod=N,
                      M=N, K=3 * Da, ldx=2 * Da, batch=Cc, bsX=(Lm + 1) * Da, bsY=N * Da, bsR=0)
             for L in A["layers"]:
-                hip.norm(hip.NORM_LAYER, x, L["ln1w"], eps=cfg.aud_ln_eps, bias=L["ln1b"], out=h[:M])
-                hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+                hip.row_stats(x, st, cfg.aud_ln_eps)                   # LayerNorm folded into the projections, as in siglip_forward
+                hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh)
                 hip.attn_self(yqk[:M], vt, ao[:M], B=Cc, N=N, Npad=Npad, H=nh, D=hd, koff=Da, scale=hd ** -0.5)
                 hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-                hip.norm(hip.NORM_LAYER, x, L["ln2w"], eps=cfg.aud_ln_eps, bias=L["ln2b"], out=h[:M])
-                hip.gemm(h[:M], L["fc1"], L["b1"], f1[:M], act=hip.ACT_GELU_ERF)
+                hip.row_stats(x, st, cfg.aud_ln_eps)
+                hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=hip.ACT_GELU_ERF)
                 hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
                 if self.dtype == torch.float16:                     # TP whisper:409-411 overflow guard
                     cv = torch.finfo(torch.float16).max - 1000
@@ -482,8 +498,7 @@ class VidiEngine:
         gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
         eps = cfg.rms_norm_eps
         for li, L in enumerate(self.layers if ntot > 0 else []):
-            if self.mistral or li == 0:                                                              # Gemma2 wiring, li > 0: produced by the previous layer's fused pass
-                hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                           # gemma.py:183-184 / mistral.py:204-205
+            hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184 / mistral.py:204-205
             hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
             if li == Lr - 1:
                 break                                                                                # dead update on the last layer
@@ -493,13 +508,15 @@ class VidiEngine:
                 hip.gemm_glu(hbuf, L["wgu"], gt, act=hip.ACT_SILU)
                 hip.gemm(gt, L["wdown"], None, X, residual=X)                                        # :135
                 continue
-            # residual + post-norm and the following pre-norm run as ONE pass over the rows (vidi_resid_norm2: the arithmetic and
-            # rounding points of NORM_GEMMA_ADD followed by NORM_GEMMA, bit-identical; 8 instead of 10 row passes per layer)
+            # (fusing each post-norm + residual with the following pre-norm through vidi_resid_norm2 — the decode path's kernel, which
+            #  requests all six operands up front — measured SLOWER at 126 080 rows: 233 vs 193 ms of norm time per prefill,
+            #  4.3 vs 5.1 TB/s; profiles/r2_notes.md)
             hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)                               # :196-197 o_proj(repeat_kv(V))
-            hip.resid_norm2(u, None, None, X, L["ln_post_attn"], L["ln_pre_ffn"], X, hbuf, eps=eps)  # :198-201 + :118
+            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_attn"], eps=eps, residual=X, out=X)           # :198-201
+            hip.norm(hip.NORM_GEMMA, X, L["ln_pre_ffn"], eps=eps, out=hbuf)                          # :118
             hip.gemm_geglu(hbuf, L["wgu"], gt)                                                       # :119 gate/up + GeGLU
             hip.gemm(gt, L["wdown"], None, u)                                                        # :119 down_proj
-            hip.resid_norm2(u, None, None, X, L["ln_post_ffn"], self.layers[li + 1]["ln_in"], X, hbuf, eps=eps)   # :120-121 + next layer's :183
+            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_ffn"], eps=eps, residual=X, out=X)            # :120-121
         if check_masks:
             # one host sync per VIDEO (the reference syncs per layer per step: xattn.py:214-215)
             for name, m in (("img", img_mask), ("aud", aud_mask)):

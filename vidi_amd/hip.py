@@ -32,6 +32,9 @@ SIGNATURES = {
     "vidi_resize_bilinear_ac": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
     "vidi_gemm_qkv_vt": [_c_vp] * 5 + [_c_int] * 13 + [_c_vp],
     "vidi_gemm_kv_cache": [_c_vp] * 5 + [_c_int] * 10 + [_c_vp],
+    "vidi_row_stats": [_c_vp, _c_vp, _c_ll, _c_int, _c_ll, _c_f, _c_int, _c_vp],
+    "vidi_gemm_ln": [_c_vp] * 6 + [_c_int] * 9 + [_c_vp],
+    "vidi_gemm_qkv_vt_ln": [_c_vp] * 7 + [_c_int] * 13 + [_c_vp],
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
@@ -106,6 +109,12 @@ def _work(name, a):
         return "gemm", 2.0 * a[3] * (2 * a[4]) * a[5], "flop"
     if name == "vidi_gemm_qkv_vt":
         return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
+    if name == "vidi_gemm_qkv_vt_ln":
+        return "gemm", 2.0 * a[7] * a[8] * a[9], "flop"
+    if name == "vidi_gemm_ln":
+        return "gemm", 2.0 * a[6] * a[7] * a[8], "flop"
+    if name == "vidi_row_stats":
+        return "norm", float(a[2]) * a[3] * 2, "byte"
     if name == "vidi_gemm_kv_cache":
         return "gemm", 2.0 * a[5] * (2 * a[6]) * a[7], "flop"
     if name == "vidi_attn_self":
@@ -137,6 +146,10 @@ def _alg_bytes(name, a):
         return 2.0 * (a[3] * a[5] + 2 * a[4] * a[5] + a[3] * a[4])
     if name == "vidi_gemm_qkv_vt":
         return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6])
+    if name == "vidi_gemm_qkv_vt_ln":
+        return 2.0 * (a[7] * a[9] + a[8] * a[9] + a[7] * a[8])
+    if name == "vidi_gemm_ln":
+        return 2.0 * (a[6] * a[8] + a[7] * a[8] + a[6] * a[7])
     if name == "vidi_gemm_kv_cache":
         return 2.0 * (a[5] * a[7] + 2 * a[6] * a[7] + 2 * a[5] * a[6])
     return 0.0
@@ -276,6 +289,45 @@ def gemm_qkv_vt(x, w, bias, yqk, vt, *, vstart, hd, seq, seqpad, nheads, tile_cf
     M, K = x.shape
     _check(lib.vidi_gemm_qkv_vt(_p(x), _p(w), _p(bias), _p(yqk), _p(vt), M, w.shape[0], K, x.stride(0), w.stride(0),
                                 yqk.stride(0), vstart, hd, seq, seqpad, nheads, tile_cfg, _dt(x), _stream()), "vidi_gemm_qkv_vt")
+
+
+def row_stats(x: torch.Tensor, stats: torch.Tensor, eps: float) -> torch.Tensor:
+    """stats[m] = (mean, rstd) of LayerNorm over row m of x — consumed by gemm_ln / gemm_qkv_vt_ln (LayerNorm folded into the projection)"""
+    _rowmajor(x, "x")
+    rows, H = x.shape
+    if stats.dtype != torch.float32 or stats.numel() < 2 * rows or not stats.is_contiguous():
+        raise VidiHipError("row_stats: stats must be a contiguous fp32 buffer of at least 2*rows elements")
+    _check(load_library().vidi_row_stats(_p(x), _p(stats), rows, H, x.stride(0), float(eps), _dt(x), _stream()), "vidi_row_stats")
+    return stats
+
+
+def _ln_vecs(stats, colsum, shift, M, N):
+    for t, n, name in ((stats, 2 * M, "stats"), (colsum, N, "colsum"), (shift, N, "shift")):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < n:
+            raise VidiHipError(f"folded LayerNorm: `{name}` must be a contiguous fp32 tensor of at least {n} elements")
+
+
+def gemm_ln(x, wf, stats, colsum, shift, out=None, *, act: int = ACT_NONE, tile_cfg: int = -1):
+    """out = act(Linear(LayerNorm(x))) with the LayerNorm folded: wf = W * gamma, colsum[n] = sum_k wf[n,k], shift = W beta + bias"""
+    lib = load_library()
+    _rowmajor(x, "x"); _rowmajor(wf, "wf")
+    M, K = x.shape
+    N = wf.shape[0]
+    _ln_vecs(stats, colsum, shift, M, N)
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _check(lib.vidi_gemm_ln(_p(x), _p(wf), _p(stats), _p(colsum), _p(shift), _p(out), M, N, K, x.stride(0), wf.stride(0), out.stride(0),
+                            act, tile_cfg, _dt(x), _stream()), "vidi_gemm_ln")
+    return out
+
+
+def gemm_qkv_vt_ln(x, wf, stats, colsum, shift, yqk, vt, *, vstart, hd, seq, seqpad, nheads, tile_cfg=-1):
+    lib = load_library()
+    M, K = x.shape
+    _ln_vecs(stats, colsum, shift, M, wf.shape[0])
+    _check(lib.vidi_gemm_qkv_vt_ln(_p(x), _p(wf), _p(stats), _p(colsum), _p(shift), _p(yqk), _p(vt), M, wf.shape[0], K, x.stride(0),
+                                   wf.stride(0), yqk.stride(0), vstart, hd, seq, seqpad, nheads, tile_cfg, _dt(x), _stream()),
+           "vidi_gemm_qkv_vt_ln")
 
 
 def gemm_kv_cache(x, wkv, kc, vtc, vrow, *, kvd, hd, ntile64, tok0, tile_cfg=-1):
