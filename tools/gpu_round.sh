@@ -22,6 +22,15 @@ prof)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
+abln)
+  timeout 900 python tools/ab_ln_fold.py 1440 3 > $OUT/ab_ln_fold.jsonl 2> $OUT/ab_ln_fold.err; echo "abln rc=$?"; cat $OUT/ab_ln_fold.jsonl ;;
+dist2)
+  # two ranks sharing the one GPU of the box (gloo transport; RCCL refuses two ranks on one device): the torchrun / sharded code path
+  # of bench.py end to end, on a 10-minute video so both ranks fit
+  VIDI_DIST_BACKEND=gloo VIDI_FORCE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
+      bench.py --gpus 2 --frames 600 --steps 1 --warmup 1 --no-preproc > $OUT/bench_dist2.json 2> $OUT/bench_dist2.err; echo "dist2 rc=$?"
+  timeout 600 python bench.py --frames 600 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
+  python tools/show_bench.py $OUT/bench_dist2.json $OUT/bench_dist1.json 2>/dev/null | grep -E "value|stages" ;;
 chunk)
   timeout 900 python tools/bench_vis_chunk.py 3600 > $OUT/vis_chunk.jsonl 2> $OUT/vis_chunk.err; echo "chunk rc=$?"; cat $OUT/vis_chunk.jsonl ;;
 pmc)

@@ -260,8 +260,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                         v[2] += T::to_f32((u16)(bv[1] & 0xffff)); v[3] += T::to_f32((u16)(bv[1] >> 16));
                     }
                     if constexpr (lnf) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(lnRs[b], v[e] - lnMu[b] * lnS[a][e], lnC[a][e]);
+                        // y = rstd * (acc - mean * s) + c  ==  rstd * acc + (c - rstd * mean * s): two packed FMAs per register pair
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const float t = -lnRs[b] * lnMu[b];
+                        const f32x2 tt = {t, t}, rr2 = {lnRs[b], lnRs[b]};
+                        const f32x2 u0 = __builtin_elementwise_fma(tt, f32x2{lnS[a][0], lnS[a][1]}, f32x2{lnC[a][0], lnC[a][1]});
+                        const f32x2 u1 = __builtin_elementwise_fma(tt, f32x2{lnS[a][2], lnS[a][3]}, f32x2{lnC[a][2], lnC[a][3]});
+                        const f32x2 y0 = __builtin_elementwise_fma(rr2, f32x2{v[0], v[1]}, u0);
+                        const f32x2 y1 = __builtin_elementwise_fma(rr2, f32x2{v[2], v[3]}, u1);
+                        v[0] = y0[0]; v[1] = y0[1]; v[2] = y1[0]; v[3] = y1[1];
                     }
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                     const int m = mrow0 + l15;

@@ -19,6 +19,7 @@ Design choices that differ from the reference on purpose (results identical):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -104,6 +105,8 @@ class VidiEngine:
         # gemma.py:353 multiplies every embedding stream by sqrt(H) rounded to the model dtype; Mistral has no normalizer
         self.normalizer = 1.0 if self.mistral else float(torch.tensor(cfg.hidden_size ** 0.5, dtype=dtype).float())
         self.glu_act = hip.ACT_SILU if self.mistral else hip.ACT_GELU_TANH
+        # towers: LayerNorm folded into the q/k/v and fc1 projections (default) or run as its own row pass (VIDI_LN_FOLD=0: the A/B arm)
+        self.ln_fold = os.environ.get("VIDI_LN_FOLD", "1") != "0"
         self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -184,9 +187,9 @@ class VidiEngine:
             L["fc1"], L["b1"], L["fc2"], L["b2"] = fc1, b1, fc2, g(p + "mlp.fc2.bias")
             for n, k in (("layer_norm1", "ln1"), ("layer_norm2", "ln2")):
                 L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
-            # layer_norm1 -> q/k/v_proj and layer_norm2 -> fc1 with the LayerNorm folded in (the plain weights are dropped)
-            L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
-            L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
+            if self.ln_fold:    # layer_norm1 -> q/k/v_proj and layer_norm2 -> fc1 with the LayerNorm folded in (the plain weights are dropped)
+                L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
+                L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
             self.vis["layers"].append(L)
 
         # ---- Whisper encoder ----
@@ -209,8 +212,9 @@ class VidiEngine:
             L["fc1"], L["b1"], L["fc2"], L["b2"] = g(p + "fc1.weight"), g(p + "fc1.bias"), g(p + "fc2.weight"), g(p + "fc2.bias")
             for n, k in (("self_attn_layer_norm", "ln1"), ("final_layer_norm", "ln2")):
                 L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
-            L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
-            L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
+            if self.ln_fold:
+                L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
+                L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
             self.aud["layers"].append(L)
 
         # ---- multimodal glue ----
@@ -270,6 +274,27 @@ class VidiEngine:
             flag.fill_(1)
         return flag
 
+    def _ln_qkv(self, x, L, st, h, yqk, vt, eps, **kw):
+        """LayerNorm -> q/k/v projection of an encoder layer.  Folded (default): LayerNorm(x) is never written — one read-only pass
+        leaves (mean, rstd) per row and the projection's epilogue applies them (vidi_gemm_ln: Linear(LayerNorm(x)) ==
+        rstd * (x Wf^T - mean * colsum) + shift)."""
+        M = x.shape[0]
+        if self.ln_fold:
+            hip.row_stats(x, st, eps)
+            hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, **kw)
+        else:
+            hip.norm(hip.NORM_LAYER, x, L["ln1w"], eps=eps, bias=L["ln1b"], out=h[:M])
+            hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, **kw)
+
+    def _ln_fc1(self, x, L, st, h, f1, eps, act):
+        M = x.shape[0]
+        if self.ln_fold:
+            hip.row_stats(x, st, eps)
+            hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=act)
+        else:
+            hip.norm(hip.NORM_LAYER, x, L["ln2w"], eps=eps, bias=L["ln2b"], out=h[:M])
+            hip.gemm(h[:M], L["fc1"], L["b1"], f1[:M], act=act)
+
     def pos_table(self, which: str, l: int, N: int, i0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
         """rms_norm(LearnablePosEmbd(...)) rows [i0, i0+rows) of l — pos.py:41-65, multimodal.py:194-197."""
         rows = l if rows is None else rows
@@ -295,7 +320,8 @@ class VidiEngine:
         fc = max(1, cfg.vis_frames_per_chunk)
         Mmax = min(T, fc) * N
         A = self._buf("vis_A", (Mmax, V["kpad"]))
-        st = self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32)
+        st = self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32) if self.ln_fold else None
+        h = None if self.ln_fold else self._buf("vis_h", (Mmax, Hv))
         yqk = self._buf("vis_qk", (Mmax, 2 * Hv))
         vt = self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True)
         ao = self._buf("vis_ao", (Mmax, Hv))
@@ -308,14 +334,10 @@ class VidiEngine:
             hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
             hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
             for L in V["layers"]:
-                # LayerNorm(x) is never written: one read-only pass leaves (mean, rstd) per row and the projection's epilogue
-                # applies them (vidi_gemm_ln: Linear(LayerNorm(x)) == rstd * (x Wf^T - mean * colsum) + shift)
-                hip.row_stats(x, st, cfg.vis_ln_eps)
-                hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+                self._ln_qkv(x, L, st, h, yqk, vt, cfg.vis_ln_eps, vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh)
                 hip.attn_self(yqk[:M], vt, ao[:M], B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=hd ** -0.5)
                 hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-                hip.row_stats(x, st, cfg.vis_ln_eps)
-                hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=hip.ACT_GELU_TANH)
+                self._ln_fc1(x, L, st, h, f1, cfg.vis_ln_eps, hip.ACT_GELU_TANH)
                 hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
         return out.view(T, N, Hv)
 
@@ -388,7 +410,8 @@ class VidiEngine:
         melT = self._buf("aud_melT", (nb * (Lm + 2) + 4, nm), zero=True)[: nb * (Lm + 2)].view(nb, Lm + 2, nm)
         y1 = self._buf("aud_y1", (nb, Lm + 1, Da), zero=True)              # row 0 = left zero pad of conv2
         y1[:, 0].zero_()
-        st = self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32)
+        st = self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32) if self.ln_fold else None
+        h = None if self.ln_fold else self._buf("aud_h", (nb * N, Da))
         yqk = self._buf("aud_qk", (nb * N, 2 * Da))
         vt = self._buf("aud_vt", (nb, nh, hd, Npad), zero=True)
         ao = self._buf("aud_ao", (nb * N, Da))
@@ -406,12 +429,10 @@ class VidiEngine:
             hip.gemm(y1[0], A["conv2_w"], A["conv2_b"], x.view(Cc, N, Da), act=hip.ACT_GELU_ERF, residual=A["pos"], rmod=N,
                      M=N, K=3 * Da, ldx=2 * Da, batch=Cc, bsX=(Lm + 1) * Da, bsY=N * Da, bsR=0)
             for L in A["layers"]:
-                hip.row_stats(x, st, cfg.aud_ln_eps)                   # LayerNorm folded into the projections, as in siglip_forward
-                hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh)
+                self._ln_qkv(x, L, st, h, yqk, vt, cfg.aud_ln_eps, vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh)
                 hip.attn_self(yqk[:M], vt, ao[:M], B=Cc, N=N, Npad=Npad, H=nh, D=hd, koff=Da, scale=hd ** -0.5)
                 hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-                hip.row_stats(x, st, cfg.aud_ln_eps)
-                hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=hip.ACT_GELU_ERF)
+                self._ln_fc1(x, L, st, h, f1, cfg.aud_ln_eps, hip.ACT_GELU_ERF)
                 hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
                 if self.dtype == torch.float16:                     # TP whisper:409-411 overflow guard
                     cv = torch.finfo(torch.float16).max - 1000
