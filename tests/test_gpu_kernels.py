@@ -253,6 +253,36 @@ def test_gemm_ln_equals_layernorm_then_linear(hip, dt, act, M, N, K, cfg):
     report(f"gemm_ln act={act}", y, ref, *tol(dt, ref.std().item(), k=2 if act != "none" else 1))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K,cfg", [(12900, 1152, 1152, -1), (12900, 1152, 4352, 5), (10001, 1280, 1280, -1), (300, 352, 192, -1), (70, 64, 64, -1)])
+def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
+    """out_proj / fc2 + residual with the fused emission of the stored rows' partial sums (persistent kernel) or the one-pass
+    fallback (small problems), in place (Y aliases R, as the towers call it): Y equals the plain bias + residual GEMM bit for bit,
+    and vidi_ln_finalize of the partials equals the two-pass row statistics of Y (row_stats) to fp32 round-off."""
+    x = seeded((M, K), 80, dtype=dt); w = seeded((N, K), 81, 0.03, dtype=dt); b = seeded((N,), 82, dtype=dt)
+    r = (seeded((M, N), 83, 2.0) + seeded((M, 1), 84, 1.5)).to(dt)
+    y_ref = r.clone().cuda()
+    hip.gemm(dev(x), dev(w), dev(b), y_ref, residual=y_ref, tile_cfg=cfg)
+    y = r.clone().cuda()
+    nstr = (N + 127) // 128
+    part = torch.full((2 * M * nstr,), float("nan"), dtype=torch.float32).cuda()
+    hip.gemm_res_stats(dev(x), dev(w), dev(b), y, y, part, tile_cfg=cfg)
+    assert torch.equal(y, y_ref)
+    p = part.view(M, nstr, 2).cpu()
+    assert torch.isfinite(p).all()
+    yf = y.float().cpu()
+    pad = torch.zeros((M, nstr * 128)); pad[:, :N] = yf
+    strips = pad.view(M, nstr, 128)
+    report("partial sums", p[..., 0], strips.sum(-1), 2e-4 * float(yf.abs().mean()) * 128, 1e-5)
+    report("partial sums of squares", p[..., 1], (strips * strips).sum(-1), 1e-4 * float((yf * yf).mean()) * 128, 1e-5)
+    st = torch.zeros(2 * M, dtype=torch.float32).cuda(); st2 = torch.zeros(2 * M, dtype=torch.float32).cuda()
+    hip.ln_finalize(part, st, M, N, 1e-6)
+    hip.row_stats(y, st2, 1e-6)
+    a, bb = st.view(M, 2).cpu(), st2.view(M, 2).cpu()
+    report("finalize mean", a[:, 0], bb[:, 0], 1e-5, 1e-5)
+    report("finalize rstd", a[:, 1], bb[:, 1], 0.0, 2e-5)
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 5])
 @pytest.mark.parametrize("hd,N,nh,B", [(72, 729, 4, 2), (16, 49, 4, 2), (64, 1500, 4, 12)])
 def test_gemm_qkv_vt_ln(hip, hd, N, nh, B, cfg):

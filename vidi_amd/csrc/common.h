@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // ---- C-ABI constants (mirrored in include/vidi_hip.h) -------------------------------------
 #define VIDI_DT_BF16 0
@@ -21,6 +22,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15); every lane of the row gets the total.  All 64 lanes must be active.
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});        // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});        // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});       // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});       // row_mirror
+    return v;
+}
 
 // ---- scalar conversions -------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }

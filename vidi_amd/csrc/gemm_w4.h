@@ -39,8 +39,9 @@ struct W4Geom {
 // (ACT_NONE / ACT_GELU_TANH / ACT_GELU_ERF), residual (0 none, 1 row m, 2 row m % rmod)
 // LNF: LayerNorm folded into the projection (GemmParams::ln_stats / ln_s / ln_c): y = rstd_m * (acc - mean_m * s_n) + c_n replaces
 // the bias add (c carries the bias)
-template <bool BIAS, int ACT, int RES, bool LNF = false>
-struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF; };
+// STATS: the stored rows' per-strip partial sums go to GemmParams::stat_part (bias + residual producers of a LayerNorm input)
+template <bool BIAS, int ACT, int RES, bool LNF = false, bool STATS = false>
+struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF, stats = STATS; };
 
 template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
 #pragma unroll
             for (int j = 0; j < NRD; ++j) val[j] = *(const u32x4*)(scr + (j * RPI + rr) * SROW + cc * 16);
         };
+        constexpr bool emit_stats = (MODE == MODE_PLAIN) && EPI::stats && (EPI::res != 0);
         auto store = [&](int b) {
             const int mrow0 = em0 + wm * 128 + b * 16;
 #pragma unroll
@@ -325,6 +327,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                 bool ok = (m < p.M) && (n < Nout);
                 if constexpr (MODE == MODE_QKV_VT) ok = ok && (n < p.vstart);
                 if constexpr (LAB::no_store) ok = ok && (p.M < 0);
+                if constexpr (emit_stats) {
+                    // every lane takes part (row reductions below run on whole 16-lane rows); out-of-range lanes contribute zeros.
+                    // The residual chunk was loaded from a clamped address, the staged value is finite: nothing here can fault.
+                    float x[8], r[8];
+                    unpack8<T>(val[j], x);
+                    unpack8<T>(res[b % 3][j], r);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        x[e] = rnd<T>(x[e] + r[e]);                       // the value that is stored (and that the next LayerNorm reads)
+                        s1 += x[e];
+                        s2 = __builtin_fmaf(x[e], x[e], s2);
+                    }
+                    if (!ok) { s1 = 0.f; s2 = 0.f; }
+                    s1 = row16_sum(s1); s2 = row16_sum(s2);               // the 16 lanes cc = 0..15 hold this row's 128 columns
+                    const int strip = no0 >> 7;
+                    if (cc == 0 && m < p.M && no0 < Nout)
+                        *(f32x2_t*)(p.stat_part + ((size_t)m * ((Nout + 127) >> 7) + strip) * 2) = f32x2_t{s1, s2};
+                    if (ok) *(u32x4*)(Yb + (size_t)m * p.ldy + n) = pack8<T>(x);
+                    continue;
+                }
                 if (!ok) continue;
                 if constexpr (MODE == MODE_KV_CACHE) {
                     if (n < p.kvd) {

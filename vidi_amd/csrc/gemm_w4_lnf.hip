@@ -3,6 +3,10 @@
 #include "gemm_w4_launch.h"
 template <typename T>
 static int lnf(const GemmParams& p, int batch, int mode, hipStream_t st) {
+    if (p.stat_part) {          // producer side: bias + residual (row m) epilogue that also emits the rows' per-strip partial sums
+        if (mode != MODE_PLAIN || batch != 1 || !p.bias || !p.R || p.rmod < p.M || p.act != ACT_NONE || p.ln_stats) return VIDI_ERR_ARG;
+        return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 1, false, true>>(p, batch, st);
+    }
     if (batch != 1 || p.R || !p.ln_s || !p.ln_c) return VIDI_ERR_ARG;
     if (mode == MODE_QKV_VT) return launch_w4<T, MODE_QKV_VT, false, Epi<true, ACT_NONE, 0, true>>(p, batch, st);
     if (mode != MODE_PLAIN) return VIDI_ERR_ARG;

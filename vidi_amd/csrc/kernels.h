@@ -37,6 +37,10 @@ struct GemmParams {
     //   ln_stats[m] = (mean_m, rstd_m)  (vidi_row_stats),  ln_s[n] = sum_k W'[n][k],  ln_c[n] = sum_k W[n][k] * beta[k] + bias[n]   (fp32)
     // == Linear(LayerNorm(x)) without materialising LayerNorm(x).  Null ln_stats: plain bias epilogue.
     const float* ln_stats; const float* ln_s; const float* ln_c;
+    // producer side of the same fusion: a bias + residual epilogue that also leaves, per output row and 128-column strip, the
+    // partial sums (sum y, sum y^2) of the values it stored — stat_part[m][strip][2], strips = ceil(N / 128) — so the NEXT
+    // LayerNorm's statistics need no pass over Y (vidi_ln_finalize turns them into (mean, rstd)).  Null: off.
+    float* stat_part;
 };
 
 struct AttnSelfParams {
@@ -101,6 +105,8 @@ int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int row
 int vidi_rope_cache_dispatch(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cs, const void* sn, int B, int Lq,
                              int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, hipStream_t st);
 int vidi_norm_dispatch(const NormParams& p, int mode, int dtype, hipStream_t st);
+int vidi_ln_finalize_dispatch(const float* part, float* stats, long long rows, int nstr, int H, float eps, hipStream_t st);
+int vidi_row_partials_dispatch(const void* Y, float* part, long long rows, int N, long long ldy, int dtype, hipStream_t st);
 int vidi_row_stats_dispatch(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, hipStream_t st);
 int vidi_ew_dispatch(int op, void** a, const long long* i, const float* f, int dtype, hipStream_t st);
 int vidi_sinusoid_dispatch(float* pe, const float* div, int rows, int i0, int l, int N, int d, hipStream_t st);

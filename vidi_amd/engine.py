@@ -274,26 +274,32 @@ class VidiEngine:
             flag.fill_(1)
         return flag
 
-    def _ln_qkv(self, x, L, st, h, yqk, vt, eps, **kw):
-        """LayerNorm -> q/k/v projection of an encoder layer.  Folded (default): LayerNorm(x) is never written — one read-only pass
-        leaves (mean, rstd) per row and the projection's epilogue applies them (vidi_gemm_ln: Linear(LayerNorm(x)) ==
-        rstd * (x Wf^T - mean * colsum) + shift)."""
+    # ---- encoder-layer pieces with the LayerNorms folded away (SigLIP and Whisper share the layer structure) ----
+    #   x -> LN1 -> q/k/v -> attention -> out_proj + x -> LN2 -> fc1 + GELU -> fc2 + x
+    # Folded (default): LayerNorm(x) is never written and x is never re-read for statistics.  The GEMM that PRODUCES x (out_proj / fc2
+    # with the residual add) leaves per-row partial sums of what it stored (vidi_gemm_res_stats), a tiny launch turns them into
+    # (mean, rstd) per row (vidi_ln_finalize) and the GEMM that CONSUMES LayerNorm(x) applies them in its epilogue (vidi_gemm_ln:
+    # Linear(LayerNorm(x)) == rstd * (x Wf^T - mean * colsum) + shift).  Only the tower's first LayerNorm needs a pass (row_stats).
+    def _tower_layer(self, x, L, ws, eps, act, attn_kw, qkv_kw):
         M = x.shape[0]
+        st, part, h, yqk, vt, ao, f1 = ws["st"], ws["part"], ws["h"], ws["yqk"], ws["vt"], ws["ao"], ws["f1"]
+        Hd = x.shape[1]
         if self.ln_fold:
-            hip.row_stats(x, st, eps)
-            hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, **kw)
+            hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, **qkv_kw)
+            hip.attn_self(yqk[:M], vt, ao[:M], **attn_kw)
+            hip.gemm_res_stats(ao[:M], L["wo"], L["bo"], x, x, part)
+            hip.ln_finalize(part, st, M, Hd, eps)
+            hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=act)
+            hip.gemm_res_stats(f1[:M], L["fc2"], L["b2"], x, x, part)
+            hip.ln_finalize(part, st, M, Hd, eps)                     # statistics of the NEXT layer's first LayerNorm
         else:
             hip.norm(hip.NORM_LAYER, x, L["ln1w"], eps=eps, bias=L["ln1b"], out=h[:M])
-            hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, **kw)
-
-    def _ln_fc1(self, x, L, st, h, f1, eps, act):
-        M = x.shape[0]
-        if self.ln_fold:
-            hip.row_stats(x, st, eps)
-            hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=act)
-        else:
+            hip.gemm_qkv_vt(h[:M], L["wqkv"], L["bqkv"], yqk[:M], vt, **qkv_kw)
+            hip.attn_self(yqk[:M], vt, ao[:M], **attn_kw)
+            hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
             hip.norm(hip.NORM_LAYER, x, L["ln2w"], eps=eps, bias=L["ln2b"], out=h[:M])
             hip.gemm(h[:M], L["fc1"], L["b1"], f1[:M], act=act)
+            hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
 
     def pos_table(self, which: str, l: int, N: int, i0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
         """rms_norm(LearnablePosEmbd(...)) rows [i0, i0+rows) of l — pos.py:41-65, multimodal.py:194-197."""
@@ -320,12 +326,12 @@ class VidiEngine:
         fc = max(1, cfg.vis_frames_per_chunk)
         Mmax = min(T, fc) * N
         A = self._buf("vis_A", (Mmax, V["kpad"]))
-        st = self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32) if self.ln_fold else None
-        h = None if self.ln_fold else self._buf("vis_h", (Mmax, Hv))
-        yqk = self._buf("vis_qk", (Mmax, 2 * Hv))
-        vt = self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True)
-        ao = self._buf("vis_ao", (Mmax, Hv))
-        f1 = self._buf("vis_f1", (Mmax, V["ipad"]))
+        fold = self.ln_fold
+        ws = {"st": self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32) if fold else None,
+              "part": self._buf("vis_part", (2 * Mmax * ((Hv + 127) // 128),), dtype=torch.float32) if fold else None,
+              "h": None if fold else self._buf("vis_h", (Mmax, Hv)),
+              "yqk": self._buf("vis_qk", (Mmax, 2 * Hv)), "vt": self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True),
+              "ao": self._buf("vis_ao", (Mmax, Hv)), "f1": self._buf("vis_f1", (Mmax, V["ipad"]))}
         pixel = pixel.to(self.dtype).contiguous()
         for c0 in range(0, T, fc):
             c1 = min(T, c0 + fc)
@@ -333,12 +339,12 @@ class VidiEngine:
             x = out[c0 * N: c1 * N]
             hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
             hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
+            if fold:
+                hip.row_stats(x, ws["st"], cfg.vis_ln_eps)
             for L in V["layers"]:
-                self._ln_qkv(x, L, st, h, yqk, vt, cfg.vis_ln_eps, vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh)
-                hip.attn_self(yqk[:M], vt, ao[:M], B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=hd ** -0.5)
-                hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-                self._ln_fc1(x, L, st, h, f1, cfg.vis_ln_eps, hip.ACT_GELU_TANH)
-                hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
+                self._tower_layer(x, L, ws, cfg.vis_ln_eps, hip.ACT_GELU_TANH,
+                                  dict(B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=hd ** -0.5),
+                                  dict(vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh))
         return out.view(T, N, Hv)
 
     # -----------------------------------------------------------------------------------------
@@ -410,12 +416,12 @@ class VidiEngine:
         melT = self._buf("aud_melT", (nb * (Lm + 2) + 4, nm), zero=True)[: nb * (Lm + 2)].view(nb, Lm + 2, nm)
         y1 = self._buf("aud_y1", (nb, Lm + 1, Da), zero=True)              # row 0 = left zero pad of conv2
         y1[:, 0].zero_()
-        st = self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32) if self.ln_fold else None
-        h = None if self.ln_fold else self._buf("aud_h", (nb * N, Da))
-        yqk = self._buf("aud_qk", (nb * N, 2 * Da))
-        vt = self._buf("aud_vt", (nb, nh, hd, Npad), zero=True)
-        ao = self._buf("aud_ao", (nb * N, Da))
-        f1 = self._buf("aud_f1", (nb * N, cfg.aud_ffn_dim))
+        fold = self.ln_fold
+        ws = {"st": self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32) if fold else None,
+              "part": self._buf("aud_part", (2 * nb * N * ((Da + 127) // 128),), dtype=torch.float32) if fold else None,
+              "h": None if fold else self._buf("aud_h", (nb * N, Da)),
+              "yqk": self._buf("aud_qk", (nb * N, 2 * Da)), "vt": self._buf("aud_vt", (nb, nh, hd, Npad), zero=True),
+              "ao": self._buf("aud_ao", (nb * N, Da)), "f1": self._buf("aud_f1", (nb * N, cfg.aud_ffn_dim))}
         mel = mel.to(self.dtype).contiguous()
         for c0 in range(0, C, cb):
             c1 = min(C, c0 + cb)
@@ -428,15 +434,17 @@ class VidiEngine:
             # conv2 (k3,s2,p1): row t reads y1 rows 2t..2t+2; GELU(erf); + embed_positions
             hip.gemm(y1[0], A["conv2_w"], A["conv2_b"], x.view(Cc, N, Da), act=hip.ACT_GELU_ERF, residual=A["pos"], rmod=N,
                      M=N, K=3 * Da, ldx=2 * Da, batch=Cc, bsX=(Lm + 1) * Da, bsY=N * Da, bsR=0)
+            if fold:
+                hip.row_stats(x, ws["st"], cfg.aud_ln_eps)
             for L in A["layers"]:
-                self._ln_qkv(x, L, st, h, yqk, vt, cfg.aud_ln_eps, vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh)
-                hip.attn_self(yqk[:M], vt, ao[:M], B=Cc, N=N, Npad=Npad, H=nh, D=hd, koff=Da, scale=hd ** -0.5)
-                hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-                self._ln_fc1(x, L, st, h, f1, cfg.aud_ln_eps, hip.ACT_GELU_ERF)
-                hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
+                self._tower_layer(x, L, ws, cfg.aud_ln_eps, hip.ACT_GELU_ERF,
+                                  dict(B=Cc, N=N, Npad=Npad, H=nh, D=hd, koff=Da, scale=hd ** -0.5),
+                                  dict(vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh))
                 if self.dtype == torch.float16:                     # TP whisper:409-411 overflow guard
                     cv = torch.finfo(torch.float16).max - 1000
                     x.clamp_(min=-cv, max=cv)
+                    if fold:                                        # the clamp may have changed rows: their statistics again
+                        hip.row_stats(x, ws["st"], cfg.aud_ln_eps)
             hip.norm(hip.NORM_LAYER, x, A["lnw"], eps=cfg.aud_ln_eps, bias=A["lnb"], out=x)
         return out.view(C, N, Da)
 

@@ -34,6 +34,8 @@ SIGNATURES = {
     "vidi_gemm_kv_cache": [_c_vp] * 5 + [_c_int] * 10 + [_c_vp],
     "vidi_row_stats": [_c_vp, _c_vp, _c_ll, _c_int, _c_ll, _c_f, _c_int, _c_vp],
     "vidi_gemm_ln": [_c_vp] * 6 + [_c_int] * 9 + [_c_vp],
+    "vidi_gemm_res_stats": [_c_vp] * 6 + [_c_int] * 9 + [_c_vp],
+    "vidi_ln_finalize": [_c_vp, _c_vp, _c_ll, _c_int, _c_f, _c_vp],
     "vidi_gemm_qkv_vt_ln": [_c_vp] * 7 + [_c_int] * 13 + [_c_vp],
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
@@ -111,7 +113,7 @@ def _work(name, a):
         return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
     if name == "vidi_gemm_qkv_vt_ln":
         return "gemm", 2.0 * a[7] * a[8] * a[9], "flop"
-    if name == "vidi_gemm_ln":
+    if name == "vidi_gemm_ln" or name == "vidi_gemm_res_stats":
         return "gemm", 2.0 * a[6] * a[7] * a[8], "flop"
     if name == "vidi_row_stats":
         return "norm", float(a[2]) * a[3] * 2, "byte"
@@ -150,6 +152,8 @@ def _alg_bytes(name, a):
         return 2.0 * (a[7] * a[9] + a[8] * a[9] + a[7] * a[8])
     if name == "vidi_gemm_ln":
         return 2.0 * (a[6] * a[8] + a[7] * a[8] + a[6] * a[7])
+    if name == "vidi_gemm_res_stats":
+        return 2.0 * (a[6] * a[8] + a[7] * a[8] + 2 * a[6] * a[7])
     if name == "vidi_gemm_kv_cache":
         return 2.0 * (a[5] * a[7] + 2 * a[6] * a[7] + 2 * a[5] * a[6])
     return 0.0
@@ -298,6 +302,24 @@ def row_stats(x: torch.Tensor, stats: torch.Tensor, eps: float) -> torch.Tensor:
     if stats.dtype != torch.float32 or stats.numel() < 2 * rows or not stats.is_contiguous():
         raise VidiHipError("row_stats: stats must be a contiguous fp32 buffer of at least 2*rows elements")
     _check(load_library().vidi_row_stats(_p(x), _p(stats), rows, H, x.stride(0), float(eps), _dt(x), _stream()), "vidi_row_stats")
+    return stats
+
+
+def gemm_res_stats(x, w, bias, out, residual, part, *, tile_cfg: int = -1):
+    """out = x w^T + bias + residual, plus part[m][strip] = (sum, sum of squares) of the stored row values per 128-column strip
+    (the next LayerNorm's statistics without a pass over `out`: ln_finalize)"""
+    _rowmajor(x, "x"); _rowmajor(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if part.dtype != torch.float32 or not part.is_contiguous() or part.numel() < 2 * M * ((N + 127) // 128):
+        raise VidiHipError("gemm_res_stats: `part` must be a contiguous fp32 buffer of 2 * M * ceil(N/128) elements")
+    _check(load_library().vidi_gemm_res_stats(_p(x), _p(w), _p(bias), _p(out), _p(residual), _p(part), M, N, K, x.stride(0), w.stride(0),
+                                              out.stride(0), residual.stride(0), tile_cfg, _dt(x), _stream()), "vidi_gemm_res_stats")
+    return out
+
+
+def ln_finalize(part, stats, rows: int, N: int, eps: float):
+    _check(load_library().vidi_ln_finalize(_p(part), _p(stats), rows, N, float(eps), _stream()), "vidi_ln_finalize")
     return stats
 
 
