@@ -31,7 +31,10 @@ struct W4Geom {
     static constexpr int BN = 256, BM = 256, BK = 64, NT = 256, TN = 8, TM = 8, ROWB = 128;
     static constexpr int STAGE_BYTES = (BN + BM) * ROWB, RING = 2 * STAGE_BYTES;
     static constexpr int SCR_ROW = 128 * 2 + 16, SCR_BYTES = 16 * SCR_ROW;       // per-wave epilogue scratch: 16 rows x (128 cols + pad)
-    static constexpr int LDS_BYTES = RING + 4 * SCR_BYTES;
+    // epilogue constants of a tile (bias, or the folded-LayerNorm column sums / shifts and row statistics): DMA'd into LDS during the
+    // tile's first K iteration, two buffers by tile parity (a wave may start the next tile while another still reads in its epilogue)
+    static constexpr int CST_OFF = RING + 4 * SCR_BYTES, CST_BYTES = 4096;
+    static constexpr int LDS_BYTES = CST_OFF + 2 * CST_BYTES;
 };
 
 // compile-time epilogue shape of MODE_PLAIN (runtime flags made every strip a maze of scalar branches and put a vmcnt(0) —
@@ -120,6 +123,38 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     auto rdX = [&](const char* buf, int b, int s) { return *(const u32x4*)(buf + x_row_off + b * 16 * ROWB + (((4 * s + hi) ^ sw) << 4)); };
 #define VIDI_PIN __builtin_amdgcn_sched_barrier(0)
 
+    // ---- epilogue constants -> LDS (one 1 KB DMA per wave per tile, issued at the top of the tile's first iteration) ---------------
+    // A global load at the start of the epilogue would retire only after the ~26 DMA pieces of the NEXT tile that are in flight by
+    // then (vector memory operations retire in order): microseconds of exposed latency per tile.  Landing the constants in LDS
+    // under the K loop removes every load from the bias / folded-LayerNorm epilogues.
+    //   bias epilogues : wave 0 fetches bias[n0 .. n0+255] (bf16, 512 B; the upper half of the piece is never read)
+    //   folded LN      : wave 0 colsum[n0 ..], wave 1 shift[n0 ..] (fp32, 1 KB each), waves 2, 3 (mean, rstd) of rows m0 .. m0+255
+    constexpr bool cst_lnf = (MODE != MODE_GEGLU) && EPI::lnf;
+    constexpr bool cst_bias = (MODE != MODE_GEGLU) && EPI::bias && !EPI::lnf;
+    __amdgpu_buffer_rsrc_t srdC0, srdC1;
+    int tpar = 0;                                           // parity of the current tile (constant buffer)
+    auto rsrc_of = [](const void* base, unsigned long long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
+    };
+    if constexpr (cst_lnf) {
+        srdC0 = rsrc_of(wave == 0 ? p.ln_s : (wave == 1 ? p.ln_c : p.ln_stats), wave < 2 ? (unsigned long long)p.N * 4 : (unsigned long long)p.M * 8);
+    } else if constexpr (cst_bias) {
+        srdC0 = rsrc_of(p.bias, (unsigned long long)p.N * 2);
+    }
+    (void)srdC1;
+    auto issue_cst = [&]() {
+        if constexpr (LAB::no_dma) return;
+        char* dst = smem + G::CST_OFF + tpar * G::CST_BYTES;
+        if constexpr (cst_lnf) {
+            // out-of-range columns / rows read as zeros (buffer range check); they are masked in the epilogue
+            const unsigned voff = wave < 2 ? (unsigned)(n0 + 4 * lane) * 4u : (unsigned)(m0 + (wave - 2) * 128 + 2 * lane) * 8u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, voff, 0, 0, 0);
+        } else if constexpr (cst_bias) {
+            if (wave == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)(n0 + 8 * lane) * 2u, 0, 0, 0);
+        }
+    };
+
     // one K iteration: 128 MFMAs on slice kt; slice kt+1's step-0 fragments are fetched and slice kt+2 is DMA'd over slice kt's
     // buffer.  FIRST: first slice of a tile, the step-0 MFMAs take C = 0 (no accumulator clearing).  NEXT: the last two iterations
     // of a tile — slices kt+1 / kt+2 are the NEXT tile's (slice kt+2-nk of its operands), issued only when `more` (a next tile
@@ -135,6 +170,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             if constexpr (NEXT) { if (more) piece(bufc, ks2, q, next_t); }
             else piece(bufc, ks2, q, next_t);
         };
+        VIDI_PIN;
+        if constexpr (FIRST) issue_cst();
         VIDI_PIN;
         // ---------------- phase 1: step-0 MFMAs ----------------
 #pragma unroll
@@ -205,10 +242,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         constexpr bool wrap = (EPI::res == 2);
         const int Nout = GLU ? (p.N >> 1) : p.N;
         const int no0 = GLU ? (en0 >> 1) + wn * 64 : en0 + wn * 128;           // first output column of this wave's strips
+        const char* cst = smem + G::CST_OFF + tpar * G::CST_BYTES;     // this tile's constants (landed during its K loop)
         u32x2 bq[TN];
         if constexpr (has_bias) {
 #pragma unroll
-            for (int a = 0; a < TN; ++a) bq[a] = *(const u32x2*)(p.bias + min(en0 + wn * 128 + a * 16 + 4 * hi, p.N - 4));
+            for (int a = 0; a < TN; ++a) bq[a] = *(const u32x2*)(cst + (wn * 128 + a * 16 + 4 * hi) * 2);
         }
         // folded LayerNorm: this lane's column sums / shifts (4 consecutive columns per tile) and the (mean, rstd) of its 8 rows
         f32x4 lnS[lnf ? TN : 1], lnC[lnf ? TN : 1];
@@ -216,15 +254,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if constexpr (lnf) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
-                const int nc = min(en0 + wn * 128 + a * 16 + 4 * hi, p.N - 4);
-                lnS[a] = *(const f32x4*)(p.ln_s + nc);
-                lnC[a] = *(const f32x4*)(p.ln_c + nc);
+                lnS[a] = *(const f32x4*)(cst + (wn * 128 + a * 16 + 4 * hi) * 4);
+                lnC[a] = *(const f32x4*)(cst + 1024 + (wn * 128 + a * 16 + 4 * hi) * 4);
             }
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const int mr = min(em0 + wm * 128 + b * 16 + l15, p.M - 1);
-                lnMu[b] = p.ln_stats[2 * (size_t)mr];
-                lnRs[b] = p.ln_stats[2 * (size_t)mr + 1];
+                const f32x2_t ms = *(const f32x2_t*)(cst + 2048 + (wm * 128 + b * 16 + l15) * 8);
+                lnMu[b] = ms[0];
+                lnRs[b] = ms[1];
             }
         }
         const int rr = lane / CPRW, cc = lane % CPRW;                // this lane's (row in read group, chunk) of the read-back
@@ -453,6 +490,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if (!has_next) break;
         vb = nvb; m0 = nm0; n0 = nn0; bz = nbz; srdW = srdWn; srdX = srdXn;
         pb = (pb + nk) & 1;
+        tpar ^= 1;
     }
 #undef VIDI_PIN
     if constexpr (LAB::stamps) {
