@@ -22,6 +22,21 @@ prof)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
+labres)
+  # residual-ring depth A/B in the GEMM lab (binaries built in the container: tools/lab/gemm_lab_rd{3,5,6}), interleaved per shape
+  : > $OUT/lab_res.jsonl
+  for shape in siglip_o siglip_fc2 siglip_fc1; do for v in w4p w4p_br w4p_bt; do for rd in old 3 5 6 old 3 5 6; do
+    LAB_SHAPE=$shape timeout 120 tools/lab/gemm_lab_rd$rd $v 5 | sed "s/^{/{\"rd\": \"$rd\", /" >> $OUT/lab_res.jsonl
+  done; done; done
+  echo "labres rc=$?"; python - <<'PY'
+import json, collections
+acc = collections.defaultdict(list)
+for l in open("gpurun_out/lab_res.jsonl"):
+    if l.startswith("{"):
+        d = json.loads(l); acc[(d["shape"], d["variant"], d["rd"])].append(d["tflops"])
+for k in sorted(acc): print(k, [round(x) for x in acc[k]])
+PY
+  ;;
 abln)
   timeout 900 python tools/ab_ln_fold.py 1440 3 > $OUT/ab_ln_fold.jsonl 2> $OUT/ab_ln_fold.err; echo "abln rc=$?"; cat $OUT/ab_ln_fold.jsonl ;;
 dist2)

@@ -27,6 +27,10 @@
 #pragma once
 #include "gemm_tile.h"
 
+#ifndef VIDI_W4_RES_DEPTH
+#define VIDI_W4_RES_DEPTH 3
+#endif
+
 struct W4Geom {
     static constexpr int BN = 256, BM = 256, BK = 64, NT = 256, TN = 8, TM = 8, ROWB = 128;
     static constexpr int STAGE_BYTES = (BN + BM) * ROWB, RING = 2 * STAGE_BYTES;
@@ -338,19 +342,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         // residual chunks are requested two strips ahead (3-deep register ring, strips 0 and 1 before the first store): vector
         // memory operations retire in issue order, so a load issued right before its use would first wait for the stores of the
         // strips before it to be acknowledged
-        u32x4 val[NRD], res[has_res ? 3 : 1][NRD];
+        constexpr int RD = VIDI_W4_RES_DEPTH;                              // residual ring depth: strips b .. b + RD - 2 are in flight while strip b is stored
+        u32x4 val[NRD], res[has_res ? RD : 1][NRD];
         auto load_res = [&](auto bt) {
             constexpr int b = decltype(bt)::value;
             if constexpr (has_res && b < TM) {
 #pragma unroll
                 for (int j = 0; j < NRD; ++j) {
                     const int mc = min(em0 + wm * 128 + b * 16 + j * RPI + rr, p.M - 1), mr = wrap ? mc % p.rmod : mc;
-                    res[b % 3][j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
+                    res[b % RD][j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
                 }
             }
         };
         load_res(std::integral_constant<int, 0>{});
         load_res(std::integral_constant<int, 1>{});
+        if constexpr (RD > 3) load_res(std::integral_constant<int, 2>{});
+        if constexpr (RD > 4) load_res(std::integral_constant<int, 3>{});
+        if constexpr (RD > 5) load_res(std::integral_constant<int, 4>{});
         auto fetch = [&](int b) {
 #pragma unroll
             for (int j = 0; j < NRD; ++j) val[j] = *(const u32x4*)(scr + (j * RPI + rr) * SROW + cc * 16);
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                     // The residual chunk was loaded from a clamped address, the staged value is finite: nothing here can fault.
                     float x[8], r[8];
                     unpack8<T>(val[j], x);
-                    unpack8<T>(res[b % 3][j], r);
+                    unpack8<T>(res[b % RD][j], r);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                         if constexpr (has_res) {
                             float x[8], r[8];
                             unpack8<T>(v, x);
-                            unpack8<T>(res[has_res ? b % 3 : 0][j], r);
+                            unpack8<T>(res[has_res ? b % RD : 0][j], r);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
                             v = pack8<T>(x);
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             constexpr int b = decltype(bt)::value;
             VIDI_PIN;
             fetch(b);
-            load_res(std::integral_constant<int, b + 2>{});
+            load_res(std::integral_constant<int, b + RD - 1>{});
             VIDI_PIN;
             if constexpr (b + 1 < TM) stage(std::integral_constant<int, b + 1>{});
             VIDI_PIN;
