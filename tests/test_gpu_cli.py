@@ -71,3 +71,24 @@ def test_checkpoint_dir_to_answer_string(tmp_path, monkeypatch):
         assert int(out[0, i]) == int(ref_ids[0, i]), f"token {i}: {int(out[0, i])} != oracle {int(ref_ids[0, i])}"
         agreed += 1
     assert agreed >= 4, f"only {agreed} high-margin steps — pick another seed"
+
+    # (4) SURVEY 8f-4 end to end: model output -> ask() string -> spans -> VUE-TR scores (vidi_amd/eval_tr.py, itself pinned on the
+    # reference's qa_eval.py in tests/test_eval_tr.py).  Two queries against the same video; the ground truth is synthetic: query 0's
+    # truth IS the model's answer (IoU / precision / recall must come out as 1), query 1's truth is disjoint from it (all 0).
+    import json
+    from vidi_amd import eval_tr as E
+    answers = {0: got, 1: INF.ask("a cat sleeping.", "video.mp4", model, tok, ip, ap)}
+    spans = {q: E.parse_time_ranges(a) for q, a in answers.items()}
+    assert spans[0] and all(0 <= s <= e <= length + 1 for s, e in spans[0])            # well-formed HH:MM:SS ranges inside the video
+    gt = [{"query_id": 0, "gt": E.merge_time_spans(__import__("numpy").array(spans[0], dtype=float)).tolist(), "duration_category": "long",
+           "query_format": "phrase", "query_modality": "vision"},
+          {"query_id": 1, "gt": [[length + 10, length + 20]], "duration_category": "long", "query_format": "phrase", "query_modality": "vision+audio"}]
+    gt_path = str(tmp_path / "gt.json")
+    json.dump(gt, open(gt_path, "w"))
+    res = E.answers_to_results(answers)
+    sc = E.score_predictions(res, gt_path)
+    assert sc["overall"]["n"] == 2 and sc["vision"]["n"] == 1
+    # (AUCs over 101 thresholds: a perfect answer scores 0.995-1.0, a disjoint one 0-0.005)
+    assert sc["vision"]["iou"] > 0.99 and sc["vision"]["precision"] > 0.999 and sc["vision"]["recall"] > 0.999
+    assert sc["vision+audio"]["iou"] < 0.01 and sc["vision+audio"]["precision"] < 0.01 and sc["vision+audio"]["recall"] < 0.01
+    assert 0.49 < sc["overall"]["precision"] < 0.51 and 0.49 < sc["overall"]["iou"] < 0.51
