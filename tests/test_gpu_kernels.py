@@ -273,15 +273,20 @@ def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
     yf = y.float().cpu()
     pad = torch.zeros((M, nstr * 128)); pad[:, :N] = yf
     strips = pad.view(M, nstr, 128)
-    report("partial sums", p[..., 0], strips.sum(-1), 2e-4 * float(yf.abs().mean()) * 128, 1e-5)
-    report("partial sums of squares", p[..., 1], (strips * strips).sum(-1), 1e-4 * float((yf * yf).mean()) * 128, 1e-5)
+    # the fused emission sums the fp32 values before their rounding to the storage dtype: against sums of the STORED values that is
+    # 128 independent half-ulp roundings per strip (6-sigma bound below); the fallback pass reads the stored values (exact)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    rms = float(yf.pow(2).mean().sqrt())
+    report("partial sums", p[..., 0], strips.sum(-1), 6 * (128 / 12) ** 0.5 * ulp * rms + 1e-4 * rms * 128 ** 0.5, 1e-5)
+    report("partial sums of squares", p[..., 1], (strips * strips).sum(-1), 6 * (128 / 12) ** 0.5 * 2 * ulp * rms * rms * 3 + 1e-4 * rms * rms * 128 ** 0.5, 1e-5)
     st = torch.zeros(2 * M, dtype=torch.float32).cuda(); st2 = torch.zeros(2 * M, dtype=torch.float32).cuda()
     hip.ln_finalize(part, st, M, N, 1e-6)
     hip.row_stats(y, st2, 1e-6)
     a, bb = st.view(M, 2).cpu(), st2.view(M, 2).cpu()
-    report("finalize mean", a[:, 0], bb[:, 0], 1e-5, 1e-5)
-    report("finalize rstd", a[:, 1], bb[:, 1], 0.0, 2e-5)
-
+    # (mean, rstd) against the two-pass statistics of the stored rows: 1e-4 of the row spread / 2e-4 relative (bf16), i.e. 40x below
+    # the resolution of the consumer's bf16 output
+    report("finalize mean", a[:, 0], bb[:, 0], (1e-4 if dt == torch.bfloat16 else 2e-5) * rms, 1e-5)
+    report("finalize rstd", a[:, 1], bb[:, 1], 0.0, 2e-4 if dt == torch.bfloat16 else 4e-5)
 
 @pytest.mark.parametrize("cfg", [-1, 0, 5])
 @pytest.mark.parametrize("hd,N,nh,B", [(72, 729, 4, 2), (16, 49, 4, 2), (64, 1500, 4, 12)])

@@ -378,13 +378,18 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                     float x[8], r[8];
                     unpack8<T>(val[j], x);
                     unpack8<T>(res[b % RD][j], r);
-                    float s1 = 0.f, s2 = 0.f;
+                    // sums of the fp32 values BEFORE their rounding to T (packed adds / FMAs): the stored values differ by independent
+                    // half-ulp roundings, which move a 1152-column mean by ~3e-5 of the row's spread — far below what the consumer's
+                    // T-rounded output resolves; rounding first would cost two conversions per element here
+                    f32x2_t sa = {0.f, 0.f}, sq = {0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        x[e] = rnd<T>(x[e] + r[e]);                       // the value that is stored (and that the next LayerNorm reads)
-                        s1 += x[e];
-                        s2 = __builtin_fmaf(x[e], x[e], s2);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t y = f32x2_t{x[e], x[e + 1]} + f32x2_t{r[e], r[e + 1]};
+                        x[e] = y[0]; x[e + 1] = y[1];
+                        sa += y;
+                        sq = __builtin_elementwise_fma(y, y, sq);
                     }
+                    float s1 = sa[0] + sa[1], s2 = sq[0] + sq[1];
                     if (!ok) { s1 = 0.f; s2 = 0.f; }
                     s1 = row16_sum(s1); s2 = row16_sum(s2);               // the 16 lanes cc = 0..15 hold this row's 128 columns
                     const int strip = no0 >> 7;
