@@ -275,10 +275,11 @@ def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
     strips = pad.view(M, nstr, 128)
     # the fused emission sums the fp32 values before their rounding to the storage dtype: against sums of the STORED values that is
     # 128 independent half-ulp roundings per strip (6-sigma bound below); the fallback pass reads the stored values (exact)
-    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-    rms = float(yf.pow(2).mean().sqrt())
-    report("partial sums", p[..., 0], strips.sum(-1), 6 * (128 / 12) ** 0.5 * ulp * rms + 1e-4 * rms * 128 ** 0.5, 1e-5)
-    report("partial sums of squares", p[..., 1], (strips * strips).sum(-1), 6 * (128 / 12) ** 0.5 * 2 * ulp * rms * rms * 3 + 1e-4 * rms * rms * 128 ** 0.5, 1e-5)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11           # spacing of the storage dtype relative to the value
+    rms, ymax = float(yf.pow(2).mean().sqrt()), float(yf.abs().max())
+    six_sigma = 6 * (128 / 12) ** 0.5 * ulp                            # 128 independent roundings, each uniform in +-ulp*|y|/2
+    report("partial sums", p[..., 0], strips.sum(-1), six_sigma * ymax + 1e-4 * rms * 128 ** 0.5, 1e-5)
+    report("partial sums of squares", p[..., 1], (strips * strips).sum(-1), six_sigma * 2 * ymax * ymax + 1e-4 * rms * rms * 128 ** 0.5, 1e-5)
     st = torch.zeros(2 * M, dtype=torch.float32).cuda(); st2 = torch.zeros(2 * M, dtype=torch.float32).cuda()
     hip.ln_finalize(part, st, M, N, 1e-6)
     hip.row_stats(y, st2, 1e-6)

@@ -122,18 +122,31 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 }
 
 // ---- math ---------------------------------------------------------------------------------
+// 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715x^3) — torch gelu(approximate='tanh') — evaluated as x / (1 + exp(-2u)): one v_exp + one
+// v_rcp, no branches (tanhf() is ~50 instructions with divergent ranges; the epilogues evaluate this once per output element with the
+// matrix cores idle).  -2u*log2(e) = x * (K0 + K1 x^2) with the constants folded; the pair form runs the polynomial, the +1 and the final
+// product on packed fp32 instructions (v_pk_mul/fma/add_f32: two elements per issue slot), the scalar form is the same arithmetic
+// element by element (bit-identical results), so every kernel of the library rounds a GELU the same way.
+#define VIDI_GELU_K0 (-2.0f * 0.7978845608028654f * 1.4426950408889634f)
+#define VIDI_GELU_K1 (-2.0f * 0.7978845608028654f * 1.4426950408889634f * 0.044715f)
+__device__ __forceinline__ f32x2_t gelu_tanh_2(f32x2_t x) {
+    const f32x2_t k0 = {VIDI_GELU_K0, VIDI_GELU_K0}, k1 = {VIDI_GELU_K1, VIDI_GELU_K1}, one = {1.0f, 1.0f};
+    const f32x2_t w = x * __builtin_elementwise_fma(k1, x * x, k0);
+    const f32x2_t d = one + f32x2_t{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};      // exp(-2u); +inf for very negative x -> result -0
+    return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715x^3) — torch gelu(approximate='tanh').
-    // Evaluated as x / (1 + exp(-2u)): one v_exp + one v_rcp, no branches (tanhf() is ~50 instructions
-    // with divergent ranges; the epilogue evaluates this once per output element with the matrix cores idle).
-    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = 0.044715f;
-    const float x2 = x * x;
-    const float w = x * __builtin_fmaf(c1, x2, 1.0f);            // x + 0.044715 x^3
-    const float e = __builtin_amdgcn_exp2f(c0 * w);              // exp(-2u); +inf for very negative x -> result -0
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    const float w = x * __builtin_fmaf(VIDI_GELU_K1, x * x, VIDI_GELU_K0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
 }
 __device__ __forceinline__ float silu_f(float x) {                   // x * sigmoid(x) (MistralMLP act), branch-free
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ f32x2_t silu_2(f32x2_t x) {               // the same arithmetic on a pair (packed multiplies / add)
+    const f32x2_t k = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+    const f32x2_t w = k * x;
+    const f32x2_t d = one + f32x2_t{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
     // 0.5*x*(1+erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7), branch-free

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                     float x[8];
                     unpack8<T>(v, x);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = gelu_tanh_f(x[e]);
+                    for (int e = 0; e < 8; e += 2) { const f32x2_t y = gelu_tanh_2(f32x2_t{x[e], x[e + 1]}); x[e] = y[0]; x[e + 1] = y[1]; }
                     v = pack8<T>(x);
                 } else if (act_erf) {
                     float x[8];

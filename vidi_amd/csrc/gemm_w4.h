@@ -280,10 +280,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                     if ((a >> 1) & 1) continue;                       // up tiles are consumed with their gate tile
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float g = rnd<T>(aread(acc[a][b][e]));
-                        const float u = rnd<T>(aread(acc[a + 2][b][e]));
-                        v[e] = rnd<T>(glu_silu ? silu_f(g) : gelu_tanh_f(g)) * u;
+                    for (int e = 0; e < 4; e += 2) {                  // pairs: the activation's polynomial / products on packed fp32 math
+                        const f32x2_t g = {rnd<T>(aread(acc[a][b][e])), rnd<T>(aread(acc[a][b][e + 1]))};
+                        const f32x2_t act = glu_silu ? silu_2(g) : gelu_tanh_2(g);
+                        v[e] = rnd<T>(act[0]) * rnd<T>(aread(acc[a + 2][b][e]));
+                        v[e + 1] = rnd<T>(act[1]) * rnd<T>(aread(acc[a + 2][b][e + 1]));
                     }
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                     const int col = (a >> 2) * 32 + (a & 1) * 16 + 4 * hi;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                             float x[8];
                             unpack8<T>(v, x);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) x[e] = gelu_tanh_f(x[e]);
+                            for (int e = 0; e < 8; e += 2) { const f32x2_t y = gelu_tanh_2(f32x2_t{x[e], x[e + 1]}); x[e] = y[0]; x[e + 1] = y[1]; }
                             v = pack8<T>(x);
                         } else if constexpr (act_erf) {
                             float x[8];
