@@ -22,6 +22,12 @@ prof)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
+variants)
+  # regression sweep of the other bench configurations on the current build (BASELINE configs[1], [4]-shape, Vidi-7B, fp16, graph decode)
+  for v in "--frames 300" "--queries 8" "--preset vidi_7b" "--dtype fp16" "--decode-graph"; do
+    n=$(echo $v | tr -d ' -' ); timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-preproc $v > $OUT/bench_$n.json 2> $OUT/bench_$n.err; echo "bench $v rc=$?"
+    python tools/show_bench.py $OUT/bench_$n.json 2>/dev/null | grep -E "value|stages"
+  done ;;
 labres)
   # residual-ring depth A/B in the GEMM lab (binaries built in the container: tools/lab/gemm_lab_rd{3,5,6}), interleaved per shape
   : > $OUT/lab_res.jsonl
