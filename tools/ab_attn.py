@@ -1,0 +1,52 @@
+"""Same-box A/B of encoder-attention schedule variants: several builds of libvidi_hip (same ABI) loaded side by side with ctypes and
+timed alternately on the SigLIP shape (N = 729, d = 72, 16 heads).  usage: python tools/ab_attn.py lib_a.so lib_b.so ... [--frames 360]"""
+import ctypes
+import json
+import sys
+
+import torch
+
+
+def main():
+    libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+    B = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 360
+    N, H, D = 729, 16, 72
+    Npad = (N + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qk = (torch.randn((B * N, 2 * H * D), generator=g, device="cuda")).to(torch.bfloat16)
+    vt = (torch.randn((B, H, D, Npad), generator=g, device="cuda")).to(torch.bfloat16)
+    outs, fns = {}, {}
+    for path in libs:
+        lib = ctypes.CDLL(path)
+        f = lib.vidi_attn_self
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 8 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+        o = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
+
+        def run(f=f, o=o):
+            rc = f(qk.data_ptr(), vt.data_ptr(), o.data_ptr(), B, N, Npad, H, D, 2 * H * D, H * D, H * D, D ** -0.5, 0,
+                   torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        run(); torch.cuda.synchronize()
+        outs[path], fns[path] = o, run
+    base = outs[libs[0]]
+    for path in libs[1:]:
+        print(json.dumps({"lib": path, "bit_identical_to_first": bool(torch.equal(outs[path], base)),
+                          "max_abs_diff": float((outs[path].float() - base.float()).abs().max())}), flush=True)
+    tot = {p: 0.0 for p in libs}
+    rounds = 4
+    for r in range(rounds):
+        for path in libs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fns[path]()
+            e1.record(); torch.cuda.synchronize()
+            tot[path] += e0.elapsed_time(e1) / 5
+    for path in libs:
+        ms = tot[path] / rounds
+        print(json.dumps({"lib": path, "frames": B, "ms": ms, "useful_tflops": 4.0 * N * N * D * H * B / ms / 1e9}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,9 @@ prof)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
+attn)
+  # encoder-attention schedule variants (tools/build_variant.sh ... in the container), same-box A/B
+  timeout 600 python tools/ab_attn.py vidi_amd/libvidi_hip.so $(ls vidi_amd/libvidi_hip_attn*.so) > $OUT/ab_attn.jsonl 2> $OUT/ab_attn.err; echo "attn rc=$?"; cat $OUT/ab_attn.jsonl ;;
 variants)
   # regression sweep of the other bench configurations on the current build (BASELINE configs[1], [4]-shape, Vidi-7B, fp16, graph decode)
   for v in "--frames 300" "--queries 8" "--preset vidi_7b" "--dtype fp16" "--decode-graph"; do

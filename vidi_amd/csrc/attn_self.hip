@@ -25,6 +25,15 @@
 #include <stdlib.h>
 
 
+// lab-only schedule variants (tools/ab_attn.py builds them into separate libraries; the product build defines none of them)
+#ifdef VIDI_ATTN_PRIO
+#define VIDI_ATTN_PRIO_HI asm volatile("s_setprio 1" ::: "memory")
+#define VIDI_ATTN_PRIO_LO asm volatile("s_setprio 0" ::: "memory")
+#else
+#define VIDI_ATTN_PRIO_HI
+#define VIDI_ATTN_PRIO_LO
+#endif
+
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
     constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
@@ -157,6 +166,21 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
         // ---- S^T = K Q^T (swapped: lane = query column) for both 32-key sub-tiles; the two accumulator
         //      chains are interleaved so no MFMA waits for the previous one's result
         f32x16 s2[2];
+        VIDI_ATTN_PRIO_HI;
+#ifdef VIDI_ATTN_KPRE
+        {   // lab variant: all K fragments of the tile requested before the first MFMA (one LDS wait instead of one per pair)
+            u32x4 kfa[KS][2];
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) kfa[s][u] = *(const u32x4*)(sK + (u * 32 + l31) * (NCH * 16) + (((2 * s + hi) ^ ksw) << 4));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) s2[u] = T::mfma32(kfa[s][u], qf[s], s == 0 ? zero16 : s2[u]);
+        }
+#else
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -164,6 +188,8 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
                 const u32x4 kf = *(const u32x4*)(sK + (u * 32 + l31) * (NCH * 16) + (((2 * s + hi) ^ ksw) << 4));
                 s2[u] = T::mfma32(kf, qf[s], s == 0 ? zero16 : s2[u]);
             }
+#endif
+        VIDI_ATTN_PRIO_LO;
         // ---- per sub-tile: online softmax (VALU) then O^T += Vt P^T (MFMA); the softmax of sub-tile 1
         //      runs under the PV MFMAs of sub-tile 0 and under the other waves of this SIMD
 #pragma unroll
@@ -209,11 +235,13 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
             }
             const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
             if constexpr (!kOnesRow) l_run += ps0 + ps1;
+            VIDI_ATTN_PRIO_HI;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 o[dt] = T::mfma32(vf[dt][0], pf0, o[dt]);
                 o[dt] = T::mfma32(vf[dt][1], pf1, o[dt]);
             }
+            VIDI_ATTN_PRIO_LO;
         }
     }
 
