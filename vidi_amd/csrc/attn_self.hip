@@ -25,14 +25,18 @@
 #include <stdlib.h>
 
 
-// lab-only schedule variants (tools/ab_attn.py builds them into separate libraries; the product build defines none of them)
-#ifdef VIDI_ATTN_PRIO
-#define VIDI_ATTN_PRIO_HI asm volatile("s_setprio 1" ::: "memory")
-#define VIDI_ATTN_PRIO_LO asm volatile("s_setprio 0" ::: "memory")
-#else
-#define VIDI_ATTN_PRIO_HI
-#define VIDI_ATTN_PRIO_LO
+// schedule knobs (tools/build_variant.sh + tools/ab_attn.py build and time alternatives as separate libraries of the same ABI; the
+// DIAG variants are timing diagnostics with wrong results and exist only in such lab builds)
+#ifndef VIDI_ATTN_PRIO
+#define VIDI_ATTN_PRIO 1               // bit 0: raise the wave's priority over its QK^T MFMAs, bit 1: over its PV MFMAs.  Same-box A/B
+#endif                                 // (tools/ab_attn.py, N = 729, d = 72): 0 -> 640, 1 -> 658, 2 -> 649, 3 -> 652 useful TFLOP/s, all bit-identical
+#ifndef VIDI_ATTN_PRIO_LEVEL
+#define VIDI_ATTN_PRIO_LEVEL 1
 #endif
+#define VIDI_STR2(x) #x
+#define VIDI_STR(x) VIDI_STR2(x)
+#define VIDI_ATTN_PRIO_HI(bit) do { if (VIDI_ATTN_PRIO & (bit)) asm volatile("s_setprio " VIDI_STR(VIDI_ATTN_PRIO_LEVEL) ::: "memory"); } while (0)
+#define VIDI_ATTN_PRIO_LO(bit) do { if (VIDI_ATTN_PRIO & (bit)) asm volatile("s_setprio 0" ::: "memory"); } while (0)
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
@@ -48,7 +52,10 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
     constexpr int KBYTES = 64 * NCH * 16, VBYTES = DT * 32 * 128, BUF = KBYTES + VBYTES;
     constexpr int KRND = (64 * NCH + 255) / 256, VRND = (D * 8 + 255) / 256;
     constexpr int ORW = (NCH % 2 == 0) ? (NCH + 1) * 16 : (NCH + 2) * 16;      // output staging row: odd number of 16-B chunks
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW];   // 2-deep K/V ring
+#ifndef VIDI_ATTN_LDS_PAD
+#define VIDI_ATTN_LDS_PAD 0            // lab knob: extra LDS per block (fewer co-resident blocks per CU)
+#endif
+    __shared__ __attribute__((aligned(16))) char smem[(2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW) + VIDI_ATTN_LDS_PAD];   // 2-deep K/V ring
     auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,9 +163,13 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
 
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
+#ifdef VIDI_ATTN_DIAG_NOBAR                               // timing diagnostic only (wrong results): no rendezvous, no refill
+        if (t == 0) { wait_vmcnt<0>(); __syncthreads(); }
+#else
         wait_vmcnt<0>();                                  // my pieces of tile t have landed ...
         __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
         if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
+#endif
         const char* sK = smem + (t & 1) * BUF;
         const char* sV = sK + KBYTES;
         const bool tail = (kb + 64 > p.N);
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
         // ---- S^T = K Q^T (swapped: lane = query column) for both 32-key sub-tiles; the two accumulator
         //      chains are interleaved so no MFMA waits for the previous one's result
         f32x16 s2[2];
-        VIDI_ATTN_PRIO_HI;
+        VIDI_ATTN_PRIO_HI(1);
 #ifdef VIDI_ATTN_KPRE
         {   // lab variant: all K fragments of the tile requested before the first MFMA (one LDS wait instead of one per pair)
             u32x4 kfa[KS][2];
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
                 s2[u] = T::mfma32(kf, qf[s], s == 0 ? zero16 : s2[u]);
             }
 #endif
-        VIDI_ATTN_PRIO_LO;
+        VIDI_ATTN_PRIO_LO(1);
         // ---- per sub-tile: online softmax (VALU) then O^T += Vt P^T (MFMA); the softmax of sub-tile 1
         //      runs under the PV MFMAs of sub-tile 0 and under the other waves of this SIMD
 #pragma unroll
@@ -229,19 +240,24 @@ __global__ __launch_bounds__(256) void attn_self_kernel(AttnSelfParams p) {
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+#ifdef VIDI_ATTN_DIAG_NOEXP                               // timing diagnostic only (wrong results): the exponentials dropped
+                pv[r] = __builtin_fmaf(s2[u][r], sc, -m_run);
+                pv[r + 1] = __builtin_fmaf(s2[u][r + 1], sc, -m_run);
+#else
                 pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run));
                 pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run));
+#endif
                 if constexpr (!kOnesRow) { ps0 += pv[r]; ps1 += pv[r + 1]; }
             }
             const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
             if constexpr (!kOnesRow) l_run += ps0 + ps1;
-            VIDI_ATTN_PRIO_HI;
+            VIDI_ATTN_PRIO_HI(2);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 o[dt] = T::mfma32(vf[dt][0], pf0, o[dt]);
                 o[dt] = T::mfma32(vf[dt][1], pf1, o[dt]);
             }
-            VIDI_ATTN_PRIO_LO;
+            VIDI_ATTN_PRIO_LO(2);
         }
     }
 
