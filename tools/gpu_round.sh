@@ -22,6 +22,11 @@ prof)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
+mfma)
+  CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc"
+  (cd /tmp && timeout 1200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- $CMD > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err); echo "mfma rc=$?"
+  python tools/mfma_busy_from_pmc.py "$(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1)" $OUT/mfma_busy.json
+  rm -rf $OUT/pmc_mfma ;;
 attn)
   # encoder-attention schedule variants (tools/build_variant.sh ... in the container), same-box A/B
   timeout 600 python tools/ab_attn.py vidi_amd/libvidi_hip.so $(ls vidi_amd/libvidi_hip_attn*.so) > $OUT/ab_attn.jsonl 2> $OUT/ab_attn.err; echo "attn rc=$?"; cat $OUT/ab_attn.jsonl ;;
