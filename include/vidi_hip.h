@@ -127,6 +127,12 @@ int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, i
 int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Npad, int H, int D,
                    int ldqk, int koff, int ldo, float scale, int dtype, void* stream);
 
+/* The same attention reading Q, K AND V row-major from ONE projection output QKV:[B*N, ld] (Q at column h*D, K at koff + h*D, V at
+ * voff + h*D): V is transposed on the fly by the LDS transpose read (ds_read_b64_tr_b16), so the q/k/v projection is a plain GEMM
+ * (vidi_gemm / vidi_gemm_ln) with no scattered V^T stores.  Same results as vidi_attn_self up to the summation order inside the MFMA. */
+int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, int koff, int voff, int ldo, float scale,
+                      int dtype, void* stream);
+
 /* Text->video / text->audio cross-attention, split-KV partial pass (flash_attn_func /
  * flash_attn_varlen_func: lmm/dattn/xattn.py:123,253 via gemma.py:81-91).  Rows r = token*G + g
  * for each kv head; keys [key_start, key_start+n_keys) of the tiled caches; mask: optional

@@ -371,6 +371,30 @@ def test_attn_self(hip, dt, D, N, H, B):
     report(f"attn_self D{D} N{N}", out, ref, *tol(dt, 0.05, k=2))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("D,N,H,B", [(72, 729, 3, 2), (72, 729, 16, 9), (64, 1500, 2, 1), (64, 1500, 20, 3), (16, 49, 4, 3), (16, 50, 4, 2), (32, 130, 2, 2), (72, 64, 2, 8), (64, 1, 2, 2)])
+def test_attn_self_rm(hip, dt, D, N, H, B):
+    """row-major-V variant (V transposed on the fly by ds_read_b64_tr_b16): same shapes as test_attn_self plus full head counts (the
+    XCD-aware block order), a one-tile and a one-key case; Q, K, V are column ranges of ONE [B*N, 3*H*D + pad] buffer with a row stride
+    that is not the packed width; checked against the oracle and against the Vt kernel (same math, same rounding points)."""
+    Hd = H * D
+    Npad = (N + 63) // 64 * 64
+    q = seeded((B, N, H, D), 30, dtype=dt); k = seeded((B, N, H, D), 31, dtype=dt); v = seeded((B, N, H, D), 32, 1.0, dtype=dt) + 0.25
+    scale = D ** -0.5
+    ref = O.sdpa_reference(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2), scale)
+    ref = ref.transpose(1, 2).reshape(B * N, Hd)
+    ld = 3 * Hd + 8
+    qkv = torch.full((B * N, ld), float("nan"), dtype=dt)
+    qkv[:, :Hd] = q.reshape(B * N, Hd); qkv[:, Hd: 2 * Hd] = k.reshape(B * N, Hd); qkv[:, 2 * Hd: 3 * Hd] = v.reshape(B * N, Hd)
+    qkv[:, 3 * Hd:] = 0
+    out = torch.zeros((B * N, Hd), dtype=dt).cuda()
+    hip.attn_self_rm(dev(qkv), out, B=B, N=N, H=H, D=D, koff=Hd, voff=2 * Hd, scale=scale)
+    report(f"attn_self_rm D{D} N{N}", out, ref, *tol(dt, 0.05, k=2))
+    out2 = torch.zeros((B * N, Hd), dtype=dt).cuda()
+    hip.attn_self(dev(qkv[:, : 2 * Hd].contiguous()), dev(pack_vt(v, Npad)), out2, B=B, N=N, Npad=Npad, H=H, D=D, koff=Hd, scale=scale)
+    report(f"attn_self_rm vs Vt kernel D{D} N{N}", out, out2.float().cpu(), *tol(dt, 0.05, k=0.5))
+
+
 def _cross_ref(q, k, v, mask, scale, softcap, G):
     """q:[Lq,nq,hd], k,v:[N,nkv,hd], mask:[N] bool -> [Lq,nq*hd] (fp32)"""
     qh = q.float().permute(1, 0, 2)[None]

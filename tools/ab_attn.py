@@ -29,8 +29,27 @@ def main():
             assert rc == 0, rc
         run(); torch.cuda.synchronize()
         outs[path], fns[path] = o, run
+    # the row-major-V kernel of every library that has it (vidi_attn_self_rm), on the same Q/K/V
+    qkv = torch.cat([qk, vt.new_zeros((B * N, H * D))], dim=1)
+    Vrm = torch.randn((B, N, H, D), generator=g, device="cuda").to(torch.bfloat16)
+    qkv[:, 2 * H * D:] = Vrm.reshape(B * N, H * D)
+    for path in list(libs):
+        lib = ctypes.CDLL(path)
+        if not hasattr(lib, "vidi_attn_self_rm"):
+            continue
+        f = lib.vidi_attn_self_rm
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 8 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+        o = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
+
+        def run_rm(f=f, o=o):
+            rc = f(qkv.data_ptr(), o.data_ptr(), B, N, H, D, 3 * H * D, H * D, 2 * H * D, H * D, D ** -0.5, 0, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        run_rm(); torch.cuda.synchronize()
+        name = path + ":rm"
+        libs.append(name); outs[name], fns[name] = outs[path], run_rm
     base = outs[libs[0]]
-    for path in libs[1:]:
+    for path in [x for x in libs[1:] if not x.endswith(":rm")]:
         print(json.dumps({"lib": path, "bit_identical_to_first": bool(torch.equal(outs[path], base)),
                           "max_abs_diff": float((outs[path].float() - base.float()).abs().max())}), flush=True)
     tot = {p: 0.0 for p in libs}

@@ -1,0 +1,276 @@
+// Non-causal multi-head self-attention for the encoder towers, ROW-MAJOR V variant (round 2).
+//
+// Same algorithm, tiling and numerics as attn_self.hip (read its header first); the difference is where V comes from:
+//   QKV [B*N, ld]  row-major, Q of head h at column h*D, K at koff + h*D, V at voff + h*D — the plain output of ONE projection GEMM.
+// attn_self.hip wants V transposed and key-permuted (Vt[b][h][d][Npad]), which made the QKV GEMM's epilogue scatter 2-byte stores for a
+// third of its columns (-14 % on that GEMM).  Here the V tile is DMA'd into LDS exactly like the K tile ([64 keys][D], 16-byte pieces)
+// and the PV MFMA's A fragments (lane = d row, 8 keys per lane) are read with gfx950's LDS transpose read, `ds_read_b64_tr_b16`: every
+// 16-lane group reads a [4 keys][16 d] block — lane i supplies the address of key (i >> 2), d-columns 4 (i & 3) .. +3 — and each lane
+// receives its d-column for the 4 keys (semantics pinned by tools/micro/tr_read_probe.hip).  The key order the swapped QK^T leaves in the
+// P registers (keys 4 hi + {0..3} and 8 + 4 hi + {0..3} per 16-slab, krow32) is produced by the ADDRESSES of the two reads of a
+// fragment, so memory holds V in natural order.  The softmax denominator's ones row (d = D when D % 32 != 0) is patched into the
+// fragment registers of the lanes that own output row D.
+//
+// Algorithmic FLOPs = 4*N*N*D per (batch, head).
+#include "kernels.h"
+#include <stdlib.h>
+
+#ifndef VIDI_ATTN_PRIO
+#define VIDI_ATTN_PRIO 1               // see attn_self.hip
+#endif
+#define VIDI_ATTN_RM_PRIO_HI(bit) do { if (VIDI_ATTN_PRIO & (bit)) asm volatile("s_setprio 1" ::: "memory"); } while (0)
+#define VIDI_ATTN_RM_PRIO_LO(bit) do { if (VIDI_ATTN_PRIO & (bit)) asm volatile("s_setprio 0" ::: "memory"); } while (0)
+
+
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
+    constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
+    constexpr int NCH = D / 8;                 // 16-byte chunks per head row
+    constexpr int DT = (D + 31) / 32;          // 32-wide output d tiles
+    constexpr int ROWB = NCH * 16;             // bytes per key row of a tile
+    // Both operand tiles are [64 keys][NCH chunks], written by 16-byte LDS-DMA (lane-linear, rows unpadded); bank conflicts are avoided
+    // by permuting which global chunk each lane fetches: chunk c of row r sits at slot c ^ swz(r).
+    //   K tile: read as ds_read_b128 fragments (lane = key row)              -> kswz, as in attn_self.hip
+    //   V tile: read as [4 keys][16 d] transpose-read blocks (lane = d col)  -> vswz: D = 64 (128-byte rows: rows r and r + 2 share
+    //           banks) XORs the chunk with 2 (r & 3); 144-, 64- and 32-byte rows need none
+    constexpr int TBYTES = 64 * NCH * 16, BUF = 2 * TBYTES;
+    constexpr int KRND = (64 * NCH + 255) / 256;
+    constexpr int ORW = (NCH % 2 == 0) ? (NCH + 1) * 16 : (NCH + 2) * 16;      // output staging row: odd number of 16-B chunks
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW];   // 2-deep K/V ring
+    auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
+    auto vswz = [](int r) { return NCH == 8 ? 2 * (r & 3) : 0; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nqt = (p.N + 127) / 128, per_b = nqt * p.H;
+    int qt, h, b;
+    {
+        const int L = blockIdx.x;
+        const int nfull = (p.B / 8) * 8;                     // frames that can be dealt round-robin over the 8 XCDs
+        if ((D * 2) % 128 == 0 && L < nfull * per_b) {
+            const int xcd = L & 7, j = L >> 3;
+            b = 8 * (j / per_b) + xcd;
+            const int w = j % per_b;
+            h = w / nqt; qt = w % nqt;
+        } else if ((D * 2) % 128 == 0) {                      // remainder frames: plain order
+            const int w = L - nfull * per_b;
+            b = nfull + w / per_b;
+            h = (w % per_b) / nqt; qt = (w % per_b) % nqt;
+        } else if ((p.B * p.H) % 8 == 0) {
+            // D=72: the q-tiles of one (frame, head) run on ONE XCD (they share its K/V through that L2), while neighbouring heads -
+            // whose 144-byte output segments share 128-byte lines - go to different XCDs (see attn_self.hip)
+            const int xcd = L & 7, j = L >> 3;
+            const int unit = (j / nqt) * 8 + xcd;
+            qt = j % nqt; b = unit / p.H; h = unit % p.H;
+        } else {                                              // q-tile fastest, then head, then frame
+            qt = L % nqt; h = (L / nqt) % p.H; b = L / per_b;
+        }
+    }
+    const int q = qt * 128 + wave * 32 + l31;
+    const int qc = min(q, p.N - 1);
+
+    // Q fragments (B operand: column = query, contraction chunk = 2s + hi); chunks past D are zero
+    u32x4 qf[KS];
+    {
+        const u16* qrow = p.QKV + ((size_t)b * p.N + qc) * p.ld + h * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 2 * s + hi;
+            qf[s] = (c < NCH) ? *(const u32x4*)(qrow + c * 8) : u32x4{0, 0, 0, 0};
+        }
+    }
+
+    const u16* kbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.koff + h * D;
+    const u16* vbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.voff + h * D;
+
+    // per-thread DMA pieces (tile independent): piece j = (key row, K source column, V source column)
+    int krow[KRND], kcol[KRND], vcol[KRND];
+#pragma unroll
+    for (int j = 0; j < KRND; ++j) {
+        const int i = j * 256 + tid;
+        const int row = i / NCH, cs = i % NCH;
+        krow[j] = row; kcol[j] = (cs ^ kswz(row)) * 8; vcol[j] = (cs ^ vswz(row)) * 8;
+    }
+    auto issue_dma = [&](int kb, int bufi) {
+        char* sK = smem + bufi * BUF;
+        char* sV = sK + TBYTES;
+#pragma unroll
+        for (int j = 0; j < KRND; ++j) {
+            const int ib = j * 256 + wave * 64;              // wave-uniform: whole 64-chunk pieces only
+            if (ib < 64 * NCH) {
+                const size_t ro = (size_t)min(kb + krow[j], p.N - 1) * p.ld;      // rows past N re-read the last key (finite; masked / weighted 0)
+                glds16(kbase_ptr + ro + kcol[j], sK + ib * 16);
+                glds16(vbase_ptr + ro + vcol[j], sV + ib * 16);
+            }
+        }
+    };
+
+    // transpose-read addresses of this lane inside a V tile: 16-lane group g reads the [4 keys][16 d] block of d-columns
+    // dt*32 + 16 (g & 1) .. +15; lane i of the group supplies key row 4 hi + (i >> 2) (+ 32 u + {0, 8, 16, 24} at the call), d-columns
+    // 4 (i & 3) .. +3 and receives column (i & 15) of the block for those 4 keys
+    int vaddr[DT];
+    {
+        const int i = lane & 15, g1 = (lane >> 4) & 1, r = 4 * hi + (i >> 2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = dt * 4 + 2 * g1 + ((i & 3) >> 1);                   // 16-byte chunk holding the lane's 4 columns
+            vaddr[dt] = r * ROWB + ((c ^ vswz(r)) << 4) + (i & 1) * 8;
+        }
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                // m_run in base-2 logit units (score * scale * log2 e)
+    const float sc = p.scale * 1.4426950408889634f;      // fold log2(e): softmax in base 2
+
+    const int ntiles = (p.N + 63) / 64;
+    const int ksw = kswz(l31);
+    // When D is not a multiple of 32 the last d-tile has spare output rows.  Row D accumulates the softmax denominator: the lanes that
+    // own it (l31 == D - 32 (DT - 1)) feed the PV MFMA a fragment of ones instead of V data, so the sum of the T-rounded P comes out of
+    // the matrix pipe for free.  (The other spare rows multiply whatever the read returns — other keys' finite V values — into output
+    // rows that are never stored.)
+    constexpr bool kOnesRow = (DT * 32 > D);
+    constexpr int ROWD = D - (DT - 1) * 32;
+    const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
+    const bool ones_lane = kOnesRow && (l31 == ROWD);
+    issue_dma(0, 0);
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kb = t * 64;
+        wait_vmcnt<0>();                                  // my pieces of tile t have landed ...
+        __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
+        if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
+        const char* sK = smem + (t & 1) * BUF;
+        const __attribute__((address_space(3))) char* sV = (const __attribute__((address_space(3))) char*)(smem + (t & 1) * BUF + TBYTES);
+        const bool tail = (kb + 64 > p.N);
+
+        f32x16 s2[2];
+        VIDI_ATTN_RM_PRIO_HI(1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32x4 kf = *(const u32x4*)(sK + (u * 32 + l31) * ROWB + (((2 * s + hi) ^ ksw) << 4));
+                s2[u] = T::mfma32(kf, qf[s], s == 0 ? zero16 : s2[u]);
+            }
+        VIDI_ATTN_RM_PRIO_LO(1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // A fragments of the PV MFMAs: contraction slots 8 hi + {0..3 | 4..7} of MFMA 0 hold keys 4 hi + {0..3} and 8 + 4 hi + {0..3}
+            // of the sub-tile (where the swapped QK^T left them in pv[0..7]); MFMA 1 the same 16 keys further
+            u32x4 vf[DT][2];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m) * ROWB));
+                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m + 8) * ROWB));
+                    const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
+                    vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                }
+            if constexpr (kOnesRow) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vf[DT - 1][m][e] = ones_lane ? one2 : vf[DT - 1][m][e];
+            }
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + u * 32 + krow32(r, hi) >= p.N) s2[u][r] = -INFINITY;
+            }
+            // online softmax on raw scores (scale folded into the exponent), lazy rescaling — see attn_self.hip
+            float mx = s2[u][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s2[u][r]);
+            mx = xhalf_max(mx);
+            constexpr float TAU = 8.0f;
+            const float m_cand = fmaxf(m_run, mx * sc);
+            if (__any(m_cand > m_run + TAU)) {                 // also the very first sub-tile (m_run = -inf)
+                const float alpha = fast_exp2(m_run - m_cand); // 0 on the first sub-tile (o = l = 0 there)
+                m_run = m_cand;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run));
+                pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run));
+                if constexpr (!kOnesRow) { ps0 += pv[r]; ps1 += pv[r + 1]; }
+            }
+            const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
+            if constexpr (!kOnesRow) l_run += ps0 + ps1;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[dt] = T::mfma32(vf[dt][0], pf0, o[dt]);
+                o[dt] = T::mfma32(vf[dt][1], pf1, o[dt]);
+            }
+        }
+    }
+
+    float l_tot;
+    if constexpr (kOnesRow) {
+        // output row D of the last d-tile: register (D%32 -> j = row/8, e = row%4) of the lanes with hi == (row/4)%2
+        constexpr int REG = 4 * (ROWD / 8) + (ROWD % 4), HI = (ROWD / 4) % 2;
+        const float mine = (hi == HI) ? o[DT - 1][REG] : 0.f;
+        l_tot = xhalf_sum(mine);
+    } else {
+        l_tot = xhalf_sum(l_run);
+    }
+    const float inv = 1.0f / l_tot;
+    // ---- epilogue: O^T registers -> LDS [128 q][D] -> row-contiguous 16-byte global stores (as attn_self.hip)
+    __syncthreads();
+    {
+        char* so = smem + (wave * 32 + l31) * ORW;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = dt * 32 + 8 * j + 4 * hi;
+                if (d < D) {
+                    const u32x2 ov = {pack2<T>(o[dt][4 * j] * inv, o[dt][4 * j + 1] * inv),
+                                      pack2<T>(o[dt][4 * j + 2] * inv, o[dt][4 * j + 3] * inv)};
+                    *(u32x2*)(so + d * 2) = ov;
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < 128 * NCH; i += 256) {
+        const int row = i / NCH, c = i % NCH;
+        const int qq = qt * 128 + row;
+        if (qq < p.N)
+            *(u32x4*)(p.O + ((size_t)b * p.N + qq) * p.ldo + h * D + c * 8) = *(const u32x4*)(smem + row * ORW + c * 16);
+    }
+}
+
+int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st) {
+    if (p.B <= 0 || p.N <= 0 || p.H <= 0) return VIDI_ERR_SHAPE;
+    if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8)) return VIDI_ERR_ALIGN;
+    if (((uintptr_t)p.QKV & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
+    const dim3 grid(((p.N + 127) / 128) * p.H * p.B);
+#define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD>), grid, dim3(256), 0, st, p)
+    if (dtype == VIDI_DT_BF16) {
+        if (D == 72) LAUNCH(BF16, 72); else if (D == 64) LAUNCH(BF16, 64); else if (D == 16) LAUNCH(BF16, 16);
+        else if (D == 32) LAUNCH(BF16, 32); else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (D == 72) LAUNCH(F16, 72); else if (D == 64) LAUNCH(F16, 64); else if (D == 16) LAUNCH(F16, 16);
+        else if (D == 32) LAUNCH(F16, 32); else return VIDI_ERR_SHAPE;
+    } else {
+        return VIDI_ERR_DTYPE;
+    }
+#undef LAUNCH
+    return (int)hipGetLastError();
+}

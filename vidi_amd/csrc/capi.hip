@@ -178,6 +178,15 @@ int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Np
     return vidi_attn_self_dispatch(p, D, dtype, (hipStream_t)stream);
 }
 
+int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, int koff, int voff, int ldo, float scale,
+                      int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!QKV || !O) return VIDI_ERR_ARG;
+    AttnSelfRmParams p;
+    p.QKV = (const u16*)QKV; p.O = (u16*)O; p.B = B; p.N = N; p.H = H; p.ld = ld; p.koff = koff; p.voff = voff; p.ldo = ldo; p.scale = scale;
+    return vidi_attn_self_rm_dispatch(p, D, dtype, (hipStream_t)stream);
+}
+
 size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD) {
     const size_t W = (size_t)zsplit;           // one partial per block (its 4 waves are merged in LDS)
     return W * nkv * Rpad * (size_t)(HD + 2) * sizeof(float);

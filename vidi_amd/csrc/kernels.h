@@ -50,6 +50,13 @@ struct AttnSelfParams {
     float scale;
 };
 
+struct AttnSelfRmParams {         // row-major V variant: Q | K | V of one projection in one buffer
+    const u16* QKV; u16* O;
+    int B, N, H;
+    int ld, koff, voff, ldo;
+    float scale;
+};
+
 struct AttnCrossParams {
     const u16* Q;            // [tokens_q, ldq]; head (kvh*G+g) at column (kvh*G+g)*HD
     const u16* Kc; const u16* Vtc; const unsigned char* mask;   // mask: [n_keys] (1 = valid) or null
@@ -97,6 +104,7 @@ int vidi_gemv_glu_dispatch(const void* X, const void* W, void* Y, int M, int I, 
 int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int dtype, hipStream_t st);
 int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t st);
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
+int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);
 int vidi_attn_merge_dispatch(const AttnMergeParams& p, int HD, int dtype, hipStream_t st);
 int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b, int HD, int dtype, hipStream_t st);

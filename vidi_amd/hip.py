@@ -41,6 +41,7 @@ SIGNATURES = {
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
     "vidi_attn_self": [_c_vp] * 3 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
+    "vidi_attn_self_rm": [_c_vp] * 2 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
     "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_merge2": [_c_vp] * 3 + [_c_int] * 2 + [_c_vp] * 3 + [_c_int] * 2 + [_c_int] * 7 + [_c_vp],
@@ -121,6 +122,8 @@ def _work(name, a):
         return "gemm", 2.0 * a[5] * (2 * a[6]) * a[7], "flop"
     if name == "vidi_attn_self":
         return "attn_self", 4.0 * a[4] * a[4] * a[7] * a[6] * a[3], "flop"
+    if name == "vidi_attn_self_rm":
+        return "attn_self", 4.0 * a[3] * a[3] * a[5] * a[4] * a[2], "flop"
     if name == "vidi_attn_cross":
         return "attn_cross", float(a[14]) * 2 * a[9] * a[10] * 2, "byte"
     if name == "vidi_norm":
@@ -397,6 +400,14 @@ def attn_self(qk, vt, out, *, B, N, Npad, H, D, koff, scale):
     lib = load_library()
     _check(lib.vidi_attn_self(_p(qk), _p(vt), _p(out), B, N, Npad, H, D, qk.stride(0), koff, out.stride(0), float(scale),
                               _dt(qk), _stream()), "vidi_attn_self")
+
+
+def attn_self_rm(qkv, out, *, B, N, H, D, koff, voff, scale):
+    """encoder self-attention reading Q | K | V row-major from one projection output (V transposed on the fly by the LDS transpose read)"""
+    lib = load_library()
+    _rowmajor(qkv, "qkv")
+    _check(lib.vidi_attn_self_rm(_p(qkv), _p(out), B, N, H, D, qkv.stride(0), koff, voff, out.stride(0), float(scale), _dt(qkv), _stream()),
+           "vidi_attn_self_rm")
 
 
 def attn_cross_workspace(zsplit: int, nkv: int, Rpad: int, HD: int, device) -> tuple:
