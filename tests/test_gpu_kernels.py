@@ -389,10 +389,10 @@ def test_attn_self_rm(hip, dt, D, N, H, B):
     qkv[:, 3 * Hd:] = 0
     out = torch.zeros((B * N, Hd), dtype=dt).cuda()
     hip.attn_self_rm(dev(qkv), out, B=B, N=N, H=H, D=D, koff=Hd, voff=2 * Hd, scale=scale)
-    report(f"attn_self_rm D{D} N{N}", out, ref, *tol(dt, 0.05, k=2))
+    report(f"attn_self_rm D{D} N{N}", out, ref, *tol(dt, ref.std().item(), k=2))
     out2 = torch.zeros((B * N, Hd), dtype=dt).cuda()
     hip.attn_self(dev(qkv[:, : 2 * Hd].contiguous()), dev(pack_vt(v, Npad)), out2, B=B, N=N, Npad=Npad, H=H, D=D, koff=Hd, scale=scale)
-    report(f"attn_self_rm vs Vt kernel D{D} N{N}", out, out2.float().cpu(), *tol(dt, 0.05, k=0.5))
+    report(f"attn_self_rm vs Vt kernel D{D} N{N}", out, out2.float().cpu(), *tol(dt, ref.std().item(), k=1))
 
 
 def _cross_ref(q, k, v, mask, scale, softcap, G):

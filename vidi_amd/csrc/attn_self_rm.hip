@@ -33,14 +33,18 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // Both operand tiles are [64 keys][NCH chunks], written by 16-byte LDS-DMA (lane-linear, rows unpadded); bank conflicts are avoided
     // by permuting which global chunk each lane fetches: chunk c of row r sits at slot c ^ swz(r).
     //   K tile: read as ds_read_b128 fragments (lane = key row)              -> kswz, as in attn_self.hip
-    //   V tile: read as [4 keys][16 d] transpose-read blocks (lane = d col)  -> vswz: D = 64 (128-byte rows: rows r and r + 2 share
-    //           banks) XORs the chunk with 2 (r & 3); 144-, 64- and 32-byte rows need none
-    constexpr int TBYTES = 64 * NCH * 16, BUF = 2 * TBYTES;
-    constexpr int KRND = (64 * NCH + 255) / 256;
+    //   V tile: see NSB / SBS below
+    // V tile image for the transpose reads: NSB column blocks ("subtiles") of [64 keys][16 d] with 32-byte rows, so a 16-lane group's
+    // [4 keys][16 d] block is 128 contiguous bytes (the conflict-free form of cdna_hip_programming.md T10; a [64][D] image with 144-byte
+    // rows measured 37 % of the LDS cycles lost to bank conflicts).  Subtiles are 2 KB + a 128-byte skew apart so the two groups of a
+    // 32-lane half (neighbouring subtiles, same rows) use different bank halves.
+    constexpr int NSB = (D + 15) / 16, SBS = 2048 + 128;
+    constexpr int KBYTES = 64 * NCH * 16, VBYTES = NSB * SBS, BUF = KBYTES + VBYTES;
+    constexpr int TBYTES = KBYTES;
+    constexpr int KRND = (64 * NCH + 255) / 256, VPC = 2 * NSB, VRND = (VPC + 3) / 4;
     constexpr int ORW = (NCH % 2 == 0) ? (NCH + 1) * 16 : (NCH + 2) * 16;      // output staging row: odd number of 16-B chunks
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW];   // 2-deep K/V ring
     auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
-    auto vswz = [](int r) { return NCH == 8 ? 2 * (r & 3) : 0; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -85,25 +89,37 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     const u16* kbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.koff + h * D;
     const u16* vbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.voff + h * D;
 
-    // per-thread DMA pieces (tile independent): piece j = (key row, K source column, V source column)
-    int krow[KRND], kcol[KRND], vcol[KRND];
+    // per-thread DMA pieces (tile independent).  K: piece j = (key row, source column) as in attn_self.hip.  V: 1 KB piece pc fills keys
+    // 32 (pc & 1) .. +31 of subtile pc >> 1 — lane L fetches chunk 2 (pc >> 1) + (L & 1) of key 32 (pc & 1) + (L >> 1); a chunk past D
+    // (the unused half of the last subtile when D % 16 != 0) re-fetches the row's last chunk (output rows >= D are never stored)
+    int krow[KRND], kcol[KRND];
 #pragma unroll
     for (int j = 0; j < KRND; ++j) {
         const int i = j * 256 + tid;
         const int row = i / NCH, cs = i % NCH;
-        krow[j] = row; kcol[j] = (cs ^ kswz(row)) * 8; vcol[j] = (cs ^ vswz(row)) * 8;
+        krow[j] = row; kcol[j] = (cs ^ kswz(row)) * 8;
+    }
+    int vrow[VRND], vcol[VRND];
+#pragma unroll
+    for (int j = 0; j < VRND; ++j) {
+        const int pc = j * 4 + wave;
+        vrow[j] = 32 * (pc & 1) + (lane >> 1);
+        vcol[j] = min(2 * (pc >> 1) + (lane & 1), NCH - 1) * 8;
     }
     auto issue_dma = [&](int kb, int bufi) {
         char* sK = smem + bufi * BUF;
-        char* sV = sK + TBYTES;
+        char* sV = sK + KBYTES;
 #pragma unroll
         for (int j = 0; j < KRND; ++j) {
             const int ib = j * 256 + wave * 64;              // wave-uniform: whole 64-chunk pieces only
-            if (ib < 64 * NCH) {
-                const size_t ro = (size_t)min(kb + krow[j], p.N - 1) * p.ld;      // rows past N re-read the last key (finite; masked / weighted 0)
-                glds16(kbase_ptr + ro + kcol[j], sK + ib * 16);
-                glds16(vbase_ptr + ro + vcol[j], sV + ib * 16);
-            }
+            if (ib < 64 * NCH)      // rows past N re-read the last key (finite; masked / weighted 0)
+                glds16(kbase_ptr + (size_t)min(kb + krow[j], p.N - 1) * p.ld + kcol[j], sK + ib * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < VRND; ++j) {
+            const int pc = j * 4 + wave;
+            if (pc < VPC)
+                glds16(vbase_ptr + (size_t)min(kb + vrow[j], p.N - 1) * p.ld + vcol[j], sV + (pc >> 1) * SBS + (pc & 1) * 1024);
         }
     };
 
@@ -112,12 +128,9 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // 4 (i & 3) .. +3 and receives column (i & 15) of the block for those 4 keys
     int vaddr[DT];
     {
-        const int i = lane & 15, g1 = (lane >> 4) & 1, r = 4 * hi + (i >> 2);
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int c = dt * 4 + 2 * g1 + ((i & 3) >> 1);                   // 16-byte chunk holding the lane's 4 columns
-            vaddr[dt] = r * ROWB + ((c ^ vswz(r)) << 4) + (i & 1) * 8;
-        }
+        for (int dt = 0; dt < DT; ++dt) vaddr[dt] = (dt * 2 + g1) * SBS + (4 * hi + (i >> 2)) * 32 + (i & 3) * 8;
     }
 
     f32x16 o[DT];
@@ -137,7 +150,11 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // own it (l31 == D - 32 (DT - 1)) feed the PV MFMA a fragment of ones instead of V data, so the sum of the T-rounded P comes out of
     // the matrix pipe for free.  (The other spare rows multiply whatever the read returns — other keys' finite V values — into output
     // rows that are never stored.)
+#ifdef VIDI_ATTN_RM_VALUSUM
+    constexpr bool kOnesRow = false;       // lab variant: denominator by VALU adds instead of the ones row
+#else
     constexpr bool kOnesRow = (DT * 32 > D);
+#endif
     constexpr int ROWD = D - (DT - 1) * 32;
     const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
     const bool ones_lane = kOnesRow && (l31 == ROWD);
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
         if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
         const char* sK = smem + (t & 1) * BUF;
-        const __attribute__((address_space(3))) char* sV = (const __attribute__((address_space(3))) char*)(smem + (t & 1) * BUF + TBYTES);
+        const __attribute__((address_space(3))) char* sV = (const __attribute__((address_space(3))) char*)(smem + (t & 1) * BUF + KBYTES);
         const bool tail = (kb + 64 > p.N);
 
         f32x16 s2[2];
@@ -171,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m) * ROWB));
-                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m + 8) * ROWB));
+                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m) * 32));
+                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m + 8) * 32));
                     const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
                     vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
                 }
