@@ -19,8 +19,9 @@ def main():
     dt = torch.bfloat16
     cfg = dataclasses.replace(C.vidi15_9b(), num_hidden_layers=1, aud_num_layers=1, vocab_size=1024)
     engs = {}
-    for name, flag in (("fold", "1"), ("plain", "0")):
+    for name, flag, rm in (("fold", "1", "1"), ("plain", "1", "0")):          # arms: row-major-V attention path vs the Vt path (both with the LayerNorm fold)
         os.environ["VIDI_LN_FOLD"] = flag
+        os.environ["VIDI_ATTN_RM"] = rm
         engs[name] = VidiEngine(cfg, init_random_weights(cfg, seed=3, dtype=dt, device="cuda"), dtype=dt, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(1)
     S = cfg.vis_image_size

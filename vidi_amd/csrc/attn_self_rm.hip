@@ -118,8 +118,13 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
 #pragma unroll
         for (int j = 0; j < VRND; ++j) {
             const int pc = j * 4 + wave;
+#ifdef VIDI_ATTN_RM_DIAG_VSRC          // timing diagnostic (wrong results): V pieces fetch whole contiguous rows like the K pieces
+            if (pc < VPC)
+                glds16(vbase_ptr + (size_t)min(kb + krow[0] + 7 * (pc % 9), p.N - 1) * p.ld + kcol[0], sV + (pc >> 1) * SBS + (pc & 1) * 1024);
+#else
             if (pc < VPC)
                 glds16(vbase_ptr + (size_t)min(kb + vrow[j], p.N - 1) * p.ld + vcol[j], sV + (pc >> 1) * SBS + (pc & 1) * 1024);
+#endif
         }
     };
 

@@ -107,6 +107,9 @@ class VidiEngine:
         self.glu_act = hip.ACT_SILU if self.mistral else hip.ACT_GELU_TANH
         # towers: LayerNorm folded into the q/k/v and fc1 projections (default) or run as its own row pass (VIDI_LN_FOLD=0: the A/B arm)
         self.ln_fold = os.environ.get("VIDI_LN_FOLD", "1") != "0"
+        # towers: q | k | v as one row-major buffer + the transpose-read attention kernel (VIDI_ATTN_RM=1) or Q|K row-major + V transposed by
+        # the projection's epilogue + the Vt attention kernel (0)
+        self.attn_rm = os.environ.get("VIDI_ATTN_RM", "1") != "0"
         self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -284,7 +287,19 @@ class VidiEngine:
         M = x.shape[0]
         st, part, h, yqk, vt, ao, f1 = ws["st"], ws["part"], ws["h"], ws["yqk"], ws["vt"], ws["ao"], ws["f1"]
         Hd = x.shape[1]
-        if self.ln_fold:
+        if self.ln_fold and self.attn_rm:
+            # q | k | v row-major from one plain projection; the attention kernel transposes V on the fly (LDS transpose read), so the
+            # GEMM has no scattered V^T stores
+            qkv = ws["qkv"]
+            hip.gemm_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], qkv[:M])
+            hip.attn_self_rm(qkv[:M], ao[:M], B=attn_kw["B"], N=attn_kw["N"], H=attn_kw["H"], D=attn_kw["D"], koff=Hd, voff=2 * Hd,
+                             scale=attn_kw["scale"])
+            hip.gemm_res_stats(ao[:M], L["wo"], L["bo"], x, x, part)
+            hip.ln_finalize(part, st, M, Hd, eps)
+            hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=act)
+            hip.gemm_res_stats(f1[:M], L["fc2"], L["b2"], x, x, part)
+            hip.ln_finalize(part, st, M, Hd, eps)
+        elif self.ln_fold:
             hip.gemm_qkv_vt_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], yqk[:M], vt, **qkv_kw)
             hip.attn_self(yqk[:M], vt, ao[:M], **attn_kw)
             hip.gemm_res_stats(ao[:M], L["wo"], L["bo"], x, x, part)
@@ -331,6 +346,7 @@ class VidiEngine:
               "part": self._buf("vis_part", (2 * Mmax * ((Hv + 127) // 128),), dtype=torch.float32) if fold else None,
               "h": None if fold else self._buf("vis_h", (Mmax, Hv)),
               "yqk": self._buf("vis_qk", (Mmax, 2 * Hv)), "vt": self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True),
+              "qkv": self._buf("vis_qkv", (Mmax, 3 * Hv)) if (fold and self.attn_rm) else None,
               "ao": self._buf("vis_ao", (Mmax, Hv)), "f1": self._buf("vis_f1", (Mmax, V["ipad"]))}
         pixel = pixel.to(self.dtype).contiguous()
         for c0 in range(0, T, fc):
@@ -421,6 +437,7 @@ class VidiEngine:
               "part": self._buf("aud_part", (2 * nb * N * ((Da + 127) // 128),), dtype=torch.float32) if fold else None,
               "h": None if fold else self._buf("aud_h", (nb * N, Da)),
               "yqk": self._buf("aud_qk", (nb * N, 2 * Da)), "vt": self._buf("aud_vt", (nb, nh, hd, Npad), zero=True),
+              "qkv": self._buf("aud_qkv", (nb * N, 3 * Da)) if (fold and self.attn_rm) else None,
               "ao": self._buf("aud_ao", (nb * N, Da)), "f1": self._buf("aud_f1", (nb * N, cfg.aud_ffn_dim))}
         mel = mel.to(self.dtype).contiguous()
         for c0 in range(0, C, cb):
