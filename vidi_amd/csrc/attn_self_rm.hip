@@ -33,15 +33,20 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // Both operand tiles are [64 keys][NCH chunks], written by 16-byte LDS-DMA (lane-linear, rows unpadded); bank conflicts are avoided
     // by permuting which global chunk each lane fetches: chunk c of row r sits at slot c ^ swz(r).
     //   K tile: read as ds_read_b128 fragments (lane = key row)              -> kswz, as in attn_self.hip
-    //   V tile: see NSB / SBS below
-    // V tile image for the transpose reads: NSB column blocks ("subtiles") of [64 keys][16 d] with 32-byte rows, so a 16-lane group's
-    // [4 keys][16 d] block is 128 contiguous bytes (the conflict-free form of cdna_hip_programming.md T10; a [64][D] image with 144-byte
-    // rows measured 37 % of the LDS cycles lost to bank conflicts).  Subtiles are 2 KB + a 128-byte skew apart so the two groups of a
-    // 32-lane half (neighbouring subtiles, same rows) use different bank halves.
-    constexpr int NSB = (D + 15) / 16, SBS = 2048 + 128;
-    constexpr int KBYTES = 64 * NCH * 16, VBYTES = NSB * SBS, BUF = KBYTES + VBYTES;
-    constexpr int TBYTES = KBYTES;
-    constexpr int KRND = (64 * NCH + 255) / 256, VPC = 2 * NSB, VRND = (VPC + 3) / 4;
+    //   V tile: see MAINC / TAILC below
+    // V tile image for the transpose reads (a 16-lane group reads a [4 keys][16 d] block, the two groups of a 32-lane half read
+    // neighbouring column blocks of the same 4 keys and must not share banks — a [64][72] image with 144-byte rows lost 37 % of its LDS
+    // cycles to conflicts):
+    //   main block  [64 keys][MAINC d], MAINC = 64 / 32 / 16: whole 128-byte rows when D >= 64, fetched as whole rows (8 keys per 1 KB
+    //               piece = 8 full lines, like the K tile); with 128-byte rows keys r and r + 2 would share banks, so chunk c of key r
+    //               sits at slot c ^ 2 (r & 3) (bank-conflict-free for every (key, column-block) pair of a half: checked with
+    //               SQ_LDS_BANK_CONFLICT)
+    //   tail block  [64 keys][8 d] (D = 72: d 64..71), 16-byte rows, ONE piece; its missing columns (72..79) are supplied from the
+    //               existing ones — they only feed output rows >= D, which are either the ones row (patched below) or never stored
+    constexpr int MAINC = D >= 64 ? 64 : (D >= 32 ? 32 : 16), TAILC = D - MAINC, MCH = MAINC / 8, MROWB = MAINC * 2;
+    static_assert(TAILC == 0 || TAILC == 8, "head dims: 16, 32, 64, 72");
+    constexpr int KBYTES = 64 * NCH * 16, VMAIN = 64 * MROWB, VBYTES = VMAIN + (TAILC ? 1024 : 0), BUF = KBYTES + VBYTES;
+    constexpr int KRND = (64 * NCH + 255) / 256, VRND = (MCH + 3) / 4;
     constexpr int ORW = (NCH % 2 == 0) ? (NCH + 1) * 16 : (NCH + 2) * 16;      // output staging row: odd number of 16-B chunks
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW];   // 2-deep K/V ring
     auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
@@ -89,9 +94,8 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     const u16* kbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.koff + h * D;
     const u16* vbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.voff + h * D;
 
-    // per-thread DMA pieces (tile independent).  K: piece j = (key row, source column) as in attn_self.hip.  V: 1 KB piece pc fills keys
-    // 32 (pc & 1) .. +31 of subtile pc >> 1 — lane L fetches chunk 2 (pc >> 1) + (L & 1) of key 32 (pc & 1) + (L >> 1); a chunk past D
-    // (the unused half of the last subtile when D % 16 != 0) re-fetches the row's last chunk (output rows >= D are never stored)
+    // per-thread DMA pieces (tile independent).  K: piece j = (key row, source column) as in attn_self.hip.  V main block: 1 KB piece pc
+    // holds keys (64 / MCH) pc .. of the main block — lane L fetches the chunk that belongs at slot L % MCH of key row L / MCH.
     int krow[KRND], kcol[KRND];
 #pragma unroll
     for (int j = 0; j < KRND; ++j) {
@@ -99,12 +103,13 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         const int row = i / NCH, cs = i % NCH;
         krow[j] = row; kcol[j] = (cs ^ kswz(row)) * 8;
     }
+    auto vswz = [](int r) { return MAINC == 64 ? 2 * (r & 3) : 0; };
     int vrow[VRND], vcol[VRND];
 #pragma unroll
     for (int j = 0; j < VRND; ++j) {
         const int pc = j * 4 + wave;
-        vrow[j] = 32 * (pc & 1) + (lane >> 1);
-        vcol[j] = min(2 * (pc >> 1) + (lane & 1), NCH - 1) * 8;
+        const int row = pc * (64 / MCH) + lane / MCH;
+        vrow[j] = row; vcol[j] = ((lane % MCH) ^ vswz(row)) * 8;
     }
     auto issue_dma = [&](int kb, int bufi) {
         char* sK = smem + bufi * BUF;
@@ -118,13 +123,10 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
 #pragma unroll
         for (int j = 0; j < VRND; ++j) {
             const int pc = j * 4 + wave;
-#ifdef VIDI_ATTN_RM_DIAG_VSRC          // timing diagnostic (wrong results): V pieces fetch whole contiguous rows like the K pieces
-            if (pc < VPC)
-                glds16(vbase_ptr + (size_t)min(kb + krow[0] + 7 * (pc % 9), p.N - 1) * p.ld + kcol[0], sV + (pc >> 1) * SBS + (pc & 1) * 1024);
-#else
-            if (pc < VPC)
-                glds16(vbase_ptr + (size_t)min(kb + vrow[j], p.N - 1) * p.ld + vcol[j], sV + (pc >> 1) * SBS + (pc & 1) * 1024);
-#endif
+            if (pc < MCH) glds16(vbase_ptr + (size_t)min(kb + vrow[j], p.N - 1) * p.ld + vcol[j], sV + pc * 1024);
+        }
+        if constexpr (TAILC != 0) {
+            if (wave == 3) glds16(vbase_ptr + (size_t)min(kb + lane, p.N - 1) * p.ld + MAINC, sV + VMAIN);      // key = lane, d MAINC .. +7
         }
     };
 
@@ -133,9 +135,18 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // 4 (i & 3) .. +3 and receives column (i & 15) of the block for those 4 keys
     int vaddr[DT];
     {
-        const int i = lane & 15, g1 = (lane >> 4) & 1;
+        const int i = lane & 15, g1 = (lane >> 4) & 1, r = 4 * hi + (i >> 2);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vaddr[dt] = (dt * 2 + g1) * SBS + (4 * hi + (i >> 2)) * 32 + (i & 3) * 8;
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = dt * 32 + 16 * g1 + 4 * (i & 3);                    // first of the 4 d-columns whose address this lane supplies
+            if (d0 < MAINC) {
+                vaddr[dt] = r * MROWB + (((d0 >> 3) ^ vswz(r)) << 4) + (i & 1) * 8;
+            } else if (TAILC != 0 && dt * 32 == MAINC) {                        // tail block (and its non-existent columns: see above)
+                vaddr[dt] = VMAIN + r * 16 + (i & 1) * 8;
+            } else {                                                            // column block past D (D = 16: d 16..31): any valid address
+                vaddr[dt] = r * MROWB + (i & 1) * 8;
+            }
+        }
     }
 
     f32x16 o[DT];
@@ -193,8 +204,8 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m) * 32));
-                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m + 8) * 32));
+                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m) * (dt * 32 < MAINC ? MROWB : 16)));
+                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m + 8) * (dt * 32 < MAINC ? MROWB : 16)));
                     const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
                     vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
                 }
