@@ -48,7 +48,14 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     constexpr int KBYTES = 64 * NCH * 16, VMAIN = 64 * MROWB, VBYTES = VMAIN + (TAILC ? 1024 : 0), BUF = KBYTES + VBYTES;
     constexpr int KRND = (64 * NCH + 255) / 256, VRND = (MCH + 3) / 4;
     constexpr int ORW = (NCH % 2 == 0) ? (NCH + 1) * 16 : (NCH + 2) * 16;      // output staging row: odd number of 16-B chunks
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW];   // 2-deep K/V ring
+    // When D is not a multiple of 32 the last d-tile has spare output rows; row D accumulates the softmax denominator: its lanes must
+    // receive ONES from the transpose reads.  The lanes that supply the addresses of columns D .. D+3 point into a constant region whose
+    // rows read {1, 0, 0, 0}, the suppliers of columns beyond into its zero half (same row stride as the real data of that d-tile, so
+    // the per-read immediate offsets apply to them too): the sum of the T-rounded P comes out of the matrix pipe, no VALU adds, no patch.
+    constexpr bool kOnesRow = (DT * 32 > D);
+    constexpr int CROWB = TAILC ? 16 : MROWB, CBYTES = kOnesRow ? 64 * CROWB : 0;
+    constexpr int RING = 2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW;
+    __shared__ __attribute__((aligned(16))) char smem[RING + CBYTES];   // 2-deep K/V ring (+ the ones / zeros constant rows)
     auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,19 +140,18 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // transpose-read addresses of this lane inside a V tile: 16-lane group g reads the [4 keys][16 d] block of d-columns
     // dt*32 + 16 (g & 1) .. +15; lane i of the group supplies key row 4 hi + (i >> 2) (+ 32 u + {0, 8, 16, 24} at the call), d-columns
     // 4 (i & 3) .. +3 and receives column (i & 15) of the block for those 4 keys
-    int vaddr[DT];
+    int vaddr[DT], vstep[DT];                            // byte offset from the start of smem in ring buffer 0; + vstep in buffer 1
     {
         const int i = lane & 15, g1 = (lane >> 4) & 1, r = 4 * hi + (i >> 2);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = dt * 32 + 16 * g1 + 4 * (i & 3);                    // first of the 4 d-columns whose address this lane supplies
-            if (d0 < MAINC) {
-                vaddr[dt] = r * MROWB + (((d0 >> 3) ^ vswz(r)) << 4) + (i & 1) * 8;
-            } else if (TAILC != 0 && dt * 32 == MAINC) {                        // tail block (and its non-existent columns: see above)
-                vaddr[dt] = VMAIN + r * 16 + (i & 1) * 8;
-            } else {                                                            // column block past D (D = 16: d 16..31): any valid address
-                vaddr[dt] = r * MROWB + (i & 1) * 8;
-            }
+            int off, in_ring = 1;
+            if (d0 < MAINC) off = KBYTES + r * MROWB + (((d0 >> 3) ^ vswz(r)) << 4) + (i & 1) * 8;
+            else if (d0 < D) off = KBYTES + VMAIN + r * 16 + (i & 1) * 8;     // tail block: d MAINC .. D-1, 16-byte rows
+            else { off = RING + r * CROWB + (d0 == D ? 0 : 8); in_ring = 0; }  // columns >= D: the ones row (d0 == D) / zeros
+            vaddr[dt] = off;
+            vstep[dt] = in_ring * BUF;
         }
     }
 
@@ -162,18 +168,11 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
 
     const int ntiles = (p.N + 63) / 64;
     const int ksw = kswz(l31);
-    // When D is not a multiple of 32 the last d-tile has spare output rows.  Row D accumulates the softmax denominator: the lanes that
-    // own it (l31 == D - 32 (DT - 1)) feed the PV MFMA a fragment of ones instead of V data, so the sum of the T-rounded P comes out of
-    // the matrix pipe for free.  (The other spare rows multiply whatever the read returns — other keys' finite V values — into output
-    // rows that are never stored.)
-#ifdef VIDI_ATTN_RM_VALUSUM
-    constexpr bool kOnesRow = false;       // lab variant: denominator by VALU adds instead of the ones row
-#else
-    constexpr bool kOnesRow = (DT * 32 > D);
-#endif
+    if constexpr (kOnesRow) {                            // constant rows: {1, 0, 0, 0 | 0 ...}
+        const unsigned one1 = (unsigned)T::from_f32(1.0f);
+        for (int i = tid; i < CBYTES / 4; i += 256) *(unsigned*)(smem + RING + i * 4) = (i % (CROWB / 4) == 0) ? one1 : 0u;
+    }
     constexpr int ROWD = D - (DT - 1) * 32;
-    const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
-    const bool ones_lane = kOnesRow && (l31 == ROWD);
     issue_dma(0, 0);
 
     for (int t = 0; t < ntiles; ++t) {
@@ -182,7 +181,10 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
         if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
         const char* sK = smem + (t & 1) * BUF;
-        const __attribute__((address_space(3))) char* sV = (const __attribute__((address_space(3))) char*)(smem + (t & 1) * BUF + KBYTES);
+        const __attribute__((address_space(3))) char* lds0 = (const __attribute__((address_space(3))) char*)smem;
+        int va[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + (t & 1) * vstep[dt];
         const bool tail = (kb + 64 > p.N);
 
         f32x16 s2[2];
@@ -204,17 +206,11 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m) * (dt * 32 < MAINC ? MROWB : 16)));
-                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(sV + vaddr[dt] + (u * 32 + 16 * m + 8) * (dt * 32 < MAINC ? MROWB : 16)));
+                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m) * (dt * 32 < MAINC ? MROWB : 16)));
+                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m + 8) * (dt * 32 < MAINC ? MROWB : 16)));
                     const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
                     vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
                 }
-            if constexpr (kOnesRow) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) vf[DT - 1][m][e] = ones_lane ? one2 : vf[DT - 1][m][e];
-            }
             if (tail) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
