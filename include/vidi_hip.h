@@ -93,6 +93,10 @@ int vidi_gemm_res_stats(const void* X, const void* W, const void* bias, void* Y,
 int vidi_ln_finalize(const float* part, float* stats, long long rows, int N, float eps, void* stream);
 int vidi_gemm_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,
                  int M, int N, int K, int ldx, int ldw, int ldy, int act, int tile_cfg, int dtype, void* stream);
+/* vidi_gemm_ln with the HEAD-MAJOR output vidi_attn_self_rm reads: N = 3 * heads * hd columns (q | k | v), M = frames * seq rows ->
+ * Y[which][frame][head][token][d] (contiguous, same size as [M, N]). */
+int vidi_gemm_ln_heads(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,
+                       int M, int N, int K, int ldx, int ldw, int seq, int hd, int tile_cfg, int dtype, void* stream);
 int vidi_gemm_qkv_vt_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Yqk, void* Vt,
                         int M, int N, int K, int ldx, int ldw, int ldy,
                         int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream);
@@ -127,11 +131,15 @@ int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, i
 int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Npad, int H, int D,
                    int ldqk, int koff, int ldo, float scale, int dtype, void* stream);
 
-/* The same attention reading Q, K AND V row-major from ONE projection output QKV:[B*N, ld] (Q at column h*D, K at koff + h*D, V at
- * voff + h*D): V is transposed on the fly by the LDS transpose read (ds_read_b64_tr_b16), so the q/k/v projection is a plain GEMM
- * (vidi_gemm / vidi_gemm_ln) with no scattered V^T stores.  Same results as vidi_attn_self up to the summation order inside the MFMA. */
-int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, int koff, int voff, int ldo, float scale,
-                      int dtype, void* stream);
+/* The same attention reading Q, K AND V from ONE projection output with V in natural order: V is transposed on the fly by the LDS
+ * transpose read (ds_read_b64_tr_b16), so the q/k/v projection needs no scattered V^T stores.  Row r of head h of frame b lies at
+ * base + b*bs + h*hs + r*ld (elements), base = QKV (Q), QKV + koff (K), QKV + voff (V):
+ *   row-major  [B*N, ld]            bs = 0 (-> N*ld), hs = 0 (-> D), koff / voff = column offsets            (vidi_gemm / vidi_gemm_ln output)
+ *   head-major [3][B][H][N][D]      ld = D, bs = H*N*D, hs = N*D, koff = B*H*N*D, voff = 2*B*H*N*D           (vidi_gemm_ln_heads output)
+ * Head-major makes every K / V tile whole 128-byte lines (+12 % on this kernel).  O:[B*N, ldo] row-major, head h at column h*D.
+ * Same results as vidi_attn_self (bit-identical: same MFMA operands in the same slots). */
+int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, long long koff, long long voff, long long bs, long long hs,
+                      int ldo, float scale, int dtype, void* stream);
 
 /* Text->video / text->audio cross-attention, split-KV partial pass (flash_attn_func /
  * flash_attn_varlen_func: lmm/dattn/xattn.py:123,253 via gemma.py:81-91).  Rows r = token*G + g

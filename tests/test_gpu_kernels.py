@@ -393,6 +393,30 @@ def test_attn_self_rm(hip, dt, D, N, H, B):
     out2 = torch.zeros((B * N, Hd), dtype=dt).cuda()
     hip.attn_self(dev(qkv[:, : 2 * Hd].contiguous()), dev(pack_vt(v, Npad)), out2, B=B, N=N, Npad=Npad, H=H, D=D, koff=Hd, scale=scale)
     report(f"attn_self_rm vs Vt kernel D{D} N{N}", out, out2.float().cpu(), *tol(dt, ref.std().item(), k=1))
+    assert torch.equal(out, out2)                                   # same MFMA operands in the same slots: bit-identical
+    # head-major input [3][B][H][N][D] (what vidi_gemm_ln_heads writes): same result bit for bit
+    hm = torch.stack([q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)]).contiguous()
+    out3 = torch.zeros((B * N, Hd), dtype=dt).cuda()
+    hip.attn_self_rm(dev(hm), out3, B=B, N=N, H=H, D=D, scale=scale, head_major=True)
+    assert torch.equal(out3, out)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("seq,frames,heads,hd,K,cfg", [(729, 18, 16, 72, 1152, -1), (49, 3, 4, 16, 192, -1), (49, 3, 4, 16, 192, 0), (1500, 9, 20, 64, 1280, 5)])
+def test_gemm_ln_heads_is_gemm_ln_rearranged(hip, dt, seq, frames, heads, hd, K, cfg):
+    """the head-major q/k/v projection equals the row-major one with its columns / rows regrouped: Y[which][frame][head][token][d]"""
+    M, N = frames * seq, 3 * heads * hd
+    x = (seeded((M, K), 90, 1.0) + seeded((M, 1), 91, 1.0)).to(dt)
+    w = seeded((N, K), 92, 0.05, dtype=dt); b = seeded((N,), 93, 0.3, dtype=dt)
+    gamma = (1.0 + seeded((K,), 94, 0.2)).to(dt); beta = seeded((K,), 95, 0.2, dtype=dt)
+    wf, cs, sh = _fold_ln(w, b, gamma, beta, dt)
+    st = torch.zeros(2 * M, dtype=torch.float32).cuda()
+    hip.row_stats(dev(x), st, 1e-6)
+    y = hip.gemm_ln(dev(x), dev(wf), st, dev(cs), dev(sh), tile_cfg=cfg)
+    yh = torch.full((M * N,), float("nan"), dtype=dt).cuda()
+    hip.gemm_ln_heads(dev(x), dev(wf), st, dev(cs), dev(sh), yh, seq=seq, hd=hd, tile_cfg=cfg)
+    want = y.view(frames, seq, 3, heads, hd).permute(2, 0, 3, 1, 4).contiguous().view(-1)
+    assert torch.equal(yh, want)
 
 
 def _cross_ref(q, k, v, mask, scale, softcap, G):

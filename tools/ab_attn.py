@@ -39,17 +39,27 @@ def main():
             continue
         f = lib.vidi_attn_self_rm
         f.restype = ctypes.c_int
-        f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 8 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+        f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_longlong] * 4 + [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
         o = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
 
         def run_rm(f=f, o=o):
-            rc = f(qkv.data_ptr(), o.data_ptr(), B, N, H, D, 3 * H * D, H * D, 2 * H * D, H * D, D ** -0.5, 0, torch.cuda.current_stream().cuda_stream)
+            rc = f(qkv.data_ptr(), o.data_ptr(), B, N, H, D, 3 * H * D, H * D, 2 * H * D, 0, 0, H * D, D ** -0.5, 0, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
         run_rm(); torch.cuda.synchronize()
         name = path + ":rm"
         libs.append(name); outs[name], fns[name] = outs[path], run_rm
+        # the same kernel on a HEAD-MAJOR input ([3][B][H][N][D]: every head's key rows contiguous)
+        hm = torch.randn((3 * B * H * N * D,), generator=g, device="cuda").to(torch.bfloat16)
+        o2 = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
+
+        def run_hm(f=f, o2=o2, hm=hm):
+            rc = f(hm.data_ptr(), o2.data_ptr(), B, N, H, D, D, B * H * N * D, 2 * B * H * N * D, H * N * D, N * D, H * D, D ** -0.5, 0,
+                   torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        run_hm(); torch.cuda.synchronize()
+        libs.append(path + ":rm_headmajor"); outs[path + ":rm_headmajor"], fns[path + ":rm_headmajor"] = outs[path], run_hm
     base = outs[libs[0]]
-    for path in [x for x in libs[1:] if not x.endswith(":rm")]:
+    for path in [x for x in libs[1:] if ":rm" not in x]:
         print(json.dumps({"lib": path, "bit_identical_to_first": bool(torch.equal(outs[path], base)),
                           "max_abs_diff": float((outs[path].float() - base.float()).abs().max())}), flush=True)
     tot = {p: 0.0 for p in libs}

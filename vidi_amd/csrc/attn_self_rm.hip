@@ -1,7 +1,10 @@
 // Non-causal multi-head self-attention for the encoder towers, ROW-MAJOR V variant (round 2).
 //
 // Same algorithm, tiling and numerics as attn_self.hip (read its header first); the difference is where V comes from:
-//   QKV [B*N, ld]  row-major, Q of head h at column h*D, K at koff + h*D, V at voff + h*D — the plain output of ONE projection GEMM.
+//   QKV: Q, K and V of ONE projection GEMM, V in natural order.  Row r of head h of frame b at  base + b*bs + h*hs + r*ld  with base =
+//   QKV (Q), QKV + koff (K), QKV + voff (V): row-major [B*N, ld] (bs = N*ld, hs = D) or HEAD-MAJOR [3][B][H][N][D] (bs = H*N*D, hs = N*D,
+//   ld = D) — there a head's key rows are contiguous and the K / V tiles are whole 128-byte lines (+12 % on this kernel, same box:
+//   a 144-byte head row inside a 6 912-byte token row costs two line fetches).
 // attn_self.hip wants V transposed and key-permuted (Vt[b][h][d][Npad]), which made the QKV GEMM's epilogue scatter 2-byte stores for a
 // third of its columns (-14 % on that GEMM).  Here the V tile is DMA'd into LDS exactly like the K tile ([64 keys][D], 16-byte pieces)
 // and the PV MFMA's A fragments (lane = d row, 8 keys per lane) are read with gfx950's LDS transpose read, `ds_read_b64_tr_b16`: every
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     // Q fragments (B operand: column = query, contraction chunk = 2s + hi); chunks past D are zero
     u32x4 qf[KS];
     {
-        const u16* qrow = p.QKV + ((size_t)b * p.N + qc) * p.ld + h * D;
+        const u16* qrow = p.QKV + (size_t)b * p.bs + (size_t)h * p.hs + (size_t)qc * p.ld;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c = 2 * s + hi;
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         }
     }
 
-    const u16* kbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.koff + h * D;
-    const u16* vbase_ptr = p.QKV + (size_t)b * p.N * p.ld + p.voff + h * D;
+    const u16* kbase_ptr = p.QKV + p.koff + (size_t)b * p.bs + (size_t)h * p.hs;
+    const u16* vbase_ptr = p.QKV + p.voff + (size_t)b * p.bs + (size_t)h * p.hs;
 
     // per-thread DMA pieces (tile independent).  K: piece j = (key row, source column) as in attn_self.hip.  V main block: 1 KB piece pc
     // holds keys (64 / MCH) pc .. of the main block — lane L fetches the chunk that belongs at slot L % MCH of key row L / MCH.
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
 
 int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st) {
     if (p.B <= 0 || p.N <= 0 || p.H <= 0) return VIDI_ERR_SHAPE;
-    if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8)) return VIDI_ERR_ALIGN;
+    if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8) || (p.bs % 8) || (p.hs % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)p.QKV & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
     const dim3 grid(((p.N + 127) / 128) * p.H * p.B);
 #define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD>), grid, dim3(256), 0, st, p)

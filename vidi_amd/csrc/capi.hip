@@ -120,6 +120,20 @@ int vidi_gemm_ln(const void* X, const void* Wf, const float* stats, const float*
     return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg, dtype, (hipStream_t)stream);
 }
 
+int vidi_gemm_ln_heads(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,
+                       int M, int N, int K, int ldx, int ldw, int seq, int hd, int tile_cfg, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wf || !stats || !colsum || !shift || !Y) return VIDI_ERR_ARG;
+    if (((uintptr_t)colsum & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)stats & 7)) return VIDI_ERR_ALIGN;
+    if (seq <= 0 || hd <= 0 || hd % 8 || M % seq || N % (3 * hd)) return VIDI_ERR_SHAPE;
+    if ((unsigned long long)M * (unsigned)seq >= (1ull << 32)) return VIDI_ERR_SHAPE;            // exactness range of the magic division
+    GemmParams p = base_params(X, Wf, nullptr, Y, nullptr, M, N, K, ldx, ldw, N, 0, 0);
+    p.ln_stats = stats; p.ln_s = colsum; p.ln_c = shift;
+    p.hm_seq = seq; p.hm_hd = hd; p.hm_heads = N / (3 * hd); p.hm_magic = (unsigned)((1ull << 32) / (unsigned)seq) + 1u;
+    if (tile_cfg == 3) return VIDI_ERR_ARG;
+    return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_qkv_vt_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Yqk, void* Vt,
                         int M, int N, int K, int ldx, int ldw, int ldy,
                         int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream) {
@@ -178,12 +192,14 @@ int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Np
     return vidi_attn_self_dispatch(p, D, dtype, (hipStream_t)stream);
 }
 
-int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, int koff, int voff, int ldo, float scale,
-                      int dtype, void* stream) {
+int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, long long koff, long long voff, long long bs, long long hs,
+                      int ldo, float scale, int dtype, void* stream) {
     (void)hipGetLastError();
     if (!QKV || !O) return VIDI_ERR_ARG;
     AttnSelfRmParams p;
     p.QKV = (const u16*)QKV; p.O = (u16*)O; p.B = B; p.N = N; p.H = H; p.ld = ld; p.koff = koff; p.voff = voff; p.ldo = ldo; p.scale = scale;
+    p.bs = bs > 0 ? bs : (long long)N * ld;            // defaults: row-major [B*N, ld]
+    p.hs = hs > 0 ? hs : D;
     return vidi_attn_self_rm_dispatch(p, D, dtype, (hipStream_t)stream);
 }
 

@@ -313,7 +313,7 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         }
         tile_cfg = (t256 >= 192 && !p.ln_stats) ? 4 : 0;
     }
-    if (p.ln_stats && tile_cfg != 0 && tile_cfg != 5) return VIDI_ERR_ARG;       // folded LayerNorm: persistent kernel or the 128x128 tile
+    if ((p.ln_stats || p.hm_seq) && tile_cfg != 0 && tile_cfg != 5) return VIDI_ERR_ARG;       // folded LayerNorm: persistent kernel or the 128x128 tile
     switch (tile_cfg) {
         case 0: return launch_cfg<T, 128, 128, 2, 2, 2, MODE, REPKV, SCHED_RING, 32>(p, batch, st);
         case 1: return launch_cfg<T, 128, 256, 2, 4, 3, MODE, REPKV, SCHED_RING, 32>(p, batch, st);

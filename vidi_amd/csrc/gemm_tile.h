@@ -446,7 +446,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(GemmParams p) {
                     for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
                     v = pack8<T>(x);
                 }
-                *(u32x4*)(Yb + (size_t)m * p.ldy + n) = v;
+                if (p.hm_seq) {                                  // head-major output (GemmParams::hm_*)
+                    const int hdim = p.hm_heads * p.hm_hd, which = n / hdim, nh = n - which * hdim, hh = nh / p.hm_hd;
+                    const int fr = m / p.hm_seq, tok = m - fr * p.hm_seq;
+                    *(u32x4*)(Yb + ((((size_t)which * (p.M / p.hm_seq) + fr) * p.hm_heads + hh) * p.hm_seq + tok) * p.hm_hd + (nh - hh * p.hm_hd)) = v;
+                } else {
+                    *(u32x4*)(Yb + (size_t)m * p.ldy + n) = v;
+                }
             }
         }
     }

@@ -47,8 +47,9 @@ struct W4Geom {
 // LNF: LayerNorm folded into the projection (GemmParams::ln_stats / ln_s / ln_c): y = rstd_m * (acc - mean_m * s_n) + c_n replaces
 // the bias add (c carries the bias)
 // STATS: the stored rows' per-strip partial sums go to GemmParams::stat_part (bias + residual producers of a LayerNorm input)
-template <bool BIAS, int ACT, int RES, bool LNF = false, bool STATS = false>
-struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF, stats = STATS; };
+// HEADS: head-major output Y[which][frame][head][token][d] (GemmParams::hm_*): the q/k/v projection of the encoder towers
+template <bool BIAS, int ACT, int RES, bool LNF = false, bool STATS = false, bool HEADS = false>
+struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF, stats = STATS, heads = HEADS; };
 
 template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
@@ -270,6 +271,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         }
         const int rr = lane / CPRW, cc = lane % CPRW;                // this lane's (row in read group, chunk) of the read-back
         const int n = no0 + cc * 8;                                  // this lane's output column in the read-back
+        // head-major output: this lane's column is (which, head, d) for the whole tile; rows split into (frame, token) per store
+        size_t hm_col = 0;
+        if constexpr (EPI::heads) {
+            const int nc = min(n, p.N - 8), hdim = p.hm_heads * p.hm_hd;
+            const int which = nc / hdim, nh = nc - which * hdim, hh = nh / p.hm_hd;
+            hm_col = ((size_t)which * (p.M / p.hm_seq) * p.hm_heads + hh) * p.hm_seq * p.hm_hd + (nh - hh * p.hm_hd);
+        }
         // ---- registers -> scratch (lane: row l15, 4 consecutive columns per 16-column tile) ----
         auto stage = [&](auto bt) {
             constexpr int b = decltype(bt)::value;
@@ -433,7 +441,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                             v = pack8<T>(x);
                         }
                     }
-                    *(u32x4*)(Yb + (size_t)m * p.ldy + n) = v;
+                    if constexpr (EPI::heads) {
+                        const int fr = (int)__umulhi((unsigned)m, p.hm_magic), tok = m - fr * p.hm_seq;      // m / seq, m % seq
+                        *(u32x4*)(Yb + hm_col + ((size_t)fr * p.hm_heads * p.hm_seq + tok) * p.hm_hd) = v;
+                    } else {
+                        *(u32x4*)(Yb + (size_t)m * p.ldy + n) = v;
+                    }
                 }
             }
         };

@@ -41,6 +41,10 @@ struct GemmParams {
     // partial sums (sum y, sum y^2) of the values it stored — stat_part[m][strip][2], strips = ceil(N / 128) — so the NEXT
     // LayerNorm's statistics need no pass over Y (vidi_ln_finalize turns them into (mean, rstd)).  Null: off.
     float* stat_part;
+    // head-major output (encoder q/k/v projection feeding vidi_attn_self_rm): column n = (which, head, d) of N = 3 * heads * hm_hd, row
+    // m = (frame, token) of M = frames * hm_seq -> Y[which][frame][head][token][d]: every head's key rows contiguous, so the attention's
+    // K / V tiles are whole 128-byte lines.  hm_seq == 0: row-major.  hm_magic = floor(2^32 / hm_seq) + 1 (exact m / hm_seq for M * seq < 2^32).
+    int hm_seq, hm_hd, hm_heads; unsigned hm_magic;
 };
 
 struct AttnSelfParams {
@@ -50,10 +54,12 @@ struct AttnSelfParams {
     float scale;
 };
 
-struct AttnSelfRmParams {         // row-major V variant: Q | K | V of one projection in one buffer
+struct AttnSelfRmParams {         // Q | K | V of one projection in one buffer, V in natural (un-transposed) order
     const u16* QKV; u16* O;
     int B, N, H;
-    int ld, koff, voff, ldo;
+    int ld, ldo;                  // row strides (elements) of the q/k/v rows and of O
+    long long koff, voff;         // element offsets of the K and V parts
+    long long bs, hs;             // frame and head strides (elements): row-major rows N*ld, D; head-major H*N*D, N*D (ld = D)
     float scale;
 };
 

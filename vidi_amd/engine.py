@@ -288,12 +288,12 @@ class VidiEngine:
         st, part, h, yqk, vt, ao, f1 = ws["st"], ws["part"], ws["h"], ws["yqk"], ws["vt"], ws["ao"], ws["f1"]
         Hd = x.shape[1]
         if self.ln_fold and self.attn_rm:
-            # q | k | v row-major from one plain projection; the attention kernel transposes V on the fly (LDS transpose read), so the
+            # q | k | v from ONE plain projection, written head-major ([3][frame][head][token][d]: a head's key rows contiguous -> whole
+            # 128-byte lines for the attention's K / V tiles); the attention kernel transposes V on the fly (LDS transpose read), so the
             # GEMM has no scattered V^T stores
             qkv = ws["qkv"]
-            hip.gemm_ln(x, L["wqkv"], st, L["sqkv"], L["cqkv"], qkv[:M])
-            hip.attn_self_rm(qkv[:M], ao[:M], B=attn_kw["B"], N=attn_kw["N"], H=attn_kw["H"], D=attn_kw["D"], koff=Hd, voff=2 * Hd,
-                             scale=attn_kw["scale"])
+            hip.gemm_ln_heads(x, L["wqkv"], st, L["sqkv"], L["cqkv"], qkv, seq=attn_kw["N"], hd=attn_kw["D"])
+            hip.attn_self_rm(qkv, ao[:M], B=attn_kw["B"], N=attn_kw["N"], H=attn_kw["H"], D=attn_kw["D"], scale=attn_kw["scale"], head_major=True)
             hip.gemm_res_stats(ao[:M], L["wo"], L["bo"], x, x, part)
             hip.ln_finalize(part, st, M, Hd, eps)
             hip.gemm_ln(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], act=act)

@@ -41,7 +41,8 @@ SIGNATURES = {
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
     "vidi_attn_self": [_c_vp] * 3 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
-    "vidi_attn_self_rm": [_c_vp] * 2 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
+    "vidi_attn_self_rm": [_c_vp] * 2 + [_c_int] * 5 + [_c_ll] * 4 + [_c_int, _c_f, _c_int, _c_vp],
+    "vidi_gemm_ln_heads": [_c_vp] * 6 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_merge2": [_c_vp] * 3 + [_c_int] * 2 + [_c_vp] * 3 + [_c_int] * 2 + [_c_int] * 7 + [_c_vp],
@@ -124,6 +125,8 @@ def _work(name, a):
         return "attn_self", 4.0 * a[4] * a[4] * a[7] * a[6] * a[3], "flop"
     if name == "vidi_attn_self_rm":
         return "attn_self", 4.0 * a[3] * a[3] * a[5] * a[4] * a[2], "flop"
+    if name == "vidi_gemm_ln_heads":
+        return "gemm", 2.0 * a[6] * a[7] * a[8], "flop"
     if name == "vidi_attn_cross":
         return "attn_cross", float(a[14]) * 2 * a[9] * a[10] * 2, "byte"
     if name == "vidi_norm":
@@ -153,7 +156,7 @@ def _alg_bytes(name, a):
         return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6])
     if name == "vidi_gemm_qkv_vt_ln":
         return 2.0 * (a[7] * a[9] + a[8] * a[9] + a[7] * a[8])
-    if name == "vidi_gemm_ln":
+    if name == "vidi_gemm_ln" or name == "vidi_gemm_ln_heads":
         return 2.0 * (a[6] * a[8] + a[7] * a[8] + a[6] * a[7])
     if name == "vidi_gemm_res_stats":
         return 2.0 * (a[6] * a[8] + a[7] * a[8] + 2 * a[6] * a[7])
@@ -402,12 +405,33 @@ def attn_self(qk, vt, out, *, B, N, Npad, H, D, koff, scale):
                               _dt(qk), _stream()), "vidi_attn_self")
 
 
-def attn_self_rm(qkv, out, *, B, N, H, D, koff, voff, scale):
-    """encoder self-attention reading Q | K | V row-major from one projection output (V transposed on the fly by the LDS transpose read)"""
+def attn_self_rm(qkv, out, *, B, N, H, D, scale, koff=None, voff=None, head_major=False):
+    """encoder self-attention reading Q | K | V (V in natural order, transposed on the fly by the LDS transpose read) from one projection
+    output: row-major [B*N, ld] with column offsets koff / voff, or head-major [3][B][H][N][D] (gemm_ln_heads)"""
     lib = load_library()
-    _rowmajor(qkv, "qkv")
-    _check(lib.vidi_attn_self_rm(_p(qkv), _p(out), B, N, H, D, qkv.stride(0), koff, voff, out.stride(0), float(scale), _dt(qkv), _stream()),
-           "vidi_attn_self_rm")
+    if head_major:
+        if not qkv.is_contiguous() or qkv.numel() < 3 * B * H * N * D:
+            raise VidiHipError("attn_self_rm: head-major input must be a contiguous [3][B][H][N][D] buffer")
+        per = B * H * N * D
+        args = (D, per, 2 * per, H * N * D, N * D)
+    else:
+        _rowmajor(qkv, "qkv")
+        args = (qkv.stride(0), koff, voff, 0, 0)
+    _check(lib.vidi_attn_self_rm(_p(qkv), _p(out), B, N, H, D, *args, out.stride(0), float(scale), _dt(qkv), _stream()), "vidi_attn_self_rm")
+
+
+def gemm_ln_heads(x, wf, stats, colsum, shift, out, *, seq: int, hd: int, tile_cfg: int = -1):
+    """gemm_ln (no activation) writing the q | k | v projection head-major: out[which][frame][head][token][d]"""
+    lib = load_library()
+    _rowmajor(x, "x"); _rowmajor(wf, "wf")
+    M, K = x.shape
+    N = wf.shape[0]
+    _ln_vecs(stats, colsum, shift, M, N)
+    if not out.is_contiguous() or out.numel() < M * N:
+        raise VidiHipError("gemm_ln_heads: `out` must be a contiguous buffer of M * N elements")
+    _check(lib.vidi_gemm_ln_heads(_p(x), _p(wf), _p(stats), _p(colsum), _p(shift), _p(out), M, N, K, x.stride(0), wf.stride(0), seq, hd,
+                                  tile_cfg, _dt(x), _stream()), "vidi_gemm_ln_heads")
+    return out
 
 
 def attn_cross_workspace(zsplit: int, nkv: int, Rpad: int, HD: int, device) -> tuple:
