@@ -9,8 +9,9 @@ import torch
 
 def main():
     libs = [a for a in sys.argv[1:] if a.endswith(".so")]
-    B = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 360
-    N, H, D = 729, 16, 72
+    def opt(name, default):
+        return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+    B, N, H, D = opt("--frames", 360), opt("--N", 729), opt("--H", 16), opt("--D", 72)
     Npad = (N + 63) // 64 * 64
     g = torch.Generator(device="cuda").manual_seed(0)
     qk = (torch.randn((B * N, 2 * H * D), generator=g, device="cuda")).to(torch.bfloat16)
