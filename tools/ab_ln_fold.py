@@ -1,5 +1,7 @@
-"""Same-box A/B of the SigLIP tower with the LayerNorm folded into the projections (default) vs run as its own pass (VIDI_LN_FOLD=0):
-two engines in one process, timed alternately (ABAB...) so clocks / box differences cancel.  usage: python tools/ab_ln_fold.py [frames] [rounds]"""
+"""Same-box A/B of the SigLIP tower under two engine configurations (environment switches read by VidiEngine at construction:
+VIDI_LN_FOLD, VIDI_ATTN_RM): two engines in one process, timed alternately (ABAB...) so clocks / box differences cancel.
+usage: python tools/ab_ln_fold.py [frames] [rounds] [armA] [armB]     arm = comma-separated NAME=VALUE pairs
+defaults: armA = shipped path (LayerNorm folded, head-major q|k|v + transpose-read attention), armB = VIDI_ATTN_RM=0 (round-1 Vt path)"""
 import dataclasses
 import json
 import os
@@ -19,9 +21,12 @@ def main():
     dt = torch.bfloat16
     cfg = dataclasses.replace(C.vidi15_9b(), num_hidden_layers=1, aud_num_layers=1, vocab_size=1024)
     engs = {}
-    for name, flag, rm in (("fold", "1", "1"), ("plain", "1", "0")):          # arms: row-major-V attention path vs the Vt path (both with the LayerNorm fold)
-        os.environ["VIDI_LN_FOLD"] = flag
-        os.environ["VIDI_ATTN_RM"] = rm
+    arm_a = sys.argv[3] if len(sys.argv) > 3 else "VIDI_LN_FOLD=1,VIDI_ATTN_RM=1"
+    arm_b = sys.argv[4] if len(sys.argv) > 4 else "VIDI_LN_FOLD=1,VIDI_ATTN_RM=0"
+    for name, arm in (("fold", arm_a), ("plain", arm_b)):
+        for kv in arm.split(","):
+            k, v = kv.split("=")
+            os.environ[k] = v
         engs[name] = VidiEngine(cfg, init_random_weights(cfg, seed=3, dtype=dt, device="cuda"), dtype=dt, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(1)
     S = cfg.vis_image_size
