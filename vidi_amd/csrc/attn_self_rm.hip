@@ -27,8 +27,15 @@
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
+#ifndef VIDI_ATTN_RM_QS
+#define VIDI_ATTN_RM_QS 1              // query sets of 32 per wave (lab knob): 2 = a 256-query block, each wave runs two independent
+#endif                                 // softmax / PV chains against every K / V tile (half the rendezvous and tile DMA per query).
+                                       // Measured (tools/ab_attn.py): 228 VGPRs -> 2 waves/SIMD, the compiler runs the two chains back
+                                       // to back, 399 vs 636 useful TFLOP/s — the in-wave overlap needs a hand-built schedule.
+
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
+    constexpr int QS = VIDI_ATTN_RM_QS, QB = 128 * QS;
     constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
     constexpr int NCH = D / 8;                 // 16-byte chunks per head row
     constexpr int DT = (D + 31) / 32;          // 32-wide output d tiles
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nqt = (p.N + 127) / 128, per_b = nqt * p.H;
+    const int nqt = (p.N + QB - 1) / QB, per_b = nqt * p.H;
     int qt, h, b;
     {
         const int L = blockIdx.x;
@@ -87,17 +94,17 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             qt = L % nqt; h = (L / nqt) % p.H; b = L / per_b;
         }
     }
-    const int q = qt * 128 + wave * 32 + l31;
-    const int qc = min(q, p.N - 1);
-
-    // Q fragments (B operand: column = query, contraction chunk = 2s + hi); chunks past D are zero
-    u32x4 qf[KS];
-    {
+    // Q fragments (B operand: column = query, contraction chunk = 2s + hi); chunks past D are zero.  Query set qs of this wave: rows
+    // qt*QB + qs*128 + wave*32 + l31 (each set is a 128-row band of the block, staged and stored as such in the epilogue)
+    u32x4 qf[QS][KS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        const int qc = min(qt * QB + qs * 128 + wave * 32 + l31, p.N - 1);
         const u16* qrow = p.QKV + (size_t)b * p.bs + (size_t)h * p.hs + (size_t)qc * p.ld;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c = 2 * s + hi;
-            qf[s] = (c < NCH) ? *(const u32x4*)(qrow + c * 8) : u32x4{0, 0, 0, 0};
+            qf[qs][s] = (c < NCH) ? *(const u32x4*)(qrow + c * 8) : u32x4{0, 0, 0, 0};
         }
     }
 
@@ -158,15 +165,19 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         }
     }
 
-    f32x16 o[DT];
+    f32x16 o[QS][DT];
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qs][t][i] = 0.f;
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;                // m_run in base-2 logit units (score * scale * log2 e)
+    float m_run[QS], l_run[QS];                          // m_run in base-2 logit units (score * scale * log2 e)
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) { m_run[qs] = -INFINITY; l_run[qs] = 0.f; }
     const float sc = p.scale * 1.4426950408889634f;      // fold log2(e): softmax in base 2
 
     const int ntiles = (p.N + 63) / 64;
@@ -190,6 +201,8 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + (t & 1) * vstep[dt];
         const bool tail = (kb + 64 > p.N);
 
+#pragma unroll
+      for (int qs = 0; qs < QS; ++qs) {
         f32x16 s2[2];
         VIDI_ATTN_RM_PRIO_HI(1);
 #pragma unroll
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32x4 kf = *(const u32x4*)(sK + (u * 32 + l31) * ROWB + (((2 * s + hi) ^ ksw) << 4));
-                s2[u] = T::mfma32(kf, qf[s], s == 0 ? zero16 : s2[u]);
+                s2[u] = T::mfma32(kf, qf[qs][s], s == 0 ? zero16 : s2[u]);
             }
         VIDI_ATTN_RM_PRIO_LO(1);
 #pragma unroll
@@ -225,66 +238,70 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s2[u][r]);
             mx = xhalf_max(mx);
             constexpr float TAU = 8.0f;
-            const float m_cand = fmaxf(m_run, mx * sc);
-            if (__any(m_cand > m_run + TAU)) {                 // also the very first sub-tile (m_run = -inf)
-                const float alpha = fast_exp2(m_run - m_cand); // 0 on the first sub-tile (o = l = 0 there)
-                m_run = m_cand;
-                l_run *= alpha;
+            const float m_cand = fmaxf(m_run[qs], mx * sc);
+            if (__any(m_cand > m_run[qs] + TAU)) {                 // also the very first sub-tile (m_run = -inf)
+                const float alpha = fast_exp2(m_run[qs] - m_cand); // 0 on the first sub-tile (o = l = 0 there)
+                m_run[qs] = m_cand;
+                l_run[qs] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+                    for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
             }
             float ps0 = 0.f, ps1 = 0.f;
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run));
-                pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run));
+                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run[qs]));
+                pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run[qs]));
                 if constexpr (!kOnesRow) { ps0 += pv[r]; ps1 += pv[r + 1]; }
             }
             const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
-            if constexpr (!kOnesRow) l_run += ps0 + ps1;
+            if constexpr (!kOnesRow) l_run[qs] += ps0 + ps1;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                o[dt] = T::mfma32(vf[dt][0], pf0, o[dt]);
-                o[dt] = T::mfma32(vf[dt][1], pf1, o[dt]);
+                o[qs][dt] = T::mfma32(vf[dt][0], pf0, o[qs][dt]);
+                o[qs][dt] = T::mfma32(vf[dt][1], pf1, o[qs][dt]);
             }
         }
+      }
     }
 
-    float l_tot;
-    if constexpr (kOnesRow) {
-        // output row D of the last d-tile: register (D%32 -> j = row/8, e = row%4) of the lanes with hi == (row/4)%2
-        constexpr int REG = 4 * (ROWD / 8) + (ROWD % 4), HI = (ROWD / 4) % 2;
-        const float mine = (hi == HI) ? o[DT - 1][REG] : 0.f;
-        l_tot = xhalf_sum(mine);
-    } else {
-        l_tot = xhalf_sum(l_run);
-    }
-    const float inv = 1.0f / l_tot;
-    // ---- epilogue: O^T registers -> LDS [128 q][D] -> row-contiguous 16-byte global stores (as attn_self.hip)
-    __syncthreads();
-    {
-        char* so = smem + (wave * 32 + l31) * ORW;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int qs = 0; qs < QS; ++qs) {
+        float l_tot;
+        if constexpr (kOnesRow) {
+            // output row D of the last d-tile: register (D%32 -> j = row/8, e = row%4) of the lanes with hi == (row/4)%2
+            constexpr int REG = 4 * (ROWD / 8) + (ROWD % 4), HI = (ROWD / 4) % 2;
+            const float mine = (hi == HI) ? o[qs][DT - 1][REG] : 0.f;
+            l_tot = xhalf_sum(mine);
+        } else {
+            l_tot = xhalf_sum(l_run[qs]);
+        }
+        const float inv = 1.0f / l_tot;
+        // ---- epilogue: O^T registers -> LDS [128 q][D] -> row-contiguous 16-byte global stores (as attn_self.hip)
+        __syncthreads();
+        {
+            char* so = smem + (wave * 32 + l31) * ORW;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = dt * 32 + 8 * j + 4 * hi;
-                if (d < D) {
-                    const u32x2 ov = {pack2<T>(o[dt][4 * j] * inv, o[dt][4 * j + 1] * inv),
-                                      pack2<T>(o[dt][4 * j + 2] * inv, o[dt][4 * j + 3] * inv)};
-                    *(u32x2*)(so + d * 2) = ov;
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = dt * 32 + 8 * j + 4 * hi;
+                    if (d < D) {
+                        const u32x2 ov = {pack2<T>(o[qs][dt][4 * j] * inv, o[qs][dt][4 * j + 1] * inv),
+                                          pack2<T>(o[qs][dt][4 * j + 2] * inv, o[qs][dt][4 * j + 3] * inv)};
+                        *(u32x2*)(so + d * 2) = ov;
+                    }
                 }
-            }
-    }
-    __syncthreads();
-    for (int i = tid; i < 128 * NCH; i += 256) {
-        const int row = i / NCH, c = i % NCH;
-        const int qq = qt * 128 + row;
-        if (qq < p.N)
-            *(u32x4*)(p.O + ((size_t)b * p.N + qq) * p.ldo + h * D + c * 8) = *(const u32x4*)(smem + row * ORW + c * 16);
+        }
+        __syncthreads();
+        for (int i = tid; i < 128 * NCH; i += 256) {
+            const int row = i / NCH, c = i % NCH;
+            const int qq = qt * QB + qs * 128 + row;
+            if (qq < p.N)
+                *(u32x4*)(p.O + ((size_t)b * p.N + qq) * p.ldo + h * D + c * 8) = *(const u32x4*)(smem + row * ORW + c * 16);
+        }
     }
 }
 
@@ -292,7 +309,7 @@ int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipS
     if (p.B <= 0 || p.N <= 0 || p.H <= 0) return VIDI_ERR_SHAPE;
     if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8) || (p.bs % 8) || (p.hs % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)p.QKV & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
-    const dim3 grid(((p.N + 127) / 128) * p.H * p.B);
+    const dim3 grid(((p.N + 128 * VIDI_ATTN_RM_QS - 1) / (128 * VIDI_ATTN_RM_QS)) * p.H * p.B);
 #define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD>), grid, dim3(256), 0, st, p)
     if (dtype == VIDI_DT_BF16) {
         if (D == 72) LAUNCH(BF16, 72); else if (D == 64) LAUNCH(BF16, 64); else if (D == 16) LAUNCH(BF16, 16);
