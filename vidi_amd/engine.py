@@ -110,6 +110,8 @@ class VidiEngine:
         # towers: q | k | v as one row-major buffer + the transpose-read attention kernel (VIDI_ATTN_RM=1) or Q|K row-major + V transposed by
         # the projection's epilogue + the Vt attention kernel (0)
         self.attn_rm = os.environ.get("VIDI_ATTN_RM", "1") != "0"
+        # multimodal stream: each (post-norm + residual, next pre-norm) pair as one launch (VIDI_STREAM_NORM2=0: two launches)
+        self.stream_norm2 = os.environ.get("VIDI_STREAM_NORM2", "1") != "0"
         self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -543,8 +545,10 @@ class VidiEngine:
         u = self._buf("mm_u", (ntot, H))
         gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
         eps = cfg.rms_norm_eps
+        fused = self.stream_norm2 and not self.mistral
         for li, L in enumerate(self.layers if ntot > 0 else []):
-            hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                               # gemma.py:183-184 / mistral.py:204-205
+            if not fused or li == 0:                                                                 # fused: produced by the previous layer's second pass
+                hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                           # gemma.py:183-184 / mistral.py:204-205
             hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
             if li == Lr - 1:
                 break                                                                                # dead update on the last layer
@@ -554,15 +558,21 @@ class VidiEngine:
                 hip.gemm_glu(hbuf, L["wgu"], gt, act=hip.ACT_SILU)
                 hip.gemm(gt, L["wdown"], None, X, residual=X)                                        # :135
                 continue
-            # (fusing each post-norm + residual with the following pre-norm through vidi_resid_norm2 — the decode path's kernel, which
-            #  requests all six operands up front — measured SLOWER at 126 080 rows: 233 vs 193 ms of norm time per prefill,
-            #  4.3 vs 5.1 TB/s; profiles/r2_notes.md)
             hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)                               # :196-197 o_proj(repeat_kv(V))
-            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_attn"], eps=eps, residual=X, out=X)           # :198-201
-            hip.norm(hip.NORM_GEMMA, X, L["ln_pre_ffn"], eps=eps, out=hbuf)                          # :118
+            if fused:
+                # residual + post-norm and the following pre-norm in ONE pass over the rows (vidi_resid_norm2, the phase-by-phase
+                # form for many rows: the arithmetic and rounding points of NORM_GEMMA_ADD followed by NORM_GEMMA, bit-identical; 4
+                # instead of 5 row transfers per pair)
+                hip.resid_norm2(u, None, None, X, L["ln_post_attn"], L["ln_pre_ffn"], X, hbuf, eps=eps)   # :198-201 + :118
+            else:
+                hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_attn"], eps=eps, residual=X, out=X)       # :198-201
+                hip.norm(hip.NORM_GEMMA, X, L["ln_pre_ffn"], eps=eps, out=hbuf)                      # :118
             hip.gemm_geglu(hbuf, L["wgu"], gt)                                                       # :119 gate/up + GeGLU
             hip.gemm(gt, L["wdown"], None, u)                                                        # :119 down_proj
-            hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_ffn"], eps=eps, residual=X, out=X)            # :120-121
+            if fused:
+                hip.resid_norm2(u, None, None, X, L["ln_post_ffn"], self.layers[li + 1]["ln_in"], X, hbuf, eps=eps)   # :120-121 + next :183
+            else:
+                hip.norm(hip.NORM_GEMMA_ADD, u, L["ln_post_ffn"], eps=eps, residual=X, out=X)        # :120-121
         if check_masks:
             # one host sync per VIDEO (the reference syncs per layer per step: xattn.py:214-215)
             for name, m in (("img", img_mask), ("aud", aud_mask)):
