@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void norm_kernel(NormParams p) {
 // stream, 10^5 rows): operands are fetched phase by phase, so a row costs ~90 VGPRs instead of ~200 and 5 waves per SIMD stay resident
 // (the preloading form measured 4.3 TB/s at 126 080 rows, two separate launches 5.1 TB/s).
 template <typename T, int MAXC, bool PRELOAD>
-__global__ __launch_bounds__(256) void resid_norm2_kernel(const u16* __restrict__ A, const u16* __restrict__ B, const u16* __restrict__ C,
-                                                          const u16* Res, const u16* __restrict__ W1, const u16* __restrict__ W2,
-                                                          u16* Y1, u16* __restrict__ Y2, int rows, int H, long long ld, float eps) {
+__device__ __forceinline__ void resid_norm2_body(const u16* __restrict__ A, const u16* __restrict__ B, const u16* __restrict__ C,
+                                                 const u16* Res, const u16* __restrict__ W1, const u16* __restrict__ W2,
+                                                 u16* Y1, u16* __restrict__ Y2, int rows, int H, long long ld, float eps) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -135,66 +135,191 @@ __global__ __launch_bounds__(256) void resid_norm2_kernel(const u16* __restrict_
             }
         }
     }
-    float x[MAXC][8];
+    // the row between the phases is kept PACKED: every value is already rounded to T (rnd<T>), so packing is lossless and the row
+    // costs 4 registers per chunk instead of 8
+    u32x4 xp[MAXC];
     float s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
-            unpack8<T>(ra[c], x[c]);
-            float z[8];
+            float x[8], z[8];
+            unpack8<T>(ra[c], x);
             if (B) {
                 unpack8<T>(PRELOAD ? rb[c] : *(const u32x4*)(B + row * ld + ch * 8), z);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(x[c][e] + z[e]);
+                for (int e = 0; e < 8; ++e) x[e] = rnd<T>(x[e] + z[e]);
             }
             if (C) {
                 unpack8<T>(PRELOAD ? rc[c] : *(const u32x4*)(C + row * ld + ch * 8), z);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(x[c][e] + z[e]);
+                for (int e = 0; e < 8; ++e) x[e] = rnd<T>(x[e] + z[e]);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s2 += x[c][e] * x[c][e];
+            for (int e = 0; e < 8; ++e) s2 += x[e] * x[e];
+            xp[c] = (B || C) ? pack8<T>(x) : ra[c];
         }
     }
     const float rs1 = rsqrtf(wave_sum(s2) / H + eps);
+    if constexpr (!PRELOAD) __builtin_amdgcn_sched_barrier(0);
     float t2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
-            float w[8], r[8];
+            float x[8], w[8], r[8];
+            unpack8<T>(xp[c], x);
             unpack8<T>(PRELOAD ? rw1[c] : *(const u32x4*)(W1 + ch * 8), w);
             unpack8<T>(PRELOAD ? rr[c] : *(const u32x4*)(Res + row * ld + ch * 8), r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[c][e] = rnd<T>(r[e] + rnd<T>(x[c][e] * rs1 * (1.0f + w[e])));
-            *(u32x4*)(Y1 + row * ld + ch * 8) = pack8<T>(x[c]);
+            for (int e = 0; e < 8; ++e) x[e] = rnd<T>(r[e] + rnd<T>(x[e] * rs1 * (1.0f + w[e])));
+            xp[c] = pack8<T>(x);
+            *(u32x4*)(Y1 + row * ld + ch * 8) = xp[c];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t2 += x[c][e] * x[c][e];
+            for (int e = 0; e < 8; ++e) t2 += x[e] * x[e];
         }
     }
     const float rs2 = rsqrtf(wave_sum(t2) / H + eps);
+    if constexpr (!PRELOAD) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
-            float w[8], y[8];
+            float x[8], w[8], y[8];
+            unpack8<T>(xp[c], x);
             unpack8<T>(PRELOAD ? rw2[c] : *(const u32x4*)(W2 + ch * 8), w);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = x[c][e] * rs2 * (1.0f + w[e]);
+            for (int e = 0; e < 8; ++e) y[e] = x[e] * rs2 * (1.0f + w[e]);
             *(u32x4*)(Y2 + row * ld + ch * 8) = pack8<T>(y);
         }
     }
+}
+
+// decode form (rows <= 64): all six operands of a row requested up front, latency over occupancy
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void resid_norm2_kernel(const u16* A, const u16* B, const u16* C, const u16* Res, const u16* W1,
+                                                          const u16* W2, u16* Y1, u16* Y2, int rows, int H, long long ld, float eps) {
+    resid_norm2_body<T, MAXC, true>(A, B, C, Res, W1, W2, Y1, Y2, rows, H, ld, eps);
+}
+
+// many-row form (the multimodal stream, 126 080 rows): operands requested phase by phase, registers capped for 4 waves per SIMD
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void resid_norm2_rows_kernel(const u16* A, const u16* B, const u16* C, const u16* Res, const u16* W1, const u16* W2, u16* Y1, u16* Y2,
+                             int rows, int H, long long ld, float eps) {
+    resid_norm2_body<T, MAXC, false>(A, B, C, Res, W1, W2, Y1, Y2, rows, H, ld, eps);
+}
+
+// ---- LayerNorm statistics only: stats[row] = (mean, rsqrt(var + eps)), two-pass variance on the register-resident row ------
+//   The consuming projection applies them in its epilogue (GemmParams::ln_stats): LayerNorm(x) is never written.
+//   One read of the row: algorithmic bytes = rows * H * 2 B.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ X, float* __restrict__ stats, long long rows, int H,
+                                                        long long ldx, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = H / 8;
+    float x[MAXC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            unpack8<T>(*(const u32x4*)(X + row * ldx + ch * 8), x[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 += x[c][e];
+        }
+    }
+    const float mean = wave_sum(s1) / H;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + c * 64 < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v += (x[c][e] - mean) * (x[c][e] - mean);
+    const float rs = rsqrtf(wave_sum(v) / H + eps);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rs;
+    }
+}
+
+// ---- LayerNorm statistics from the per-strip partial sums a producing GEMM left (GemmParams::stat_part) ------------------------------
+//   part[row][strip] = (sum y, sum y^2) over a 128-column strip;  stats[row] = (mean, rsqrt(E[y^2] - mean^2 + eps)).
+//   One-pass variance in fp32: the relative error of var is ~1e-7 * E[y^2]/var, i.e. below the bf16 rounding of the consumer for any
+//   row whose mean is within ~50 standard deviations of zero (the towers' residual streams are within a few).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, long long rows, int nstr,
+                                                          float invH, float eps) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const f32x2_t* p = (const f32x2_t*)part + row * nstr;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < nstr; ++i) { const f32x2_t v = p[i]; s1 += v[0]; s2 += v[1]; }
+    const float mean = s1 * invH;
+    const float var = fmaxf(s2 * invH - mean * mean, 0.f);
+    *((f32x2_t*)stats + row) = f32x2_t{mean, rsqrtf(var + eps)};
+}
+
+int vidi_ln_finalize_dispatch(const float* part, float* stats, long long rows, int nstr, int H, float eps, hipStream_t st) {
+    if (rows <= 0 || nstr <= 0 || H <= 0) return VIDI_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, stats, rows, nstr, 1.0f / H, eps);
+    return (int)hipGetLastError();
+}
+
+// the same partial sums computed from a stored matrix (small problems whose GEMM runs on a tile kernel without the fused emission)
+template <typename T>
+__global__ __launch_bounds__(256) void row_partials_kernel(const u16* __restrict__ Y, float* __restrict__ part, long long rows, int N, long long ldy) {
+    const int nstr = (N + 127) >> 7;
+    const long long idx = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);          // one 16-lane row per (matrix row, strip)
+    const int c = threadIdx.x & 15;
+    const bool live = idx < rows * nstr;
+    const long long row = live ? idx / nstr : 0;
+    const int strip = live ? (int)(idx % nstr) : 0;
+    const int n = strip * 128 + c * 8;
+    float s1 = 0.f, s2 = 0.f;
+    if (live && n < N) {
+        float x[8];
+        unpack8<T>(*(const u32x4*)(Y + row * ldy + n), x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += x[e]; s2 = __builtin_fmaf(x[e], x[e], s2); }
+    }
+    s1 = row16_sum(s1); s2 = row16_sum(s2);
+    if (live && c == 0) *((f32x2_t*)part + idx) = f32x2_t{s1, s2};
+}
+
+int vidi_row_partials_dispatch(const void* Y, float* part, long long rows, int N, long long ldy, int dtype, hipStream_t st) {
+    if (rows <= 0 || N <= 0 || N % 8 || ldy % 8) return VIDI_ERR_SHAPE;
+    const long long items = rows * ((N + 127) >> 7);
+    const dim3 grid((unsigned)((items + 15) / 16));
+    if (dtype == VIDI_DT_BF16) hipLaunchKernelGGL(row_partials_kernel<BF16>, grid, dim3(256), 0, st, (const u16*)Y, part, rows, N, ldy);
+    else if (dtype == VIDI_DT_F16) hipLaunchKernelGGL(row_partials_kernel<F16>, grid, dim3(256), 0, st, (const u16*)Y, part, rows, N, ldy);
+    else return VIDI_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+int vidi_row_stats_dispatch(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, hipStream_t st) {
+    if (rows <= 0 || H <= 0 || H % 8 || ldx % 8) return VIDI_ERR_SHAPE;
+    const int nchunk = H / 8;
+    const int grid = (int)((rows + 3) / 4);
+#define VIDI_RS(TT, MC) hipLaunchKernelGGL((row_stats_kernel<TT, MC>), dim3(grid), dim3(256), 0, st, (const u16*)X, stats, rows, H, ldx, eps)
+    if (dtype == VIDI_DT_BF16) {
+        if (nchunk <= 64) VIDI_RS(BF16, 1); else if (nchunk <= 192) VIDI_RS(BF16, 3); else if (nchunk <= 512) VIDI_RS(BF16, 8); else return VIDI_ERR_SHAPE;
+    } else if (dtype == VIDI_DT_F16) {
+        if (nchunk <= 64) VIDI_RS(F16, 1); else if (nchunk <= 192) VIDI_RS(F16, 3); else if (nchunk <= 512) VIDI_RS(F16, 8); else return VIDI_ERR_SHAPE;
+    } else return VIDI_ERR_DTYPE;
+#undef VIDI_RS
+    return (int)hipGetLastError();
 }
 
 int vidi_resid_norm2_dispatch(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1,
                               void* Y2, int rows, int H, long long ld, float eps, int dtype, hipStream_t st) {
     if (rows <= 0 || H <= 0 || H % 8 || ld % 8) return VIDI_ERR_SHAPE;
     const int nchunk = H / 8, grid = (rows + 3) / 4;
-#define VIDI_RN2_(TT, MC, PL)                                                                                                     \
-    hipLaunchKernelGGL((resid_norm2_kernel<TT, MC, PL>), dim3(grid), dim3(256), 0, st, (const u16*)A, (const u16*)B, (const u16*)C, \
+#define VIDI_RN2_(TT, MC, KN)                                                                                                     \
+    hipLaunchKernelGGL((KN<TT, MC>), dim3(grid), dim3(256), 0, st, (const u16*)A, (const u16*)B, (const u16*)C, \
                        (const u16*)Res, (const u16*)W1, (const u16*)W2, (u16*)Y1, (u16*)Y2, rows, H, ld, eps)
-#define VIDI_RN2(TT, MC) do { if (rows <= 64) VIDI_RN2_(TT, MC, true); else VIDI_RN2_(TT, MC, false); } while (0)
+#define VIDI_RN2(TT, MC) do { if (rows <= 64) VIDI_RN2_(TT, MC, resid_norm2_kernel); else VIDI_RN2_(TT, MC, resid_norm2_rows_kernel); } while (0)
     if (dtype == VIDI_DT_BF16) {
         if (nchunk <= 64) VIDI_RN2(BF16, 1); else if (nchunk <= 192) VIDI_RN2(BF16, 3); else if (nchunk <= 512) VIDI_RN2(BF16, 8); else return VIDI_ERR_SHAPE;
     } else if (dtype == VIDI_DT_F16) {
