@@ -150,6 +150,13 @@ size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD);
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
                     float scale, float softcap, int zsplit, int dtype, void* stream);
+/* T2V and T2A of one layer in ONE launch (gemma.py:81-91 runs them back to back): two vidi_attn_cross sweeps over disjoint key regions
+ * [key_startA, +n_keysA) and [key_startB, +n_keysB) of the same caches, with zsplitA / zsplitB key slices and their own masks and
+ * workspaces; identical partials to the two separate calls.  At decode a launch costs ~8 us on top of its bytes. */
+int vidi_attn_cross2(const void* Q, const void* Kc, const void* Vtc,
+                     const void* maskA, float* OpartA, float* MLA, int key_startA, int n_keysA, int zsplitA,
+                     const void* maskB, float* OpartB, float* MLB, int key_startB, int n_keysB, int zsplitB,
+                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, float scale, float softcap, int dtype, void* stream);
 /* Merge partials -> Out:[tokens, ldo] (head (kvh*G+g) at column (kvh*G+g)*HD).  Optional OutF32
  * [nkv][Rpad][HD] / OutML [nkv][Rpad][2] receive the merged result in PARTIAL form (numerator, m, l)
  * — one slice of the Opart/ML layout — so per-GPU results can be all-gathered and merged again.
@@ -184,6 +191,15 @@ int vidi_attn_text(const void* Q, const void* Kc, const void* Vc, const void* km
 int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void* kmask, void* O,
                        int B, int Lq, int Lmax, int nq, int nkv, int HD, const int* past_len_dev, int window,
                        float scale, float softcap, int dtype, void* stream);
+/* The single-token decode step's T2T in one launch: rope(q), rope(k) of the new token (TP gemma2:146-168), the KV-cache append
+ * (TP gemma2:262-275) and the attention of its nq heads over cache slots [max(0, pos - window), pos] (gemma.py:165-175) — what
+ * vidi_rope_cache followed by vidi_attn_text / vidi_attn_text_dyn compute at Lq = 1 (same scores and probabilities; the fp32
+ * summation order of the dot products differs).  qkv [B][ldqkv] = (q | k | v); cos/sin [B][HD]; O [B][nq*HD]; pos = *pos_dev when
+ * pos_dev is non-null (hipGraph-capturable), else pos0.  VIDI_ERR_SHAPE when the scores of the visible keys do not fit 64 KB of LDS
+ * (callers then use the two-launch form). */
+int vidi_attn_text_decode(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cos_, const void* sin_, void* O,
+                          int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window, float scale, float softcap,
+                          int dtype, void* stream);
 /* apply_rotary_pos_emb in place (TP gemma2:146-168); cos/sin:[rows,HD] in the storage dtype. */
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
               int dtype, void* stream);

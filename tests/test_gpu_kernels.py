@@ -705,3 +705,121 @@ def test_gemv_glu_equals_gemv_plus_unpack(hip, dt, M, I, K, act):
     out = torch.empty_like(ref)
     hip.gemv_glu(x, w, out, code)
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
+# ---------------------------------------------------------------------------------------------
+# decode-step launches (round 2): fused T2T, dual cross-attention, multi-block argmax
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nq,nkv,HD", [(16, 8, 256), (8, 2, 128), (4, 2, 64)])
+@pytest.mark.parametrize("pos,window,dyn", [(0, 0, False), (5, 0, True), (70, 0, False), (200, 0, True), (200, 16, False), (131, 64, True)])
+def test_attn_text_decode_equals_rope_cache_then_attn_text(hip, dt, nq, nkv, HD, pos, window, dyn):
+    """vidi_attn_text_decode (rope + cache append + T2T in one launch) against vidi_rope_cache + vidi_attn_text[_dyn] at Lq = 1:
+    the caches bit for bit; the output within accumulation-order noise of the SAME scores and probabilities (fp32 dot products summed
+    in a different order, then one rounding to the dtype): 2 ulp of the dtype relative + 0.2 % of the output spread."""
+    B, Lmax = 2, 256
+    kvd = nkv * HD
+    qkv = seeded((B, nq * HD + 2 * kvd + 8), 90, dtype=dt)[:, : nq * HD + 2 * kvd].cuda()
+    posn = torch.tensor([[pos], [max(pos - 3, 0)]])                                  # per-row rope positions (right-padded batch)
+    cos, sin = O.rope_cos_sin(posn, HD, 10000.0, dt)
+    cs, sn = dev(cos.reshape(B, HD).contiguous()), dev(sin.reshape(B, HD).contiguous())
+    kc0 = seeded((B, Lmax, kvd), 91, dtype=dt); vc0 = seeded((B, Lmax, kvd), 92, dtype=dt)
+    kmask = torch.ones((B, Lmax), dtype=torch.uint8)
+    kmask[1, 1: pos: 3] = 0                                                           # some padded keys in row 1
+    kmask = kmask.cuda()
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device="cuda") if dyn else None
+    sc, cap = HD ** -0.5, 50.0
+    kc_a, vc_a = dev(kc0.clone()), dev(vc0.clone())
+    qr = torch.empty((B, nq * HD), dtype=dt, device="cuda")
+    ref = torch.zeros((B, nq * HD), dtype=dt, device="cuda")
+    hip.rope_cache(qkv, qr, kc_a, vc_a, cs, sn, B=B, Lq=1, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, pos0=pos, pos_dev=pos_dev)
+    if dyn:
+        hip.attn_text_dyn(qr, kc_a, vc_a, kmask, ref, B=B, Lq=1, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, past_len_dev=pos_dev, window=window,
+                          scale=sc, softcap=cap)
+    else:
+        hip.attn_text(qr, kc_a, vc_a, kmask, ref, B=B, Lq=1, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, past_len=pos, window=window, scale=sc,
+                      softcap=cap)
+    kc_b, vc_b = dev(kc0.clone()), dev(vc0.clone())
+    out = torch.zeros((B, nq * HD), dtype=dt, device="cuda")
+    assert hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=HD, Lmax=Lmax, window=window, pos0=None if dyn else pos)
+    hip.attn_text_decode(qkv, kc_b, vc_b, kmask, cs, sn, out, B=B, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, window=window, scale=sc, softcap=cap,
+                         pos0=pos, pos_dev=pos_dev)
+    assert torch.equal(kc_a.view(torch.int16), kc_b.view(torch.int16)) and torch.equal(vc_a.view(torch.int16), vc_b.view(torch.int16))
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    report("attn_text_decode vs two launches", out, ref.float(), 2e-3 * ref.float().std().item(), 2 * ulp)
+
+
+def test_attn_text_decode_rejects_what_does_not_fit(hip):
+    """a cache whose scores do not fit the kernel's LDS plan is refused (the engine then uses the two-launch form)"""
+    dt = torch.bfloat16
+    nq, nkv, HD, Lmax = 16, 8, 256, 8192
+    assert not hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=HD, Lmax=Lmax, window=0, pos0=None)
+    qkv = torch.zeros((1, (nq + 2 * nkv) * HD), dtype=dt, device="cuda")
+    kc = torch.zeros((1, Lmax, nkv * HD), dtype=dt, device="cuda")
+    cs = torch.zeros((1, HD), dtype=dt, device="cuda")
+    out = torch.zeros((1, nq * HD), dtype=dt, device="cuda")
+    pos_dev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    with pytest.raises(hip.VidiHipError):
+        hip.attn_text_decode(qkv, kc, kc.clone(), None, cs, cs, out, B=1, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, window=0, scale=1.0, softcap=0.0,
+                             pos_dev=pos_dev)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("HD,nkv,G,Lq,Na,Nb,za,zb,masked", [(256, 8, 2, 1, 3000, 1100, 5, 2, True), (128, 2, 4, 3, 700, 200, 3, 1, False),
+                                                            (256, 2, 2, 39, 500, 333, 2, 2, True)])
+def test_attn_cross2_equals_two_launches(hip, dt, HD, nkv, G, Lq, Na, Nb, za, zb, masked):
+    """T2V + T2A in one launch: the partials (and so the merged outputs) are bit-identical to two vidi_attn_cross launches"""
+    nq = nkv * G
+    start_b = (Na + 63) // 64 * 64
+    ntile = (start_b + Nb + 63) // 64
+    g = torch.Generator(device="cuda").manual_seed(17)
+    kc = torch.randn((nkv, ntile, 64, HD), generator=g, device="cuda").to(dt)
+    vtc = torch.randn((nkv, 2 * ntile, HD, 32), generator=g, device="cuda").to(dt)
+    q = torch.randn((Lq, nq * HD), generator=g, device="cuda").to(dt)
+    ma = None
+    if masked:
+        ma = torch.ones((Na + 63) // 64 * 64, dtype=torch.uint8, device="cuda")
+        ma[5: Na: 7] = 0
+    R = Lq * G
+    Rpad = (R + 31) // 32 * 32
+    outs = []
+    for dual in (False, True):
+        wa = hip.attn_cross_workspace(za, nkv, Rpad, HD, "cuda"); wb = hip.attn_cross_workspace(zb, nkv, Rpad, HD, "cuda")
+        for t in (*wa, *wb):
+            t.fill_(float("nan"))
+        kw = dict(R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD, ntile64=ntile, scale=HD ** -0.5, softcap=50.0)
+        if dual:
+            hip.attn_cross2(q, kc, vtc, dict(mask=ma, opart=wa[0], ml=wa[1], key_start=0, n_keys=Na, zsplit=za),
+                            dict(mask=None, opart=wb[0], ml=wb[1], key_start=start_b, n_keys=Nb, zsplit=zb), **kw)
+        else:
+            hip.attn_cross(q, kc, vtc, ma, wa[0], wa[1], key_start=0, n_keys=Na, zsplit=za, **kw)
+            hip.attn_cross(q, kc, vtc, None, wb[0], wb[1], key_start=start_b, n_keys=Nb, zsplit=zb, **kw)
+        oa = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda"); ob = torch.zeros_like(oa)
+        hip.attn_merge2(wa[0], wa[1], oa, za, False, wb[0], wb[1], ob, zb, False, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+        outs.append((oa, ob))
+    assert torch.isfinite(outs[0][0].float()).all() and torch.isfinite(outs[0][1].float()).all()
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,V,pad", [(1, 256000, 0), (3, 1000, 0), (2, 1003, 5), (4, 40, 0)])
+def test_softcap_argmax_multi_block(hip, dt, B, V, pad):
+    """rows spread over many blocks: softcap values as the elementwise chain, FIRST maximal index (ties planted in different
+    blocks' slices), repeated calls (the per-row scratch cleans itself), rows that are not 16-byte aligned"""
+    cap = 30.0
+    for rep in range(3):
+        lg = seeded((B, V + pad), 100 + rep, 20.0, dtype=dt)[:, : V]
+        big = lg.float().abs().max().item() * 2 + 1.0
+        for b in range(B):                                                 # the same maximum at three places; the first one must win
+            for i in sorted(set([(7 * b + 3) % V, V // 2, V - 1 - b])):
+                lg[b, i] = big
+        ld = lg.cuda() if pad == 0 else torch.empty((B, V + pad), dtype=dt, device="cuda")[:, : V].copy_(lg)
+        idx = torch.full((B,), -1, dtype=torch.int64, device="cuda")
+        hip.softcap_argmax(ld, idx, cap)
+        x = lg.float() / cap
+        ref = (torch.tanh(x.to(dt).float()).to(dt).float() * cap).to(dt)
+        report("softcap (multi-block)", ld, ref.float(), *tol(dt, 10.0))
+        want = torch.tensor([min((7 * b + 3) % V, V // 2, V - 1 - b) for b in range(B)])
+        assert torch.equal(idx.cpu(), want), (idx.cpu(), want)
+        assert torch.equal(idx.cpu(), torch.argmax(ld.float().cpu(), dim=-1))

@@ -1,0 +1,128 @@
+"""Same-box A/B of the decode step (Vidi1.5-9B decoder, 60-min caches: 90 000 image + 36 000 audio keys, random data).
+
+  python tools/ab_decode.py gemv lib_a.so lib_b.so ...   the decoder's five skinny projections on every library (same ABI, loaded side by
+                                                       side with ctypes), weights cycled through > 256 MB so every call streams HBM
+  python tools/ab_decode.py one [tokens] [rounds]        the same loop with the engine's default switches only (for rocprofv3)
+  python tools/ab_decode.py e2e [tokens] [rounds]        one engine (the library VIDI_HIP_LIB names, default the product), ms per greedy
+                                                       token with the decode switches flipped between timed runs; greedy tokens compared
+"""
+import ctypes
+import dataclasses
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def gemv_ab(libs):
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [("qkv", "gemv", 1, 8192, 3584, 6), ("o_proj x3", "gemv", 3, 3584, 4096, 10), ("gate/up", "glu", 1, 14336, 3584, 3),
+              ("down", "gemv", 1, 3584, 14336, 4), ("lm_head", "gemv", 1, 256000, 3584, 1)]
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    for name, kind, M, N, K, copies in shapes:
+        rows = 2 * N if kind == "glu" else N
+        ws = [(torch.randn((rows, K), generator=g, device="cuda") * 0.02).to(dt) for _ in range(copies)]
+        x = torch.randn((M, K), generator=g, device="cuda").to(dt)
+        res, outs = {}, {}
+        for path in libs:
+            lib = ctypes.CDLL(path)
+            if kind == "glu":
+                f = lib.vidi_gemv_glu
+                f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+            else:
+                f = lib.vidi_gemv
+                f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+            f.restype = ctypes.c_int
+            y = torch.zeros((M, N), dtype=dt, device="cuda")
+
+            def run(w, f=f, y=y):
+                if kind == "glu":
+                    rc = f(x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, N, 1, 0, st())
+                else:
+                    rc = f(x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, N, 0, st())
+                assert rc == 0, rc
+            run(ws[0]); torch.cuda.synchronize()
+            outs[path] = y.clone()
+            res[path] = [run, 0.0]
+        rounds, reps = 5, 4
+        for _ in range(rounds):
+            for path in libs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    for w in ws:
+                        res[path][0](w)
+                e1.record(); torch.cuda.synchronize()
+                res[path][1] += e0.elapsed_time(e1) / (reps * len(ws))
+        for path in libs:
+            us = res[path][1] / rounds * 1e3
+            print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "lib": os.path.basename(path), "us": round(us, 2),
+                              "TB/s": round(rows * K * 2 / us / 1e6, 3),
+                              "bit_identical_to_first": bool(torch.equal(outs[path], outs[libs[0]]))}), flush=True)
+        del ws
+
+
+def e2e(tokens, rounds, only_default=False):
+    from vidi_amd import config as C
+    from vidi_amd.engine import VidiEngine
+    from vidi_amd.weights import init_random_weights
+    dt = torch.bfloat16
+    cfg = dataclasses.replace(C.vidi15_9b(), vis_num_layers=1, aud_num_layers=1)
+    eng = VidiEngine(cfg, init_random_weights(cfg, seed=3, dtype=dt, device="cuda"), dtype=dt, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = (torch.randn((90000, cfg.hidden_size), generator=g, device="cuda") * cfg.mm_std * eng.normalizer).to(dt)
+    aud = (torch.randn((36000, cfg.hidden_size), generator=g, device="cuda") * cfg.mm_std * eng.normalizer).to(dt)
+    mm = eng.mm_stream_prefill(img, None, aud, None, pre_normalized=True, check_masks=False)
+    mm.img_any_valid = mm.aud_any_valid = True
+    del img, aud
+    L = 39
+    ids = torch.randint(0, cfg.vocab_size, (1, L), generator=g, device="cuda")
+
+    def run(n):
+        ts = eng.new_text_state(1, L + n + 2)
+        hn = eng.text_forward(eng.embed_tokens(ids), torch.arange(L, device="cuda"), ts, mm, Lq=L)
+        ts.n_valid = torch.tensor([L], device="cuda")
+        _, nxt = eng.logits_argmax(hn.view(1, L, -1)[:, -1])
+        torch.cuda.synchronize()
+        toks = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            emb = eng.embed_tokens(nxt)
+            posn = ts.n_valid.clone(); ts.n_valid += 1
+            hn = eng.text_forward(emb, posn, ts, mm, Lq=1)
+            _, nxt = eng.logits_argmax(hn)
+            toks.append(int(nxt[0]))
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, toks
+
+    arms = [("two-launch T2T, cross per modality", False, False), ("fused T2T", True, False), ("dual cross", False, True),
+            ("fused T2T + dual cross", True, True)]
+    if only_default:                                     # the engine's own switches (env), e.g. under rocprofv3
+        arms = [("engine defaults", eng.decode_attn, eng.cross_dual)]
+    tot = {a[0]: 0.0 for a in arms}
+    toks = {}
+    for r in range(rounds + 1):
+        for name, da, cd in arms:
+            eng.decode_attn, eng.cross_dual = da, cd
+            ms, t = run(tokens)
+            if r == 0:
+                toks[name] = t
+            else:
+                tot[name] += ms
+    for name, _, _ in arms:
+        print(json.dumps({"lib": os.path.basename(os.environ.get("VIDI_HIP_LIB", "libvidi_hip.so")), "arm": name,
+                          "ms_per_token": round(tot[name] / rounds, 3), "same_greedy_tokens_as_first_arm": toks[name] == toks[arms[0][0]]}),
+              flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gemv":
+        gemv_ab([a for a in sys.argv[2:] if a.endswith(".so")])
+    else:
+        a = [x for x in sys.argv[2:]]
+        e2e(int(a[0]) if a else 24, int(a[1]) if len(a) > 1 else 2, only_default=sys.argv[1] == "one")

@@ -19,8 +19,10 @@
 #include "kernels.h"
 
 
+// z / zsplit: this block's key slice and the number of slices of ITS modality (the dual launch below runs the slices of two
+// modalities in one grid)
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
+__device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const int z, const int zsplit) {
     constexpr int QROW = HD * 2;                 // bytes per row
     constexpr int CPR = HD / 8;                  // 16-byte chunks per K/Q row (32 for HD=256)
     constexpr int KST = HD / 16;                 // k16 steps of QK^T
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 
     // ---- this wave's key range (32-key sub-tiles) ----------------------------------------------
     const int nsub = (p.n_keys + 31) / 32;
-    const int wtot = gridDim.z * 4;
-    const int wg = blockIdx.z * 4 + wave;
+    const int wtot = zsplit * 4;
+    const int wg = z * 4 + wave;
     const int per = (nsub + wtot - 1) / wtot;
     const int st_begin = min(wg * per, nsub), st_end = min(st_begin + per, nsub);
 
@@ -253,13 +255,26 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             accv += v * scw;
             l += scw * sml[(w * 32 + row) * 2 + 1];
         }
-        const size_t base = ((size_t)blockIdx.z * p.nkv + kvh) * p.Rpad + r;
+        const size_t base = ((size_t)z * p.nkv + kvh) * p.Rpad + r;
         *(f32x4*)(p.Opart + base * HD + c4 * 4) = accv;
         if (c4 == 0) {
             p.ML[base * 2] = m;
             p.ML[base * 2 + 1] = l;
         }
     }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) { attn_cross_body<T, HD>(p, blockIdx.z, gridDim.z); }
+
+// T2V and T2A of one layer in ONE launch (decode: a launch of this kernel costs ~8 us on top of its bytes, measured from the two
+// modalities' durations; the two key regions are disjoint slices of the same caches): the first `za` z-slices sweep set a's keys,
+// the rest set b's.  Same per-slice arithmetic as two attn_cross_kernel launches with zsplit = za and gridDim.z - za.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_cross2_kernel(AttnCrossParams a, AttnCrossParams b, int za) {
+    const int bz = blockIdx.z;
+    if (bz < za) attn_cross_body<T, HD>(a, bz, za);
+    else attn_cross_body<T, HD>(b, bz - za, (int)gridDim.z - za);
 }
 
 // Combine W partials per (row, kv head): O = sum_w 2^(m_w-m) O_w / sum_w 2^(m_w-m) l_w.
@@ -365,6 +380,31 @@ int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int d
             done = true;                                                                      \
         }                                                                                     \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                \
+    } while (0)
+    if (dtype == VIDI_DT_BF16) { if (HD == 256) LAUNCH(BF16, 256); else LAUNCH(BF16, 128); }
+    else if (dtype == VIDI_DT_F16) { if (HD == 256) LAUNCH(F16, 256); else LAUNCH(F16, 128); }
+    else return VIDI_ERR_DTYPE;
+#undef LAUNCH
+    return (int)hipGetLastError();
+}
+
+int vidi_attn_cross2_dispatch(const AttnCrossParams& a, const AttnCrossParams& b, int HD, int za, int zb, int dtype, hipStream_t st) {
+    if (a.R <= 0 || a.n_keys <= 0 || b.n_keys <= 0 || a.G <= 0 || a.nkv <= 0 || za <= 0 || zb <= 0) return VIDI_ERR_SHAPE;
+    if (a.key_start % 64 != 0 || b.key_start % 64 != 0 || a.Rpad % 32 != 0 || a.Rpad < a.R) return VIDI_ERR_SHAPE;
+    if ((a.ldq % 8) || ((uintptr_t)a.Q & 15) || ((uintptr_t)a.Kc & 15) || ((uintptr_t)a.Vtc & 15)) return VIDI_ERR_ALIGN;
+    if (HD != 256 && HD != 128) return VIDI_ERR_SHAPE;
+    const dim3 grid(a.nkv, a.Rpad / 32, za + zb);
+    const int lds = 32 * HD * 2 + 4 * (32 * HD * 2 + HD * 64);
+#define LAUNCH(TT, HH)                                                                        \
+    do {                                                                                      \
+        auto kern = attn_cross2_kernel<TT, HH>;                                               \
+        static bool done = false;                                                             \
+        if (!done) {                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return (int)e;                                               \
+            done = true;                                                                      \
+        }                                                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, b, za);                         \
     } while (0)
     if (dtype == VIDI_DT_BF16) { if (HD == 256) LAUNCH(BF16, 256); else LAUNCH(BF16, 128); }
     else if (dtype == VIDI_DT_F16) { if (HD == 256) LAUNCH(F16, 256); else LAUNCH(F16, 128); }

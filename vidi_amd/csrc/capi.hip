@@ -221,6 +221,22 @@ int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* 
     return vidi_attn_cross_dispatch(p, HD, zsplit, dtype, (hipStream_t)stream);
 }
 
+int vidi_attn_cross2(const void* Q, const void* Kc, const void* Vtc,
+                     const void* maskA, float* OpartA, float* MLA, int key_startA, int n_keysA, int zsplitA,
+                     const void* maskB, float* OpartB, float* MLB, int key_startB, int n_keysB, int zsplitB,
+                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, float scale, float softcap, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!Q || !Kc || !Vtc || !OpartA || !MLA || !OpartB || !MLB) return VIDI_ERR_ARG;
+    if ((key_startA + n_keysA + 63) / 64 > ntile64 || (key_startB + n_keysB + 63) / 64 > ntile64) return VIDI_ERR_SHAPE;
+    AttnCrossParams a, b;
+    a.Q = (const u16*)Q; a.Kc = (const u16*)Kc; a.Vtc = (const u16*)Vtc; a.mask = (const unsigned char*)maskA;
+    a.Opart = OpartA; a.ML = MLA; a.R = R; a.Rpad = Rpad; a.G = G; a.nkv = nkv; a.ldq = ldq;
+    a.ntile64 = ntile64; a.key_start = key_startA; a.n_keys = n_keysA; a.scale = scale; a.softcap = softcap;
+    b = a;
+    b.mask = (const unsigned char*)maskB; b.Opart = OpartB; b.ML = MLB; b.key_start = key_startB; b.n_keys = n_keysB;
+    return vidi_attn_cross2_dispatch(a, b, HD, zsplitA, zsplitB, dtype, (hipStream_t)stream);
+}
+
 int vidi_attn_merge(const float* Opart, const float* ML, void* Out, float* OutF32, float* OutML,
                     int W, int nkv, int R, int Rpad, int G, int HD, int ldo, int zero_out, int dtype, void* stream) {
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
@@ -288,6 +304,15 @@ int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void
     p.B = B; p.Lq = Lq; p.Lmax = Lmax; p.nq = nq; p.nkv = nkv; p.past_len = 0; p.past_len_dev = past_len_dev; p.window = window;
     p.scale = scale; p.softcap = softcap;
     return vidi_attn_text_dispatch(p, HD, dtype, (hipStream_t)stream);
+}
+
+int vidi_attn_text_decode(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cos_, const void* sin_, void* O,
+                          int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window, float scale, float softcap,
+                          int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!qkv || !Kc || !Vc || !cos_ || !sin_ || !O) return VIDI_ERR_ARG;
+    return vidi_attn_text_decode_dispatch(qkv, ldqkv, Kc, Vc, kmask, cos_, sin_, O, B, Lmax, nq, nkv, HD, pos0, pos_dev, window, scale,
+                                          softcap, dtype, (hipStream_t)stream);
 }
 
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,

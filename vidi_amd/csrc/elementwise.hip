@@ -209,34 +209,72 @@ __global__ void geglu_unpack_kernel(const u16* __restrict__ Yp, u16* __restrict_
 
 // ---- final-logit softcap + greedy argmax — gemma.py:565-569 + do_sample=False ------------------
 //   logits <- T(T(tanh(T(x/cap))) * cap) in place ; idx[b] = first argmax
+//   One block per row walked the 256 000 logits in 123 us per decode step (round 2 trace); now a row is spread over up to 128 blocks:
+//   each reduces its slice to (value, first index), folds it into a per-row 64-bit key with atomicMax (value in the high word as an
+//   order-preserving integer, ~index in the low word: max = largest value, then smallest index) and the last block to arrive writes
+//   idx[b] and clears the row's scratch for the next call.  The scratch lives in the library (VIDI_AM_ROWS rows): calls on different
+//   streams must not overlap in time (the engine issues its decode step on one stream).
+#define VIDI_AM_ROWS 256
+__device__ unsigned long long g_am_best[VIDI_AM_ROWS];
+__device__ unsigned int g_am_count[VIDI_AM_ROWS];
+
 template <typename T>
-__global__ __launch_bounds__(1024) void softcap_argmax_kernel(u16* __restrict__ logits, long long* __restrict__ idx, int V,
-                                                              long long ld, float cap) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    u16* row = logits + (size_t)blockIdx.x * ld;
+__device__ __forceinline__ float softcap_value(float x, float cap) { return rnd<T>(rnd<T>(tanhf(rnd<T>(x / cap))) * cap); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void softcap_argmax_kernel(u16* __restrict__ logits, long long* __restrict__ idx, int V,
+                                                             long long ld, float cap, int vec) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    u16* row = logits + (size_t)b * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        float x = T::to_f32(row[i]);
-        if (cap > 0.f) {
-            x = rnd<T>(rnd<T>(tanhf(rnd<T>(x / cap))) * cap);
-            row[i] = T::from_f32(x);
+    if (vec) {                                           // V % 8 == 0 and 16-byte aligned rows
+        for (int c = blockIdx.x * 256 + tid; c < V / 8; c += gridDim.x * 256) {
+            float x[8];
+            unpack8<T>(*(const u32x4*)(row + (size_t)c * 8), x);
+            if (cap > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = softcap_value<T>(x[e], cap);
+                *(u32x4*)(row + (size_t)c * 8) = pack8<T>(x);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (x[e] > best || (x[e] == best && c * 8 + e < bi)) { best = x[e]; bi = c * 8 + e; }
         }
-        if (x > best || (x == best && i < bi)) { best = x; bi = i; }
+    } else {
+        for (int i = blockIdx.x * 256 + tid; i < V; i += gridDim.x * 256) {
+            float x = T::to_f32(row[i]);
+            if (cap > 0.f) {
+                x = softcap_value<T>(x, cap);
+                row[i] = T::from_f32(x);
+            }
+            if (x > best || (x == best && i < bi)) { best = x; bi = i; }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        idx[blockIdx.x] = bi;
+        if (bi != 0x7fffffff) {                          // a slice of NaNs only contributes nothing (as `x > best` never held for them)
+            unsigned u = __float_as_uint(best);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            atomicMax(&g_am_best[b], ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi));
+        }
+        __threadfence();
+        if (atomicAdd(&g_am_count[b], 1u) == gridDim.x - 1) {
+            const unsigned long long key = atomicExch(&g_am_best[b], 0ull);
+            g_am_count[b] = 0;
+            idx[b] = key ? (long long)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0x7fffffffll;
+        }
     }
 }
 
@@ -341,8 +379,12 @@ static int ew_dispatch_T(int op, void** a, const long long* i, const float* f, h
             break;
         }
         case EW_SOFTCAP_ARGMAX: {
-            hipLaunchKernelGGL(softcap_argmax_kernel<T>, dim3((int)i[0]), dim3(1024), 0, st, (u16*)a[0], (long long*)a[1],
-                               (int)i[1], i[2], f[0]);
+            const int B = (int)i[0], V = (int)i[1];
+            if (B > VIDI_AM_ROWS) return VIDI_ERR_SHAPE;
+            const int vec = (V % 8 == 0) && (i[2] % 8 == 0) && (((uintptr_t)a[0] & 15) == 0);
+            const int items = vec ? V / 8 : V;
+            const int nblk = max(1, min(128, (items + 255) / 256));
+            hipLaunchKernelGGL(softcap_argmax_kernel<T>, dim3(nblk, B), dim3(256), 0, st, (u16*)a[0], (long long*)a[1], V, i[2], f[0], vec);
             break;
         }
         case EW_MEL_T: {

@@ -73,137 +73,6 @@ __global__ __launch_bounds__(256) void gemm_kernel_regstage(GemmParams p) {
     }
 }
 
-// ---- skinny GEMM (M <= 8): HBM-bound weight streaming for decode -------------------------------
-//   Y[m][n] = sum_k X[m][k] W[n][k].  Every wave owns RPW weight rows per step and streams them
-//   with 16-byte non-temporal loads straight into VGPRs (no LDS round trip: each weight byte is
-//   used once); the few activation rows are re-read from L1/L2.  Wave-reduce at the end.
-//   Algorithmic bytes = N*K*2 (weights); roofline = HBM.
-template <typename T, int MMAX, int RPW>
-__global__ __launch_bounds__(256) void gemv_kernel(const u16* __restrict__ X, const u16* __restrict__ W, u16* __restrict__ Y,
-                                                   int M, int N, int K, int ldx, int ldw, int ldy) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nchunk = K / 8;                          // 16-byte chunks per row
-    const int waves_total = gridDim.x * 4;
-    for (int nb = (blockIdx.x * 4 + wave) * RPW; nb < N; nb += waves_total * RPW) {
-        float acc[RPW][MMAX];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int m = 0; m < MMAX; ++m) acc[r][m] = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
-            u32x4 wv[RPW];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int n = min(nb + r, N - 1);
-                wv[r] = __builtin_nontemporal_load((const u32x4*)(W + (size_t)n * ldw + c * 8));
-            }
-            float xf[MMAX][8];
-#pragma unroll
-            for (int m = 0; m < MMAX; ++m) {
-                const int mm = min(m, M - 1);
-                const u32x4 xv = *(const u32x4*)(X + (size_t)mm * ldx + c * 8);
-                unpack8<T>(xv, xf[m]);
-            }
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                float wf[8];
-                unpack8<T>(wv[r], wf);
-#pragma unroll
-                for (int m = 0; m < MMAX; ++m)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[r][m] = fmaf(wf[e], xf[m][e], acc[r][m]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int m = 0; m < MMAX; ++m) {
-                const float s = wave_sum(acc[r][m]);
-                if (lane == 0 && nb + r < N && m < M) Y[(size_t)m * ldy + nb + r] = T::from_f32(s);
-            }
-    }
-}
-
-// ---- skinny gated-MLP front half: gate/up GEMV + act(gate) * up in one launch ------------------------------------------
-//   W: [2I, K] with gate/up rows interleaved in blocks of 32 (the MODE_GEGLU weight layout); a wave owns RPW features i and
-//   streams their gate row (i/32)*64 + i%32 and up row (+32).  Y[m][i] = T( T(act(T(g))) * T(u) ) — the values of
-//   gemv_kernel followed by geglu_unpack_kernel, bit for bit (same per-lane accumulation order), one launch and no [M, 2I] round trip.
-template <typename T, int MMAX, int RPW>
-__global__ __launch_bounds__(256) void gemv_glu_kernel(const u16* __restrict__ X, const u16* __restrict__ W, u16* __restrict__ Y,
-                                                       int M, int I, int K, int ldx, int ldw, int ldy, int silu) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nchunk = K / 8;
-    const int waves_total = gridDim.x * 4;
-    for (int ib = (blockIdx.x * 4 + wave) * RPW; ib < I; ib += waves_total * RPW) {
-        float ag[RPW][MMAX], au[RPW][MMAX];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int m = 0; m < MMAX; ++m) { ag[r][m] = 0.f; au[r][m] = 0.f; }
-        for (int c = lane; c < nchunk; c += 64) {
-            u32x4 wg[RPW], wu[RPW];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int i = min(ib + r, I - 1);
-                const size_t grow = (size_t)(i >> 5) * 64 + (i & 31);
-                wg[r] = __builtin_nontemporal_load((const u32x4*)(W + grow * ldw + c * 8));
-                wu[r] = __builtin_nontemporal_load((const u32x4*)(W + (grow + 32) * ldw + c * 8));
-            }
-            float xf[MMAX][8];
-#pragma unroll
-            for (int m = 0; m < MMAX; ++m) {
-                const int mm = min(m, M - 1);
-                unpack8<T>(*(const u32x4*)(X + (size_t)mm * ldx + c * 8), xf[m]);
-            }
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                float gf[8], uf[8];
-                unpack8<T>(wg[r], gf);
-                unpack8<T>(wu[r], uf);
-#pragma unroll
-                for (int m = 0; m < MMAX; ++m) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ag[r][m] = fmaf(gf[e], xf[m][e], ag[r][m]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) au[r][m] = fmaf(uf[e], xf[m][e], au[r][m]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int m = 0; m < MMAX; ++m) {
-                const float g = rnd<T>(wave_sum(ag[r][m])), u = rnd<T>(wave_sum(au[r][m]));
-                if (lane == 0 && ib + r < I && m < M) Y[(size_t)m * ldy + ib + r] = T::from_f32(rnd<T>(silu ? silu_f(g) : gelu_tanh_f(g)) * u);
-            }
-    }
-}
-
-int vidi_gemv_glu_dispatch(const void* X, const void* W, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype,
-                           hipStream_t st) {
-    if (M <= 0 || M > 8 || I <= 0 || (I % 32) || K <= 0 || K % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0) return VIDI_ERR_SHAPE;
-    if (((uintptr_t)W & 15) || ((uintptr_t)X & 15)) return VIDI_ERR_ALIGN;
-    if (act != ACT_GELU_TANH && act != ACT_SILU) return VIDI_ERR_ARG;
-    const int silu = act == ACT_SILU;
-    auto go = [&](auto kern, int rpw) -> int {
-        const int blocks = max(1, min((I + 4 * rpw - 1) / (4 * rpw), 256 * 8));
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, (const u16*)X, (const u16*)W, (u16*)Y, M, I, K, ldx, ldw, ldy, silu);
-        return (int)hipGetLastError();
-    };
-    if (dtype == VIDI_DT_BF16) {
-        if (M <= 1) return go(gemv_glu_kernel<BF16, 1, 2>, 2);
-        if (M <= 2) return go(gemv_glu_kernel<BF16, 2, 2>, 2);
-        if (M <= 4) return go(gemv_glu_kernel<BF16, 4, 1>, 1);
-        return go(gemv_glu_kernel<BF16, 8, 1>, 1);
-    } else if (dtype == VIDI_DT_F16) {
-        if (M <= 1) return go(gemv_glu_kernel<F16, 1, 2>, 2);
-        if (M <= 2) return go(gemv_glu_kernel<F16, 2, 2>, 2);
-        if (M <= 4) return go(gemv_glu_kernel<F16, 4, 1>, 1);
-        return go(gemv_glu_kernel<F16, 8, 1>, 1);
-    }
-    return VIDI_ERR_DTYPE;
-}
-
 // ---- fp32 GEMM on f32-input MFMA (exact fp32): the positional-embedding MLPs run in fp32 -------
 //   Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]); all fp32, K % 16 == 0.
 //   mfma_f32_32x32x2f32: A lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31].
@@ -352,29 +221,6 @@ int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int 
     if (mode == MODE_KV_CACHE && (((uintptr_t)p.Kc & 15) || ((uintptr_t)p.Vrow & 15) || (p.hd % 8))) return VIDI_ERR_ALIGN;
     if (dtype == VIDI_DT_BF16) return launch_dtype<BF16>(p, batch, mode, repkv, tile_cfg, st);
     if (dtype == VIDI_DT_F16) return launch_dtype<F16>(p, batch, mode, repkv, tile_cfg, st);
-    return VIDI_ERR_DTYPE;
-}
-
-int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
-                       int dtype, hipStream_t st) {
-    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0) return VIDI_ERR_SHAPE;
-    if (((uintptr_t)W & 15) || ((uintptr_t)X & 15)) return VIDI_ERR_ALIGN;
-    auto go = [&](auto kern, int rpw) -> int {
-        const int blocks = max(1, min((N + 4 * rpw - 1) / (4 * rpw), 256 * 8));
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, (const u16*)X, (const u16*)W, (u16*)Y, M, N, K, ldx, ldw, ldy);
-        return (int)hipGetLastError();
-    };
-    if (dtype == VIDI_DT_BF16) {
-        if (M <= 1) return go(gemv_kernel<BF16, 1, 4>, 4);
-        if (M <= 2) return go(gemv_kernel<BF16, 2, 4>, 4);
-        if (M <= 4) return go(gemv_kernel<BF16, 4, 2>, 2);
-        return go(gemv_kernel<BF16, 8, 2>, 2);
-    } else if (dtype == VIDI_DT_F16) {
-        if (M <= 1) return go(gemv_kernel<F16, 1, 4>, 4);
-        if (M <= 2) return go(gemv_kernel<F16, 2, 4>, 4);
-        if (M <= 4) return go(gemv_kernel<F16, 4, 2>, 2);
-        return go(gemv_kernel<F16, 8, 2>, 2);
-    }
     return VIDI_ERR_DTYPE;
 }
 

@@ -112,9 +112,13 @@ int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, fl
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);
+int vidi_attn_cross2_dispatch(const AttnCrossParams& a, const AttnCrossParams& b, int HD, int za, int zb, int dtype, hipStream_t st);
 int vidi_attn_merge_dispatch(const AttnMergeParams& p, int HD, int dtype, hipStream_t st);
 int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b, int HD, int dtype, hipStream_t st);
 int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStream_t st);
+int vidi_attn_text_decode_dispatch(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cs, const void* sn,
+                                   void* O, int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window,
+                                   float scale, float softcap, int dtype, hipStream_t st);
 int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int rows, int nq, int nkv, int HD, int dtype, hipStream_t st);
 int vidi_rope_cache_dispatch(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cs, const void* sn, int B, int Lq,
                              int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, hipStream_t st);

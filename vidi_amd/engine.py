@@ -112,6 +112,10 @@ class VidiEngine:
         self.attn_rm = os.environ.get("VIDI_ATTN_RM", "1") != "0"
         # multimodal stream: each (post-norm + residual, next pre-norm) pair as one launch (VIDI_STREAM_NORM2=0: two launches)
         self.stream_norm2 = os.environ.get("VIDI_STREAM_NORM2", "1") != "0"
+        # decode step: rope + cache append + T2T as one launch (VIDI_DECODE_ATTN=0: rope_cache + attn_text), T2V + T2A partial passes as
+        # one launch (VIDI_CROSS_DUAL=0: one launch per modality) — the A/B arms of tools/ab_decode.py
+        self.decode_attn = os.environ.get("VIDI_DECODE_ATTN", "1") != "0"
+        self.cross_dual = os.environ.get("VIDI_CROSS_DUAL", "1") != "0"
         self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -652,6 +656,36 @@ class VidiEngine:
         hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
         return None
 
+    def _cross_dual(self, q: torch.Tensor, li: int, mm: MMState, out_img: torch.Tensor, out_aud: torch.Tensor, R: int) -> bool:
+        """single-GPU T2V + T2A of one layer: ONE split-KV launch over both key regions (vidi_attn_cross2, the key slices shared out
+        in proportion to the modalities' keys) and ONE merge launch.  False: shape not eligible (the caller runs them separately)."""
+        cfg = self.cfg
+        nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+        G = cfg.num_attention_heads // nkv
+        Rpad = _round_up(R, 32)
+        Z = 256 // max(1, nkv * (Rpad // 32))
+        if mm.n_img <= 0 or mm.n_aud <= 0 or Z < 2:
+            return False
+        sub = {"img": (mm.n_img + 31) // 32, "aud": (mm.n_aud + 31) // 32}
+        za = min(max(1, round(Z * sub["img"] / (sub["img"] + sub["aud"]))), Z - 1)
+        zs = {"img": max(1, min(za, (sub["img"] + 7) // 8)), "aud": max(1, min(Z - za, (sub["aud"] + 7) // 8))}
+        sets = {}
+        for which in ("img", "aud"):
+            key = f"xattn_ws_{which}_{zs[which]}_{Rpad}"
+            if key not in self._ws:
+                with torch.inference_mode(False):
+                    self._ws[key] = hip.attn_cross_workspace(zs[which], nkv, Rpad, hd, self.dev)
+            opart, ml = self._ws[key]
+            sets[which] = dict(mask=mm.img_mask if which == "img" else mm.aud_mask, opart=opart, ml=ml,
+                               key_start=mm.img_start if which == "img" else mm.aud_start,
+                               n_keys=mm.n_img if which == "img" else mm.n_aud, zsplit=zs[which])
+        hip.attn_cross2(q, mm.kc[li], mm.vtc[li], sets["img"], sets["aud"], R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
+                        scale=cfg.query_pre_attn_scalar ** -0.5, softcap=cfg.attn_logit_softcapping)
+        hip.attn_merge2(sets["img"]["opart"], sets["img"]["ml"], out_img, zs["img"], not mm.img_any_valid,
+                        sets["aud"]["opart"], sets["aud"]["ml"], out_aud, zs["aud"], not mm.aud_any_valid,
+                        nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd)
+        return True
+
     def _cross_sharded(self, q: torch.Tensor, li: int, mm: MMState, outs: Dict[str, torch.Tensor], R: int):
         """T2V + T2A of one layer with the keys sharded over ranks.  Per rank: split-KV partials over the local keys ->
         ONE launch folds them into the partial form (numerator, m, l) of both modalities, written straight into a packed send
@@ -757,7 +791,13 @@ class VidiEngine:
             self.proj(hn, L["wqkv"], qkv)
             # RoPE'd q for T2T (raw q stays in qkv for the cross-attention, gemma.py:58), RoPE'd k and v appended to the cache
             window = cfg.sliding_window if (self.mistral or li % 2 == 0) else 0                       # gemma.py:104; Mistral: every layer
-            if dyn:
+            if Lq == 1 and self.decode_attn and hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=hd, Lmax=ts.Lmax, window=window,
+                                                                          pos0=None if dyn else p0):
+                # decode: rope + cache append + T2T in one launch (vidi_attn_text_decode)
+                hip.attn_text_decode(qkv, ts.kc[li], ts.vc[li], ts.kmask, cos, sin, att[:M], B=B, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
+                                     window=window, scale=sc, softcap=cfg.attn_logit_softcapping, pos0=p0,
+                                     pos_dev=ts.pos_dev if dyn else None)
+            elif dyn:
                 hip.rope_cache(qkv, qr, ts.kc[li], ts.vc[li], cos, sin, B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
                                pos_dev=ts.pos_dev)
                 hip.attn_text_dyn(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
@@ -780,9 +820,15 @@ class VidiEngine:
             else:
                 both = has_img and has_aud
                 pend = []
-                if has_img:
+                if both and self.cross_dual and self._cross_dual(qraw, li, mm, att[M: 2 * M], att[2 * M: 3 * M], R=M * G):
+                    k = 3                                               # T2V + T2A partials in one launch, merged by one launch
+                    both = False
+                    has_img_l = has_aud_l = False
+                else:
+                    has_img_l, has_aud_l = has_img, has_aud
+                if has_img_l:
                     pend.append(self._cross(qraw, li, mm, "img", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
-                if has_aud:
+                if has_aud_l:
                     pend.append(self._cross(qraw, li, mm, "aud", att[k * M: (k + 1) * M], R=M * G, defer_merge=both)); k += 1
                 if both:
                     if pend[0] is not None and pend[1] is not None:     # T2V and T2A partials merged by one launch

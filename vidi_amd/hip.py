@@ -47,6 +47,8 @@ SIGNATURES = {
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_merge2": [_c_vp] * 3 + [_c_int] * 2 + [_c_vp] * 3 + [_c_int] * 2 + [_c_int] * 7 + [_c_vp],
     "vidi_attn_merge2_sharded": ([_c_vp] * 2 + [_c_ll] * 2 + [_c_vp] * 3 + [_c_int] * 2) * 2 + [_c_int] * 8 + [_c_vp],
+    "vidi_attn_cross2": [_c_vp] * 3 + ([_c_vp] * 3 + [_c_int] * 3) * 2 + [_c_int] * 7 + [_c_f, _c_f, _c_int, _c_vp],
+    "vidi_attn_text_decode": [_c_vp, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text_dyn": [_c_vp] * 5 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
@@ -129,6 +131,8 @@ def _work(name, a):
         return "gemm", 2.0 * a[6] * a[7] * a[8], "flop"
     if name == "vidi_attn_cross":
         return "attn_cross", float(a[14]) * 2 * a[9] * a[10] * 2, "byte"
+    if name == "vidi_attn_cross2":
+        return "attn_cross", float(a[7] + a[13]) * 2 * a[18] * a[19] * 2, "byte"
     if name == "vidi_norm":
         return "norm", float(a[8]) * a[9] * 2 * 2, "byte"
     if name == "vidi_resid_norm2":
@@ -448,6 +452,17 @@ def attn_cross(q, kc, vtc, mask, opart, ml, *, R, Rpad, G, nkv, HD, ntile64, key
            "vidi_attn_cross")
 
 
+def attn_cross2(q, kc, vtc, set_a, set_b, *, R, Rpad, G, nkv, HD, ntile64, scale, softcap):
+    """T2V and T2A of one layer in one launch; set_x = dict(mask, opart, ml, key_start, n_keys, zsplit)"""
+    lib = load_library()
+    sa, sb = set_a, set_b
+    _check(lib.vidi_attn_cross2(_p(q), _p(kc), _p(vtc),
+                                _p(sa["mask"]), _p(sa["opart"]), _p(sa["ml"]), sa["key_start"], sa["n_keys"], sa["zsplit"],
+                                _p(sb["mask"]), _p(sb["opart"]), _p(sb["ml"]), sb["key_start"], sb["n_keys"], sb["zsplit"],
+                                R, Rpad, G, nkv, HD, q.stride(0), ntile64, float(scale), float(softcap or 0.0), _dt(q), _stream()),
+           "vidi_attn_cross2")
+
+
 def attn_merge(opart, ml, out, *, W, nkv, R, Rpad, G, HD, zero_out=False, out_f32=None, out_ml=None, dtype=None):
     lib = load_library()
     # out_f32 [nkv,Rpad,HD] / out_ml [nkv,Rpad,2]: merged result in partial form (for the cross-GPU merge)
@@ -496,6 +511,26 @@ def attn_text_dyn(q, kc, vc, kmask, out, *, B, Lq, Lmax, nq, nkv, HD, past_len_d
     lib = load_library()
     _check(lib.vidi_attn_text_dyn(_p(q), _p(kc), _p(vc), _p(kmask), _p(out), B, Lq, Lmax, nq, nkv, HD, _p(past_len_dev), window,
                                   float(scale), float(softcap or 0.0), _dt(q), _stream()), "vidi_attn_text_dyn")
+
+
+def attn_text_decode_fits(*, nq, nkv, HD, Lmax, window, pos0=None) -> bool:
+    """whether vidi_attn_text_decode's LDS plan (query rows, scores of the visible keys, PV partials) fits its 64 KB"""
+    G = nq // nkv
+    nvis = Lmax if pos0 is None else pos0 + 1
+    if window and window > 0:
+        nvis = min(nvis, window + 1)
+    lcap = (nvis + 3) & ~3
+    return HD in (64, 128, 256) and G <= 8 and (G * HD + 8 + G * lcap + (256 // (HD // 8)) * G * HD) * 4 <= 64 * 1024
+
+
+def attn_text_decode(qkv, kc, vc, kmask, cos, sin, out, *, B, Lmax, nq, nkv, HD, window, scale, softcap, pos0=0, pos_dev=None):
+    """Lq = 1: rope(q), rope(k), KV-cache append and the T2T attention in one launch (rope_cache + attn_text[_dyn])"""
+    lib = load_library()
+    if pos_dev is not None and (pos_dev.dtype != torch.int32 or not pos_dev.is_cuda):
+        raise VidiHipError("attn_text_decode: pos_dev must be a CUDA int32 tensor")
+    _check(lib.vidi_attn_text_decode(_p(qkv), qkv.stride(0), _p(kc), _p(vc), _p(kmask), _p(cos), _p(sin), _p(out), B, Lmax, nq, nkv, HD,
+                                     int(pos0), _p(pos_dev), int(window), float(scale), float(softcap or 0.0), _dt(qkv), _stream()),
+           "vidi_attn_text_decode")
 
 
 def rope_cache(qkv, qr, kc, vc, cos, sin, *, B, Lq, Lmax, nq, nkv, HD, pos0=0, pos_dev=None):
