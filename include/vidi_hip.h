@@ -118,6 +118,16 @@ int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ld
  * Same values as vidi_gemv + vidi_geglu_unpack / vidi_glu_unpack, one launch. */
 int vidi_gemv_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype,
                   void* stream);
+/* Decode: vidi_resid_norm2 FUSED INTO the skinny projection that consumes its second output (gemma.py:236-237 + :118 -> Gemma2MLP
+ * gate/up, and :120-121 + the next layer's :162 -> q/k/v):  s = T(T(A+B)+C) (B, C optional);  Y1 = T(Res + T(gemma(s; W1)));
+ * x = T(gemma(Y1; W2));  Y = x W^T  (vidi_gemv_norm2)  or  Y = act(x Wg^T) * (x Wu^T) on the interleaved gate/up weight
+ * (vidi_gemv_glu_norm2).  Every block derives x itself under the HBM latency of its first weight rows; block 0 writes Y1.
+ * M <= 4 rows, K <= 4096, Y1 MUST NOT alias Res (VIDI_ERR_ARG).  Element arithmetic and rounding points are vidi_resid_norm2's; the
+ * sums of squares are reduced in a different order, so Y1 / x may differ from it in the last bit of the dtype. */
+int vidi_gemv_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, long long ld,
+                    float eps, const void* W, void* Y, int M, int N, int K, int ldw, int ldy, int dtype, void* stream);
+int vidi_gemv_glu_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, long long ld,
+                        float eps, const void* Wgu, void* Y, int M, int I, int K, int ldw, int ldy, int act, int dtype, void* stream);
 
 /* fp32 projection on exact-fp32 MFMA: LearnablePosEmbd's fp32 MLP (mm_vision/pos.py:36-39,55;
  * model/mm_layer/mlp.py:31-40). act: VIDI_ACT_NONE / VIDI_ACT_GELU_ERF. */

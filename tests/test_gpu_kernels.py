@@ -823,3 +823,35 @@ def test_softcap_argmax_multi_block(hip, dt, B, V, pad):
         want = torch.tensor([min((7 * b + 3) % V, V // 2, V - 1 - b) for b in range(B)])
         assert torch.equal(idx.cpu(), want), (idx.cpu(), want)
         assert torch.equal(idx.cpu(), torch.argmax(ld.float().cpu(), dim=-1))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,K,N,nsrc,glu", [(1, 3584, 8192, 1, False), (1, 3584, 14336, 3, True), (3, 3584, 512, 2, False), (4, 256, 96, 3, True),
+                                            (2, 4096, 1000, 1, False), (1, 1536, 64, 2, True)])
+def test_gemv_norm2_equals_resid_norm2_then_gemv(hip, dt, M, K, N, nsrc, glu):
+    """the decode fusion (norm pair inside the projection) against vidi_resid_norm2 followed by vidi_gemv / vidi_gemv_glu: the residual
+    output within one ulp of the dtype (the sums of squares are reduced in a different order; same element arithmetic), the projection
+    within the GEMV tolerance of the two-launch result"""
+    a = seeded((M, K), 110, dtype=dt).cuda(); b = seeded((M, K), 111, dtype=dt).cuda(); c = seeded((M, K), 112, dtype=dt).cuda()
+    res = seeded((M, K), 113, dtype=dt).cuda()
+    w1 = seeded((K,), 114, 0.1, dtype=dt).cuda(); w2 = seeded((K,), 115, 0.1, dtype=dt).cuda()
+    bb, cc = (b if nsrc >= 2 else None), (c if nsrc >= 3 else None)
+    rows = 2 * N if glu else N
+    w = seeded((rows, K), 116, 0.05, dtype=dt).cuda()
+    y1_ref = torch.empty_like(a); x_ref = torch.empty_like(a)
+    hip.resid_norm2(a, bb, cc, res, w1, w2, y1_ref, x_ref, eps=1e-6)
+    out_ref = torch.zeros((M, N), dtype=dt, device="cuda")
+    if glu:
+        hip.gemv_glu(x_ref, w, out_ref, hip.ACT_GELU_TANH)
+    else:
+        hip.gemv(x_ref, w, out_ref)
+    y1 = torch.full_like(a, float("nan")); out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    if glu:
+        hip.gemv_glu_norm2(a, bb, cc, res, w1, w2, y1, w, out, eps=1e-6, act=hip.ACT_GELU_TANH)
+    else:
+        hip.gemv_norm2(a, bb, cc, res, w1, w2, y1, w, out, eps=1e-6)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    report("gemv_norm2: residual stream", y1, y1_ref.float(), ulp * y1_ref.float().abs().max().item(), ulp)
+    report("gemv_norm2: projection", out, out_ref.float(), *tol(dt, out_ref.float().std().item(), k=2 if glu else 1))
+    with pytest.raises(hip.VidiHipError):                                  # in-place residual is refused (blocks race on it)
+        hip.gemv_norm2(a, bb, cc, res, w1, w2, res, w[:N], out, eps=1e-6)

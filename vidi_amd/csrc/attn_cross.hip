@@ -18,6 +18,10 @@
 //   * swapped MFMAs (S^T = K Q^T, O^T = Vt P^T): per-lane softmax statistics, P stays in registers.
 #include "kernels.h"
 
+#ifndef VIDI_XATTN_INTERLEAVE
+#define VIDI_XATTN_INTERLEAVE 1
+#endif
+
 
 // z / zsplit: this block's key slice and the number of slices of ITS modality (the dual launch below runs the slices of two
 // modalities in one grid)
@@ -65,8 +69,15 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
     const int nsub = (p.n_keys + 31) / 32;
     const int wtot = zsplit * 4;
     const int wg = z * 4 + wave;
+    // key slices INTERLEAVED over the waves (wave wg sweeps sub-tiles wg, wg + wtot, ...): at any moment the waves of a kv head read
+    // one contiguous window of its K and of its V cache (wtot x 16 KB each) that slides through memory, instead of wtot separate
+    // streams half a megabyte apart (VIDI_XATTN_INTERLEAVE=0: a contiguous range per wave, the round-1 form)
+#if VIDI_XATTN_INTERLEAVE
+    const int st_begin = min(wg, nsub), st_end = nsub, st_step = wtot;
+#else
     const int per = (nsub + wtot - 1) / wtot;
-    const int st_begin = min(wg * per, nsub), st_end = min(st_begin + per, nsub);
+    const int st_begin = min(wg * per, nsub), st_end = min(st_begin + per, nsub), st_step = 1;
+#endif
 
     const u16* kc_head = p.Kc + (size_t)kvh * p.ntile64 * 64 * HD;
     const u16* vt_head = p.Vtc + (size_t)kvh * p.ntile64 * HD * 64;
@@ -107,8 +118,8 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
         issue_k(st_begin);
         issue_v(st_begin);
     }
-    for (int st = st_begin; st < st_end; ++st) {
-        const bool has_next = (st + 1 < st_end);
+    for (int st = st_begin; st < st_end; st += st_step) {
+        const bool has_next = (st + st_step < st_end);
         // K(st) landed?  (V(st) may still be in flight)
         wait_vmcnt<VLD>();
         // ---- S^T = K Q^T : Q fragments are register-resident; K fragments stream from LDS in
@@ -116,6 +127,9 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#ifdef VIDI_XATTN_DIAG_NOCOMPUTE                          // lab builds only (wrong results): the DMA / wait skeleton without MFMAs and softmax
+        if (p.R < 0)
+#endif
         {
             u32x4 kf[2][4];
 #pragma unroll
@@ -136,10 +150,15 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
         }
         // all K-fragment reads are consumed by the MFMAs above -> the K ring slot is free
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (has_next) issue_k(st + 1);
+        if (has_next) issue_k(st + st_step);
 
         // ---- logits: scale, softcap, mask; online softmax in base 2 --------------------------
         const int kb_local = st * 32;
+        u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
+#ifdef VIDI_XATTN_DIAG_NOCOMPUTE
+        if (p.R < 0)
+#endif
+        {
         float mx = -INFINITY;
         if (use_cap) {
 #pragma unroll
@@ -182,16 +201,21 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
             psum += pv[r];
         }
         l_run = l_run * alpha + psum;
-        const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
+        pf0 = pack8<T>(pv);
+        pf1 = pack8<T>(pv + 8);
         if (!__all(alpha == 1.0f)) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
         }
+        }
         // V(st) landed?  (K(st+1) may be in flight)
         if (has_next) wait_vmcnt<KLD>(); else wait_vmcnt<0>();
         // ---- O^T += Vt P^T : 2 d-tiles (4 fragments) per batch, reads one batch ahead ----------
+#ifdef VIDI_XATTN_DIAG_NOCOMPUTE
+        if (p.R < 0)
+#endif
         {
             u32x4 vf[2][4];
             auto read_v = [&](int buf, int dt0) {
@@ -217,7 +241,7 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (has_next) issue_v(st + 1);
+        if (has_next) issue_v(st + st_step);
     }
 
     // ---- merge the block's 4 waves in LDS (their private K/V rings are free now) and emit ONE partial ---------
@@ -280,17 +304,18 @@ __global__ __launch_bounds__(256) void attn_cross2_kernel(AttnCrossParams a, Att
 // Combine W partials per (row, kv head): O = sum_w 2^(m_w-m) O_w / sum_w 2^(m_w-m) l_w.
 // Optionally emits the merged result in PARTIAL form (numerator, m, l) for a further cross-GPU merge.
 
+// One (row r, kv head) merged by threads d = 0 .. HD-1 of the block; threads with d >= HD (a 256-thread caller at HD = 128) only take
+// part in the barriers.
 template <typename T, int HD>
-__device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
-    const int r = blockIdx.x, kvh = blockIdx.y, d = threadIdx.x;
+__device__ __forceinline__ void attn_merge_row(const AttnMergeParams& p, const int r, const int kvh, const int d, float* s_m, float* s_l) {
     // the W (m, l) pairs of this (row, kv head) are fetched by W threads at once and shared through LDS; the weights
     // 2^(m_w - m) are then uniform values and the numerator loads of all partials are independent of each other
-    __shared__ float s_m[256], s_l[256];
+    const bool act = d < HD;
     float m = -INFINITY;
     for (int w0 = 0; w0 < p.W; w0 += 256) {
         __syncthreads();
         const int nw = min(256, p.W - w0);
-        for (int w = d; w < nw; w += HD) {
+        for (int w = d; act && w < nw; w += HD) {
             const size_t base = (size_t)(w0 + w) * p.wsML + ((size_t)kvh * p.Rpad + r) * 2;
             s_m[w] = p.ML[base];
             s_l[w] = p.ML[base + 1];
@@ -304,7 +329,7 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
             const int nw = min(256, p.W - w0);
             if (p.W > 256) {                                            // re-stage this window (single window: still resident)
                 __syncthreads();
-                for (int w = d; w < nw; w += HD) {
+                for (int w = d; act && w < nw; w += HD) {
                     const size_t base = (size_t)(w0 + w) * p.wsML + ((size_t)kvh * p.Rpad + r) * 2;
                     s_m[w] = p.ML[base];
                     s_l[w] = p.ML[base + 1];
@@ -316,11 +341,12 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
                 const float mw = s_m[w];
                 const float sc = (mw == -INFINITY) ? 0.f : fast_exp2(mw - m);
                 den += sc * s_l[w];
-                const float v = p.Opart[(size_t)(w0 + w) * p.wsO + ((size_t)kvh * p.Rpad + r) * HD + d];
+                const float v = p.Opart[(size_t)(w0 + w) * p.wsO + ((size_t)kvh * p.Rpad + r) * HD + (act ? d : 0)];
                 num += (mw == -INFINITY) ? 0.f : sc * v;                // a skipped partial may hold stale (even non-finite) data
             }
         }
     }
+    if (!act) return;
     const int tq = r / p.G, g = r % p.G;
     const size_t oidx = (size_t)tq * p.ldo + (kvh * p.G + g) * HD + d;
     float out = (den > 0.f && !p.zero_out) ? num / den : 0.f;
@@ -332,6 +358,12 @@ __device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
         p.OutML[pbase * 2] = m;
         p.OutML[pbase * 2 + 1] = den;
     }
+}
+
+template <typename T, int HD>
+__device__ __forceinline__ void attn_merge_body(const AttnMergeParams& p) {
+    __shared__ float s_m[256], s_l[256];
+    attn_merge_row<T, HD>(p, blockIdx.x, blockIdx.y, threadIdx.x, s_m, s_l);
 }
 
 template <typename T, int HD>

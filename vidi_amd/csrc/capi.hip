@@ -175,6 +175,20 @@ int vidi_gemv_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, 
     return vidi_gemv_glu_dispatch(X, Wgu, Y, M, I, K, ldx, ldw, ldy, act, dtype, (hipStream_t)stream);
 }
 
+int vidi_gemv_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, long long ld,
+                    float eps, const void* W, void* Y, int M, int N, int K, int ldw, int ldy, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!A || !Res || !W1 || !W2 || !Y1 || !W || !Y) return VIDI_ERR_ARG;
+    return vidi_gemv_norm2_dispatch(A, B, C, Res, W1, W2, Y1, ld, eps, W, Y, M, N, K, ldw, ldy, -1, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemv_glu_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, long long ld,
+                        float eps, const void* Wgu, void* Y, int M, int I, int K, int ldw, int ldy, int act, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!A || !Res || !W1 || !W2 || !Y1 || !Wgu || !Y || act < 0) return VIDI_ERR_ARG;
+    return vidi_gemv_norm2_dispatch(A, B, C, Res, W1, W2, Y1, ld, eps, Wgu, Y, M, I, K, ldw, ldy, act, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
                   int ldx, int ldw, int ldy, int act, void* stream) {
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error

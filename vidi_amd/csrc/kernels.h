@@ -107,6 +107,9 @@ int vidi_resid_norm2_dispatch(const void* A, const void* B, const void* C, const
                               void* Y2, int rows, int H, long long ld, float eps, int dtype, hipStream_t st);
 int vidi_gemm_dispatch(const GemmParams& p, int batch, int mode, int repkv, int tile_cfg, int dtype, hipStream_t st);
 int vidi_gemv_glu_dispatch(const void* X, const void* W, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype, hipStream_t st);
+int vidi_gemv_norm2_dispatch(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1,
+                             long long ld, float eps, const void* W, void* Y, int M, int N, int K, int ldw, int ldy, int glu_act,
+                             int dtype, hipStream_t st);
 int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int dtype, hipStream_t st);
 int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t st);
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);

@@ -116,6 +116,12 @@ class VidiEngine:
         # one launch (VIDI_CROSS_DUAL=0: one launch per modality) — the A/B arms of tools/ab_decode.py
         self.decode_attn = os.environ.get("VIDI_DECODE_ATTN", "1") != "0"
         self.cross_dual = os.environ.get("VIDI_CROSS_DUAL", "1") != "0"
+        # decode step: the Gemma2 norm pairs folded into the gate/up and the next layer's q/k/v projections (VIDI_DECODE_NORM_GEMV=0:
+        # vidi_resid_norm2 + vidi_gemv[_glu] as separate launches)
+        self.decode_norm_gemv = os.environ.get("VIDI_DECODE_NORM_GEMV", "1") != "0"
+        # multimodal stream: o_proj over repeat_kv(V) as one GEMM over V with the G column blocks of o_proj summed at load time
+        # (VIDI_FOLD_REPKV=0: the repeat done by the GEMM's operand read, K twice as long)
+        self.fold_repkv = os.environ.get("VIDI_FOLD_REPKV", "1") != "0"
         self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -160,6 +166,11 @@ class VidiEngine:
             nqd = cfg.num_attention_heads * cfg.head_dim
             L["wkv"] = L["wqkv"][nqd:]                                        # [Wk; Wv] view
             L["wo"] = g(p + "self_attn.o_proj.weight")
+            if self.fold_repkv and i + 1 < cfg.num_hidden_layers:
+                # multimodal stream: o_proj(repeat_kv(V)) (gemma.py:196-197) == V (sum_g Wo[:, head kvh*G+g])^T — the G column blocks of
+                # o_proj that repeat_kv feeds with the same values, summed in fp32 and rounded once: half the K of that GEMM
+                Gq = cfg.num_attention_heads // cfg.num_key_value_heads
+                L["wo_kv"] = L["wo"].view(H, cfg.num_key_value_heads, Gq, cfg.head_dim).float().sum(2).reshape(H, -1).to(dt).contiguous()
             gate, up = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
             # 32-row interleave [gate 0..31 | up 0..31 | gate 32..63 | ...] for the fused GeGLU epilogue
             L["wgu"] = torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous()
@@ -557,12 +568,18 @@ class VidiEngine:
             if li == Lr - 1:
                 break                                                                                # dead update on the last layer
             if self.mistral:
-                hip.gemm(vrow, L["wo"], None, X, repkv=(hd, G), K=G * kvd, residual=X)               # mistral.py:219-221: x += o_proj(repeat_kv(V))
+                if self.fold_repkv:
+                    hip.gemm(vrow, L["wo_kv"], None, X, residual=X)                                  # mistral.py:219-221: x += o_proj(repeat_kv(V))
+                else:
+                    hip.gemm(vrow, L["wo"], None, X, repkv=(hd, G), K=G * kvd, residual=X)
                 hip.norm(hip.NORM_MM, X, L["ln_post_attn"], eps=eps, out=hbuf)                       # :131-134 feed_foward
                 hip.gemm_glu(hbuf, L["wgu"], gt, act=hip.ACT_SILU)
                 hip.gemm(gt, L["wdown"], None, X, residual=X)                                        # :135
                 continue
-            hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)                               # :196-197 o_proj(repeat_kv(V))
+            if self.fold_repkv:
+                hip.gemm(vrow, L["wo_kv"], None, u)                                                  # :196-197 o_proj(repeat_kv(V)), K folded
+            else:
+                hip.gemm(vrow, L["wo"], None, u, repkv=(hd, G), K=G * kvd)
             if fused:
                 # residual + post-norm and the following pre-norm in ONE pass over the rows (vidi_resid_norm2, the phase-by-phase
                 # form for many rows: the arithmetic and rounding points of NORM_GEMMA_ADD followed by NORM_GEMMA, bit-identical; 4
@@ -783,12 +800,19 @@ class VidiEngine:
         sc = cfg.query_pre_attn_scalar ** -0.5
         tmp = self._buf("t_tmp", (M, H)) if self.mistral else None
         fused = not self.mistral       # Gemma2 wiring: add3 + post-norm/residual + next pre-norm run as one launch (vidi_resid_norm2)
+        # decode (few rows): that launch is folded into the skinny projection that consumes it (vidi_gemv[_glu]_norm2); the residual
+        # stream then ping-pongs between two buffers (the fused launch reads the old one in every block while block 0 writes the new one)
+        fuse_proj = fused and self.decode_norm_gemv and hip.gemv_norm2_fits(M, H)
+        other = self._buf("t_hid2", (M, H)) if fuse_proj else None
+        qkv_ready = False
         nL = len(self.layers)
         final_out = None
         for li, L in enumerate(self.layers):
-            if not (fused and li > 0):                                                               # fused: produced by the previous layer's FFN side
-                hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                       # gemma.py:162 / mistral.py:187
-            self.proj(hn, L["wqkv"], qkv)
+            if not qkv_ready:
+                if not (fused and li > 0):                                                           # fused: produced by the previous layer's FFN side
+                    hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                   # gemma.py:162 / mistral.py:187
+                self.proj(hn, L["wqkv"], qkv)
+            qkv_ready = False
             # RoPE'd q for T2T (raw q stays in qkv for the cross-attention, gemma.py:58), RoPE'd k and v appended to the cache
             window = cfg.sliding_window if (self.mistral or li % 2 == 0) else 0                       # gemma.py:104; Mistral: every layer
             if Lq == 1 and self.decode_attn and hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=hd, Lmax=ts.Lmax, window=window,
@@ -858,15 +882,26 @@ class VidiEngine:
                     hip.gemm(gt, L["wdown"], None, hidden, residual=hidden)
                 continue
             # text + image + audio (:236), residual + post_attention_layernorm (:237), pre_feedforward_layernorm (:118)
-            hip.resid_norm2(oall[:M], oall[M: 2 * M] if nstream >= 2 else None, oall[2 * M: 3 * M] if nstream == 3 else None,
-                            hidden, L["ln_post_attn"], L["ln_pre_ffn"], hidden, hn, eps=eps)
-            if M <= 8:
-                hip.gemv_glu(hn, L["wgu"], gt, hip.ACT_GELU_TANH)
+            o_b = oall[M: 2 * M] if nstream >= 2 else None
+            o_c = oall[2 * M: 3 * M] if nstream == 3 else None
+            if fuse_proj:
+                hip.gemv_glu_norm2(oall[:M], o_b, o_c, hidden, L["ln_post_attn"], L["ln_pre_ffn"], other, L["wgu"], gt, eps=eps,
+                                   act=hip.ACT_GELU_TANH)
+                hidden, other = other, hidden
             else:
-                hip.gemm_geglu(hn, L["wgu"], gt)
+                hip.resid_norm2(oall[:M], o_b, o_c, hidden, L["ln_post_attn"], L["ln_pre_ffn"], hidden, hn, eps=eps)
+                if M <= 8:
+                    hip.gemv_glu(hn, L["wgu"], gt, hip.ACT_GELU_TANH)
+                else:
+                    hip.gemm_geglu(hn, L["wgu"], gt)
             self.proj(gt, L["wdown"], dn)
             # residual + post_feedforward_layernorm (:120-121), then the NEXT layer's input_layernorm (:162) or the final norm (:411)
-            if li + 1 < nL:
+            if li + 1 < nL and fuse_proj:
+                nxt = self.layers[li + 1]
+                hip.gemv_norm2(dn, None, None, hidden, L["ln_post_ffn"], nxt["ln_in"], other, nxt["wqkv"], qkv, eps=eps)   # + next :57-60
+                hidden, other = other, hidden
+                qkv_ready = True
+            elif li + 1 < nL:
                 hip.resid_norm2(dn, None, None, hidden, L["ln_post_ffn"], self.layers[li + 1]["ln_in"], hidden, hn, eps=eps)
             else:
                 final_out = torch.empty_like(hidden)

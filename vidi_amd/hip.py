@@ -39,6 +39,8 @@ SIGNATURES = {
     "vidi_gemm_qkv_vt_ln": [_c_vp] * 7 + [_c_int] * 13 + [_c_vp],
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
+    "vidi_gemv_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
+    "vidi_gemv_glu_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
     "vidi_attn_self": [_c_vp] * 3 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
     "vidi_attn_self_rm": [_c_vp] * 2 + [_c_int] * 5 + [_c_ll] * 4 + [_c_int, _c_f, _c_int, _c_vp],
@@ -141,6 +143,10 @@ def _work(name, a):
         return "gemv", float(a[4]) * a[5] * 2, "byte"
     if name == "vidi_gemv_glu":
         return "gemv", 2.0 * a[4] * a[5] * 2, "byte"
+    if name == "vidi_gemv_norm2":
+        return "gemv", float(a[12]) * a[13] * 2, "byte"
+    if name == "vidi_gemv_glu_norm2":
+        return "gemv", 2.0 * a[12] * a[13] * 2, "byte"
     if name == "vidi_gemm_f32":
         return "gemm_f32", 2.0 * a[4] * a[5] * a[6], "flop"
     if name == "vidi_resize_h_u8":                      # read every source byte once, write the uint8 intermediate once
@@ -376,6 +382,36 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     _check(lib.vidi_gemv(_p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _dt(x), _stream()), "vidi_gemv")
+    return out
+
+
+def gemv_norm2_fits(M: int, K: int) -> bool:
+    return M <= 4 and K <= 4096 and K % 8 == 0
+
+
+def gemv_norm2(a, b, c, res, w1, w2, y1, w, out, *, eps: float):
+    """resid_norm2(a, b, c, res, w1, w2) -> (y1, x) and out = x @ w.T in one launch (decode; y1 must not alias res)"""
+    lib = load_library()
+    M, K = a.shape
+    N = w.shape[0]
+    for t in (a, b, c, res, y1):
+        if t is not None and (t.stride(0) != a.stride(0) or t.stride(1) != 1):
+            raise VidiHipError("gemv_norm2: all row tensors must share the row stride")
+    _check(lib.vidi_gemv_norm2(_p(a), _p(b), _p(c), _p(res), _p(w1), _p(w2), _p(y1), a.stride(0), float(eps), _p(w), _p(out), M, N, K,
+                               w.stride(0), out.stride(0), _dt(a), _stream()), "vidi_gemv_norm2")
+    return out
+
+
+def gemv_glu_norm2(a, b, c, res, w1, w2, y1, wgu, out, *, eps: float, act: int = ACT_GELU_TANH):
+    """resid_norm2(...) -> (y1, x) and out = act(x Wg^T) * (x Wu^T) on the interleaved gate/up weight in one launch"""
+    lib = load_library()
+    M, K = a.shape
+    I = wgu.shape[0] // 2
+    for t in (a, b, c, res, y1):
+        if t is not None and (t.stride(0) != a.stride(0) or t.stride(1) != 1):
+            raise VidiHipError("gemv_glu_norm2: all row tensors must share the row stride")
+    _check(lib.vidi_gemv_glu_norm2(_p(a), _p(b), _p(c), _p(res), _p(w1), _p(w2), _p(y1), a.stride(0), float(eps), _p(wgu), _p(out), M, I, K,
+                                   wgu.stride(0), out.stride(0), act, _dt(a), _stream()), "vidi_gemv_glu_norm2")
     return out
 
 
