@@ -107,8 +107,9 @@ def cross_ab(libs):
             outs[path] = torch.cat([oa, ob]).float()
             runs[path] = [run, 0.0]
         rounds, reps = 5, 4
+        names = list(runs)
         for _ in range(rounds):
-            for path in libs:
+            for path in names:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
@@ -117,7 +118,7 @@ def cross_ab(libs):
                 e1.record(); torch.cuda.synchronize()
                 runs[path][1] += e0.elapsed_time(e1) / (reps * len(caches))
         nbytes = (Nv + Na) * 2 * nkv * HD * 2
-        for path in libs:
+        for path in names:
             us = runs[path][1] / rounds * 1e3
             print(json.dumps({"shape": f"cross2 Lq={Lq}", "za": za, "zb": zb, "lib": os.path.basename(path), "us": round(us, 1),
                               "TB/s": round(nbytes / us / 1e6, 3),
@@ -160,8 +161,7 @@ def e2e(tokens, rounds, only_default=False):
         return e0.elapsed_time(e1) / n, toks
 
     arms = [("two-launch T2T, cross per modality, norm pairs as launches", False, False, False), ("fused T2T", True, False, False),
-            ("dual cross", False, True, False), ("norm pairs inside the projections", False, False, True),
-            ("all three", True, True, True)]
+            ("dual cross", False, True, False), ("norm pairs inside the projections", False, False, True), ("all three", True, True, True)]
     if only_default:                                     # the engine's own switches (env), e.g. under rocprofv3
         arms = [("engine defaults", eng.decode_attn, eng.cross_dual, eng.decode_norm_gemv)]
     tot = {a[0]: 0.0 for a in arms}

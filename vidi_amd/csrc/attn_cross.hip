@@ -21,6 +21,9 @@
 #ifndef VIDI_XATTN_INTERLEAVE
 #define VIDI_XATTN_INTERLEAVE 1
 #endif
+#ifndef VIDI_XATTN_NT
+#define VIDI_XATTN_NT 1
+#endif
 
 
 // z / zsplit: this block's key slice and the number of slices of ITS modality (the dual launch below runs the slices of two
@@ -82,24 +85,42 @@ __device__ __forceinline__ void attn_cross_body(const AttnCrossParams& p, const 
     const u16* kc_head = p.Kc + (size_t)kvh * p.ntile64 * 64 * HD;
     const u16* vt_head = p.Vtc + (size_t)kvh * p.ntile64 * HD * 64;
 
+    // streamed once: when a single row tile sweeps the keys (decode, short prompts) every K/V byte is read by exactly one CU, and the
+    // non-temporal policy on the DMA shortens issued -> landed (MI355X_MICROARCH.md "nt-weights"); with several row tiles the later
+    // tiles re-read the slice from L2 and the default policy is kept
+    const bool nt = VIDI_XATTN_NT && gridDim.y == 1;
     auto issue_k = [&](int st) {
         const int kb = p.key_start + st * 32;
         const u16* src = kc_head + (size_t)kb * HD;                 // 32 consecutive keys are contiguous
+        if (nt) {
 #pragma unroll
-        for (int j = 0; j < KLD; ++j) {
-            const int pidx = j * 64 + lane, row = pidx / CPR, cl = pidx % CPR;
-            const int cg = cl ^ (row & 15);
-            glds16(src + row * HD + cg * 8, sK + j * 1024);
+            for (int j = 0; j < KLD; ++j) {
+                const int pidx = j * 64 + lane, row = pidx / CPR, cl = pidx % CPR;
+                glds16<2>(src + row * HD + (cl ^ (row & 15)) * 8, sK + j * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KLD; ++j) {
+                const int pidx = j * 64 + lane, row = pidx / CPR, cl = pidx % CPR;
+                glds16(src + row * HD + (cl ^ (row & 15)) * 8, sK + j * 1024);
+            }
         }
     };
     auto issue_v = [&](int st) {
         const int kb = p.key_start + st * 32;
         const u16* src = vt_head + (size_t)(kb >> 5) * HD * 32;          // [HD][32 positions]: 16 KB of linear 64-byte rows
+        if (nt) {
 #pragma unroll
-        for (int j = 0; j < VLD; ++j) {
-            const int pidx = j * 64 + lane, d = pidx >> 2, cl = pidx & 3;
-            const int cg = cl ^ ((d >> 2) & 3);
-            glds16(src + d * 32 + cg * 8, sV + j * 1024);
+            for (int j = 0; j < VLD; ++j) {
+                const int pidx = j * 64 + lane, d = pidx >> 2, cl = pidx & 3;
+                glds16<2>(src + d * 32 + (cl ^ ((d >> 2) & 3)) * 8, sV + j * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VLD; ++j) {
+                const int pidx = j * 64 + lane, d = pidx >> 2, cl = pidx & 3;
+                glds16(src + d * 32 + (cl ^ ((d >> 2) & 3)) * 8, sV + j * 1024);
+            }
         }
     };
 
