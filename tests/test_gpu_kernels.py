@@ -803,7 +803,7 @@ def test_attn_cross2_equals_two_launches(hip, dt, HD, nkv, G, Lq, Na, Nb, za, zb
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,V,pad", [(1, 256000, 0), (3, 1000, 0), (2, 1003, 5), (4, 40, 0)])
+@pytest.mark.parametrize("B,V,pad", [(1, 256000, 0), (3, 1000, 0), (2, 1003, 5), (4, 40, 0), (2, 1000, 3), (600, 512, 0)])
 def test_softcap_argmax_multi_block(hip, dt, B, V, pad):
     """rows spread over many blocks: softcap values as the elementwise chain, FIRST maximal index (ties planted in different
     blocks' slices), repeated calls (the per-row scratch cleans itself), rows that are not 16-byte aligned"""
@@ -812,7 +812,7 @@ def test_softcap_argmax_multi_block(hip, dt, B, V, pad):
         lg = seeded((B, V + pad), 100 + rep, 20.0, dtype=dt)[:, : V]
         big = lg.float().abs().max().item() * 2 + 1.0
         for b in range(B):                                                 # the same maximum at three places; the first one must win
-            for i in sorted(set([(7 * b + 3) % V, V // 2, V - 1 - b])):
+            for i in sorted(set([(7 * b + 3) % V, V // 2, (V - 1 - b) % V])):
                 lg[b, i] = big
         ld = lg.cuda() if pad == 0 else torch.empty((B, V + pad), dtype=dt, device="cuda")[:, : V].copy_(lg)
         idx = torch.full((B,), -1, dtype=torch.int64, device="cuda")
@@ -820,7 +820,7 @@ def test_softcap_argmax_multi_block(hip, dt, B, V, pad):
         x = lg.float() / cap
         ref = (torch.tanh(x.to(dt).float()).to(dt).float() * cap).to(dt)
         report("softcap (multi-block)", ld, ref.float(), *tol(dt, 10.0))
-        want = torch.tensor([min((7 * b + 3) % V, V // 2, V - 1 - b) for b in range(B)])
+        want = torch.tensor([min((7 * b + 3) % V, V // 2, (V - 1 - b) % V) for b in range(B)])
         assert torch.equal(idx.cpu(), want), (idx.cpu(), want)
         assert torch.equal(idx.cpu(), torch.argmax(ld.float().cpu(), dim=-1))
 

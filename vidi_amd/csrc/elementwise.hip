@@ -380,11 +380,12 @@ static int ew_dispatch_T(int op, void** a, const long long* i, const float* f, h
         }
         case EW_SOFTCAP_ARGMAX: {
             const int B = (int)i[0], V = (int)i[1];
-            if (B > VIDI_AM_ROWS) return VIDI_ERR_SHAPE;
             const int vec = (V % 8 == 0) && (i[2] % 8 == 0) && (((uintptr_t)a[0] & 15) == 0);
             const int items = vec ? V / 8 : V;
             const int nblk = max(1, min(128, (items + 255) / 256));
-            hipLaunchKernelGGL(softcap_argmax_kernel<T>, dim3(nblk, B), dim3(256), 0, st, (u16*)a[0], (long long*)a[1], V, i[2], f[0], vec);
+            for (int b0 = 0; b0 < B; b0 += VIDI_AM_ROWS)      // more rows than scratch slots: stream-ordered batches reuse the slots
+                hipLaunchKernelGGL(softcap_argmax_kernel<T>, dim3(nblk, min(VIDI_AM_ROWS, B - b0)), dim3(256), 0, st,
+                                   (u16*)a[0] + (size_t)b0 * i[2], (long long*)a[1] + b0, V, i[2], f[0], vec);
             break;
         }
         case EW_MEL_T: {
