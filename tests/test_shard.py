@@ -121,3 +121,28 @@ def test_generate_under_set_dist_shards_the_video_and_reproduces_single_rank(wor
         assert toks == ref, (rank, toks, ref)
         f0, f1 = S.shard(frames, world, rank)
         assert sh == dict(kind="img", local=f1 - f0, off=f0, total=frames)          # what the product handed this rank's engine
+
+
+def test_split_key_slices_of_the_dual_cross_attention_launch():
+    """host logic of engine._cross_dual: slices in proportion to the keys, never empty, never more than the launch has, short modalities
+    capped at one slice per 8 sub-tiles"""
+    from vidi_amd.shard import split_key_slices
+    assert split_key_slices(32, 2813, 1125) == (23, 9)                 # the 60-min config at decode: 90 000 / 36 000 keys
+    assert split_key_slices(10, 2813, 1125) == (7, 3)                  # ... at the 39-token prompt (3 row tiles)
+    for slices in (2, 3, 10, 32, 64):
+        for a in (1, 7, 8, 9, 100, 2813, 30000):
+            for b in (1, 5, 64, 1125, 12000):
+                za, zb = split_key_slices(slices, a, b)
+                assert za >= 1 and zb >= 1 and za + zb <= slices
+                assert za <= max(1, (a + 7) // 8) and zb <= max(1, (b + 7) // 8)
+                if a >= 8 * slices and b >= 8 * slices:                # both long: every slice is used, and the longer slice of
+                    assert za + zb == slices                           # the two modalities is within one slice of a perfect split
+                    per = lambda n, z: -(-n // (4 * z))
+                    ideal = -(-(a + b) // (4 * slices))
+                    assert max(per(a, za), per(b, zb)) <= ideal * (1 + 1.0 / min(za, zb)) + 1
+    import pytest
+    with pytest.raises(ValueError):
+        split_key_slices(1, 10, 10)
+    with pytest.raises(ValueError):
+        split_key_slices(8, 0, 10)
+

@@ -683,9 +683,8 @@ class VidiEngine:
         Z = 256 // max(1, nkv * (Rpad // 32))
         if mm.n_img <= 0 or mm.n_aud <= 0 or Z < 2:
             return False
-        sub = {"img": (mm.n_img + 31) // 32, "aud": (mm.n_aud + 31) // 32}
-        za = min(max(1, round(Z * sub["img"] / (sub["img"] + sub["aud"]))), Z - 1)
-        zs = {"img": max(1, min(za, (sub["img"] + 7) // 8)), "aud": max(1, min(Z - za, (sub["aud"] + 7) // 8))}
+        from .shard import split_key_slices
+        zs = dict(zip(("img", "aud"), split_key_slices(Z, (mm.n_img + 31) // 32, (mm.n_aud + 31) // 32)))
         sets = {}
         for which in ("img", "aud"):
             key = f"xattn_ws_{which}_{zs[which]}_{Rpad}"

@@ -67,3 +67,16 @@ def packed_offsets(slot: int, nkv: int, rows: int, hd: int) -> Tuple[int, int]:
     """(numerator offset, (m, l) offset) in fp32 words of modality slot `slot` inside one rank's packed partial."""
     base = slot * nkv * rows * (hd + 2)
     return base, base + nkv * rows * hd
+
+
+def split_key_slices(slices: int, subtiles_a: int, subtiles_b: int, min_subtiles: int = 8):
+    """Share `slices` split-KV key slices of ONE cross-attention launch between two modalities in proportion to their 32-key sub-tiles
+    (the launch is as long as its slowest slice): -> (za, zb), each >= 1, za + zb <= slices, and no slice shorter than `min_subtiles`
+    sub-tiles unless the modality itself is shorter (a slice costs a partial and a merge step whatever its length)."""
+    if slices < 2 or subtiles_a <= 0 or subtiles_b <= 0:
+        raise ValueError("two non-empty modalities and at least two slices")
+    za = min(max(1, round(slices * subtiles_a / (subtiles_a + subtiles_b))), slices - 1)
+    zb = slices - za
+    cap = lambda z, n: max(1, min(z, (n + min_subtiles - 1) // min_subtiles))
+    return cap(za, subtiles_a), cap(zb, subtiles_b)
+
