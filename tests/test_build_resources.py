@@ -9,16 +9,18 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "vidi_amd", "csrc", "build")
 HOT = {
-    "gemm.resources.txt": ["gemm_kernel", "gemv_kernel", "gemv_glu_kernel", "gemm_f32_kernel"],
+    "gemm.resources.txt": ["gemm_kernel", "gemm_f32_kernel"],
+    "gemv.resources.txt": ["gemv_kernel", "gemv_glu_kernel", "gemv_norm2_kernel"],
     "gemm_w4_bf16.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_f16.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_modes.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_lnf.resources.txt": ["gemm_w4_kernel"],
     "attn_self.resources.txt": ["attn_self_kernel"],
     "attn_self_rm.resources.txt": ["attn_self_rm_kernel"],
-    "attn_cross.resources.txt": ["attn_cross_kernel", "attn_merge"],
-    "attn_text.resources.txt": ["attn_text_kernel", "rope_cache_kernel"],
-    "rowops.resources.txt": ["norm_kernel", "resid_norm2_kernel", "row_stats_kernel"],
+    "attn_cross.resources.txt": ["attn_cross_kernel", "attn_cross2_kernel", "attn_merge"],
+    "attn_text.resources.txt": ["attn_text_kernel", "attn_text_decode_kernel", "rope_cache_kernel"],
+    "rowops.resources.txt": ["norm_kernel", "resid_norm2_kernel", "resid_norm2_rows_kernel", "row_stats_kernel"],
+    "elementwise.resources.txt": ["softcap_argmax_kernel"],
     "preproc.resources.txt": ["resize_h_u8_kernel", "resize_v_u8_norm_kernel"],
 }
 
