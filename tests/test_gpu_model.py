@@ -291,3 +291,46 @@ def test_generate_do_sample(tiny_setup):
     a = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, temperature=1.5, top_p=0.95, generator=g(), eos_token_id=-1)
     b = model.generate(ids, mm_state=st, max_new_tokens=5, do_sample=True, temperature=1.5, top_p=0.95, generator=g(), eos_token_id=-1)
     assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < cfg.vocab_size
+
+
+def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
+    """The baseline arm of every engine switch (what tools/ab_*.py time against) computes the same function: one
+    video, prefill + teacher-forced decode steps on the default engine and on one built with every switch at 0.  The two arms differ in
+    summation order and in weight roundings (LayerNorm and repeat_kv folds): hidden states and stream caches within the model-level
+    tolerance."""
+    cfg, eng, w32, dt = tiny_setup
+    names = {"ln_fold": "VIDI_LN_FOLD", "attn_rm": "VIDI_ATTN_RM", "stream_norm2": "VIDI_STREAM_NORM2", "fold_repkv": "VIDI_FOLD_REPKV",
+             "decode_attn": "VIDI_DECODE_ATTN", "cross_dual": "VIDI_CROSS_DUAL", "decode_norm_gemv": "VIDI_DECODE_NORM_GEMV"}
+    assert all(getattr(eng, n) for n in names), "the fixture engine runs the default arms"
+    for env in names.values():
+        monkeypatch.setenv(env, "0")
+    eng0, _ = make(cfg, dt)
+    assert not any(getattr(eng0, n) for n in names)
+    T, C = 3, 1
+    px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 126, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((C, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 127, 0.3).to(dt)
+    ids = torch.tensor([[2, 21, 22, 23, 24, 25, 26]], dtype=torch.int64).cuda()
+    forced = [31, 7, 19, 44, 5]
+    runs = []
+    for e in (eng, eng0):
+        fi, mi = e.encode_video_images(px.cuda())
+        fa, ma = e.encode_video_audios(mel.cuda(), 100)
+        mm = e.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=False)
+        L = ids.shape[1]
+        ts = e.new_text_state(1, L + len(forced) + 2)
+        hn = e.text_forward(e.embed_tokens(ids), torch.arange(L, device="cuda"), ts, mm, Lq=L)
+        ts.n_valid = torch.tensor([L], device="cuda")
+        hs = [hn.view(1, L, -1)[:, -1].float().cpu()]
+        for t in forced:
+            posn = ts.n_valid.clone(); ts.n_valid += 1
+            h = e.text_forward(e.embed_tokens(torch.tensor([t], device="cuda")), posn, ts, mm, Lq=1)
+            hs.append(h.float().cpu())
+        runs.append((mm.kc.float().cpu(), mm.vtc.float().cpu(), torch.cat(hs)))
+    a, b = runs
+    # each arm is held to `tol` against the oracle elsewhere in this file; against each other their errors add: twice those bounds
+    def tol2(x, tight):
+        at, rt = tol(dt, x.std().item(), tight=tight)
+        return 2 * at, 2 * rt
+    report("switch arms: stream K caches", a[0], b[0], *tol2(b[0], True))
+    report("switch arms: stream V caches", a[1], b[1], *tol2(b[1], True))
+    report("switch arms: prefill + decode hidden states", a[2], b[2], *tol2(b[2], False))
