@@ -210,6 +210,14 @@ int vidi_attn_text_dyn(const void* Q, const void* Kc, const void* Vc, const void
 int vidi_attn_text_decode(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cos_, const void* sin_, void* O,
                           int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window, float scale, float softcap,
                           int dtype, void* stream);
+/* vidi_attn_text_decode and vidi_attn_merge2 in ONE launch (the decode step runs the T2V + T2A partial pass first): neither fills the
+ * chip and neither depends on the other; the o_proj that follows (gemma.py:94) needs both.  Arguments as in the two calls; results
+ * bit-identical to them.  HD 128 or 256. */
+int vidi_attn_text_decode_merge2(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cos_, const void* sin_, void* O,
+                                 int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window, float scale, float softcap,
+                                 const float* OpartA, const float* MLA, void* OutA, int WA, int zeroA,
+                                 const float* OpartB, const float* MLB, void* OutB, int WB, int zeroB,
+                                 int R, int Rpad, int ldo, int dtype, void* stream);
 /* apply_rotary_pos_emb in place (TP gemma2:146-168); cos/sin:[rows,HD] in the storage dtype. */
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,
               int dtype, void* stream);

@@ -855,3 +855,45 @@ def test_gemv_norm2_equals_resid_norm2_then_gemv(hip, dt, M, K, N, nsrc, glu):
     report("gemv_norm2: projection", out, out_ref.float(), *tol(dt, out_ref.float().std().item(), k=2 if glu else 1))
     with pytest.raises(hip.VidiHipError):                                  # in-place residual is refused (blocks race on it)
         hip.gemv_norm2(a, bb, cc, res, w1, w2, res, w[:N], out, eps=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nq,nkv,HD,B,pos,dyn", [(16, 8, 256, 1, 70, False), (8, 2, 128, 2, 131, True), (16, 8, 256, 1, 0, True)])
+def test_attn_text_decode_merge2_equals_the_two_launches(hip, dt, nq, nkv, HD, B, pos, dyn):
+    """the decode step's T2T and the merge of the cross-attention partials as ONE launch: text-attention output, caches and both merged
+    outputs bit-identical to vidi_attn_text_decode + vidi_attn_merge2"""
+    Lmax, window = 256, 0
+    G = nq // nkv
+    kvd = nkv * HD
+    qkv = seeded((B, nq * HD + 2 * kvd), 130, dtype=dt).cuda()
+    posn = torch.full((B, 1), pos)
+    cos, sin = O.rope_cos_sin(posn, HD, 10000.0, dt)
+    cs, sn = dev(cos.reshape(B, HD).contiguous()), dev(sin.reshape(B, HD).contiguous())
+    kc0 = seeded((B, Lmax, kvd), 131, dtype=dt); vc0 = seeded((B, Lmax, kvd), 132, dtype=dt)
+    kmask = torch.ones((B, Lmax), dtype=torch.uint8).cuda()
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device="cuda") if dyn else None
+    R, Rpad, WA, WB = B * G, 32, 5, 3
+    g = torch.Generator(device="cuda").manual_seed(133)
+    parts = []
+    for W in (WA, WB):
+        op = torch.randn((W, nkv, Rpad, HD), generator=g, device="cuda")
+        ml = torch.stack([torch.randn((W, nkv, Rpad), generator=g, device="cuda"),
+                          torch.rand((W, nkv, Rpad), generator=g, device="cuda") + 0.5], dim=-1).contiguous()
+        ml[0, :, 0, 0] = float("-inf")                                       # an empty partial (a wave without keys)
+        parts.append((op, ml))
+    kw = dict(B=B, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, window=window, scale=HD ** -0.5, softcap=50.0, pos0=pos, pos_dev=pos_dev)
+    res = []
+    for fused in (False, True):
+        kc, vc = dev(kc0.clone()), dev(vc0.clone())
+        o_t = torch.full((B, nq * HD), float("nan"), dtype=dt, device="cuda")
+        oa = torch.full((B, nq * HD), float("nan"), dtype=dt, device="cuda"); ob = torch.full_like(oa, float("nan"))
+        ma = (parts[0][0], parts[0][1], oa, WA, False); mb = (parts[1][0], parts[1][1], ob, WB, False)
+        if fused:
+            hip.attn_text_decode_merge2(qkv, kc, vc, kmask, cs, sn, o_t, ma, mb, R=R, Rpad=Rpad, **kw)
+        else:
+            hip.attn_text_decode(qkv, kc, vc, kmask, cs, sn, o_t, **kw)
+            hip.attn_merge2(*ma, *mb, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+        res.append((o_t, oa, ob, kc, vc))
+    for x, y in zip(*res):
+        assert torch.isfinite(x.float()).all()
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))

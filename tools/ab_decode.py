@@ -160,15 +160,16 @@ def e2e(tokens, rounds, only_default=False):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n, toks
 
-    arms = [("two-launch T2T, cross per modality, norm pairs as launches", False, False, False), ("fused T2T", True, False, False),
-            ("dual cross", False, True, False), ("norm pairs inside the projections", False, False, True), ("all three", True, True, True)]
+    arms = [("two-launch T2T, cross per modality, norm pairs as launches", False, False, False, False), ("fused T2T", True, False, False, False),
+            ("dual cross", False, True, False, False), ("norm pairs inside the projections", False, False, True, False),
+            ("all three", True, True, True, False), ("all three + T2T and merge as one launch", True, True, True, True)]
     if only_default:                                     # the engine's own switches (env), e.g. under rocprofv3
-        arms = [("engine defaults", eng.decode_attn, eng.cross_dual, eng.decode_norm_gemv)]
+        arms = [("engine defaults", eng.decode_attn, eng.cross_dual, eng.decode_norm_gemv, eng.decode_tail)]
     tot = {a[0]: 0.0 for a in arms}
     toks = {}
     for r in range(rounds + 1):
-        for name, da, cd, ng in arms:
-            eng.decode_attn, eng.cross_dual, eng.decode_norm_gemv = da, cd, ng
+        for name, da, cd, ng, dtl in arms:
+            eng.decode_attn, eng.cross_dual, eng.decode_norm_gemv, eng.decode_tail = da, cd, ng, dtl
             ms, t = run(tokens)
             if r == 0:
                 toks[name] = t

@@ -1,5 +1,6 @@
 // extern "C" entry points of libvidi_hip.so (declared in include/vidi_hip.h).
 #include "kernels.h"
+#include "attn_text_decode.h"
 #include <stdlib.h>
 #include "../../include/vidi_hip.h"
 
@@ -327,6 +328,27 @@ int vidi_attn_text_decode(const void* qkv, int ldqkv, void* Kc, void* Vc, const 
     if (!qkv || !Kc || !Vc || !cos_ || !sin_ || !O) return VIDI_ERR_ARG;
     return vidi_attn_text_decode_dispatch(qkv, ldqkv, Kc, Vc, kmask, cos_, sin_, O, B, Lmax, nq, nkv, HD, pos0, pos_dev, window, scale,
                                           softcap, dtype, (hipStream_t)stream);
+}
+
+int vidi_attn_text_decode_merge2(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cos_, const void* sin_, void* O,
+                                 int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window, float scale, float softcap,
+                                 const float* OpartA, const float* MLA, void* OutA, int WA, int zeroA,
+                                 const float* OpartB, const float* MLB, void* OutB, int WB, int zeroB,
+                                 int R, int Rpad, int ldo, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!qkv || !Kc || !Vc || !cos_ || !sin_ || !O || !OpartA || !MLA || !OutA || !OpartB || !MLB || !OutB) return VIDI_ERR_ARG;
+    AttnTextDecodeParams tp;
+    size_t lds;
+    const int rc = attn_text_decode_params(tp, lds, qkv, ldqkv, Kc, Vc, kmask, cos_, sin_, O, B, Lmax, nq, nkv, HD, pos0, pos_dev, window, scale,
+                                           softcap);
+    if (rc) return rc;
+    AttnMergeParams a, b;
+    a.Opart = OpartA; a.ML = MLA; a.Out = (u16*)OutA; a.OutF32 = nullptr; a.OutML = nullptr;
+    a.W = WA; a.nkv = nkv; a.R = R; a.Rpad = Rpad; a.G = nq / nkv; a.ldo = ldo; a.zero_out = zeroA;
+    a.wsO = (long long)nkv * Rpad * HD; a.wsML = (long long)nkv * Rpad * 2; a.rpo = Rpad;
+    b = a;
+    b.Opart = OpartB; b.ML = MLB; b.Out = (u16*)OutB; b.W = WB; b.zero_out = zeroB;
+    return vidi_attn_text_decode_merge2_dispatch(tp, lds, a, b, HD, dtype, (hipStream_t)stream);
 }
 
 int vidi_rope(void* Q, void* K, const void* cos_, const void* sin_, int rows, int nq, int nkv, int HD,

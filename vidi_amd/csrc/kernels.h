@@ -122,6 +122,9 @@ int vidi_attn_text_dispatch(const AttnTextParams& p, int HD, int dtype, hipStrea
 int vidi_attn_text_decode_dispatch(const void* qkv, int ldqkv, void* Kc, void* Vc, const void* kmask, const void* cs, const void* sn,
                                    void* O, int B, int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int window,
                                    float scale, float softcap, int dtype, hipStream_t st);
+struct AttnTextDecodeParams;
+int vidi_attn_text_decode_merge2_dispatch(const AttnTextDecodeParams& tp, size_t lds, const AttnMergeParams& a, const AttnMergeParams& b, int HD,
+                                          int dtype, hipStream_t st);
 int vidi_rope_dispatch(void* Q, void* K, const void* cs, const void* sn, int rows, int nq, int nkv, int HD, int dtype, hipStream_t st);
 int vidi_rope_cache_dispatch(const void* qkv, int ldqkv, void* QR, void* Kc, void* Vc, const void* cs, const void* sn, int B, int Lq,
                              int Lmax, int nq, int nkv, int HD, int pos0, const int* pos_dev, int dtype, hipStream_t st);

@@ -119,6 +119,8 @@ class VidiEngine:
         # decode step: the Gemma2 norm pairs folded into the gate/up and the next layer's q/k/v projections (VIDI_DECODE_NORM_GEMV=0:
         # vidi_resid_norm2 + vidi_gemv[_glu] as separate launches)
         self.decode_norm_gemv = os.environ.get("VIDI_DECODE_NORM_GEMV", "1") != "0"
+        # decode step: the T2T launch and the merge of the cross-attention partials as one launch (VIDI_DECODE_TAIL=0: two launches)
+        self.decode_tail = os.environ.get("VIDI_DECODE_TAIL", "1") != "0"
         # multimodal stream: o_proj over repeat_kv(V) as one GEMM over V with the G column blocks of o_proj summed at load time
         # (VIDI_FOLD_REPKV=0: the repeat done by the GEMM's operand read, K twice as long)
         self.fold_repkv = os.environ.get("VIDI_FOLD_REPKV", "1") != "0"
@@ -673,7 +675,8 @@ class VidiEngine:
         hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd, zero_out=not any_valid)
         return None
 
-    def _cross_dual(self, q: torch.Tensor, li: int, mm: MMState, out_img: torch.Tensor, out_aud: torch.Tensor, R: int) -> bool:
+    def _cross_dual(self, q: torch.Tensor, li: int, mm: MMState, out_img: torch.Tensor, out_aud: torch.Tensor, R: int,
+                    defer_merge: bool = False):
         """single-GPU T2V + T2A of one layer: ONE split-KV launch over both key regions (vidi_attn_cross2, the key slices shared out
         in proportion to the modalities' keys) and ONE merge launch.  False: shape not eligible (the caller runs them separately)."""
         cfg = self.cfg
@@ -697,9 +700,11 @@ class VidiEngine:
                                n_keys=mm.n_img if which == "img" else mm.n_aud, zsplit=zs[which])
         hip.attn_cross2(q, mm.kc[li], mm.vtc[li], sets["img"], sets["aud"], R=R, Rpad=Rpad, G=G, nkv=nkv, HD=hd, ntile64=mm.ntile64,
                         scale=cfg.query_pre_attn_scalar ** -0.5, softcap=cfg.attn_logit_softcapping)
-        hip.attn_merge2(sets["img"]["opart"], sets["img"]["ml"], out_img, zs["img"], not mm.img_any_valid,
-                        sets["aud"]["opart"], sets["aud"]["ml"], out_aud, zs["aud"], not mm.aud_any_valid,
-                        nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd)
+        merge = ((sets["img"]["opart"], sets["img"]["ml"], out_img, zs["img"], not mm.img_any_valid),
+                 (sets["aud"]["opart"], sets["aud"]["ml"], out_aud, zs["aud"], not mm.aud_any_valid))
+        if defer_merge:                                  # the caller merges (together with the decode step's T2T launch)
+            return merge
+        hip.attn_merge2(*merge[0], *merge[1], nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd)
         return True
 
     def _cross_sharded(self, q: torch.Tensor, li: int, mm: MMState, outs: Dict[str, torch.Tensor], R: int):
@@ -814,12 +819,19 @@ class VidiEngine:
             qkv_ready = False
             # RoPE'd q for T2T (raw q stays in qkv for the cross-attention, gemma.py:58), RoPE'd k and v appended to the cache
             window = cfg.sliding_window if (self.mistral or li % 2 == 0) else 0                       # gemma.py:104; Mistral: every layer
-            if Lq == 1 and self.decode_attn and hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=hd, Lmax=ts.Lmax, window=window,
-                                                                          pos0=None if dyn else p0):
+            t2t_fused = Lq == 1 and self.decode_attn and hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=hd, Lmax=ts.Lmax, window=window,
+                                                                                   pos0=None if dyn else p0)
+            t2t_kw = dict(B=B, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd, window=window, scale=sc, softcap=cfg.attn_logit_softcapping, pos0=p0,
+                          pos_dev=ts.pos_dev if dyn else None)
+            # decode with both modalities on one GPU: the T2T launch is held back and issued together with the merge of the
+            # cross-attention partials (vidi_attn_text_decode_merge2) after the T2V + T2A partial pass
+            t2t_with_merge = (t2t_fused and self.decode_tail and self.cross_dual and self.world == 1 and hd in (128, 256)
+                              and mm is not None and mm.g_img > 0 and mm.g_aud > 0)
+            if t2t_with_merge:
+                pass
+            elif t2t_fused:
                 # decode: rope + cache append + T2T in one launch (vidi_attn_text_decode)
-                hip.attn_text_decode(qkv, ts.kc[li], ts.vc[li], ts.kmask, cos, sin, att[:M], B=B, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
-                                     window=window, scale=sc, softcap=cfg.attn_logit_softcapping, pos0=p0,
-                                     pos_dev=ts.pos_dev if dyn else None)
+                hip.attn_text_decode(qkv, ts.kc[li], ts.vc[li], ts.kmask, cos, sin, att[:M], **t2t_kw)
             elif dyn:
                 hip.rope_cache(qkv, qr, ts.kc[li], ts.vc[li], cos, sin, B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
                                pos_dev=ts.pos_dev)
@@ -843,7 +855,14 @@ class VidiEngine:
             else:
                 both = has_img and has_aud
                 pend = []
-                if both and self.cross_dual and self._cross_dual(qraw, li, mm, att[M: 2 * M], att[2 * M: 3 * M], R=M * G):
+                dual = both and self.cross_dual and self._cross_dual(qraw, li, mm, att[M: 2 * M], att[2 * M: 3 * M], R=M * G,
+                                                                     defer_merge=t2t_with_merge)
+                if t2t_with_merge and dual:
+                    hip.attn_text_decode_merge2(qkv, ts.kc[li], ts.vc[li], ts.kmask, cos, sin, att[:M], dual[0], dual[1], R=M * G,
+                                                Rpad=_round_up(M * G, 32), **t2t_kw)
+                elif t2t_with_merge:                                    # the dual launch was not eligible after all: T2T on its own
+                    hip.attn_text_decode(qkv, ts.kc[li], ts.vc[li], ts.kmask, cos, sin, att[:M], **t2t_kw)
+                if dual:
                     k = 3                                               # T2V + T2A partials in one launch, merged by one launch
                     both = False
                     has_img_l = has_aud_l = False

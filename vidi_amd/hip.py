@@ -51,6 +51,8 @@ SIGNATURES = {
     "vidi_attn_merge2_sharded": ([_c_vp] * 2 + [_c_ll] * 2 + [_c_vp] * 3 + [_c_int] * 2) * 2 + [_c_int] * 8 + [_c_vp],
     "vidi_attn_cross2": [_c_vp] * 3 + ([_c_vp] * 3 + [_c_int] * 3) * 2 + [_c_int] * 7 + [_c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text_decode": [_c_vp, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
+    "vidi_attn_text_decode_merge2": [_c_vp, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f] +
+                                    ([_c_vp] * 3 + [_c_int] * 2) * 2 + [_c_int] * 4 + [_c_vp],
     "vidi_attn_text": [_c_vp] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_vp],
     "vidi_attn_text_dyn": [_c_vp] * 5 + [_c_int] * 6 + [_c_vp, _c_int, _c_f, _c_f, _c_int, _c_vp],
     "vidi_rope": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
@@ -567,6 +569,21 @@ def attn_text_decode(qkv, kc, vc, kmask, cos, sin, out, *, B, Lmax, nq, nkv, HD,
     _check(lib.vidi_attn_text_decode(_p(qkv), qkv.stride(0), _p(kc), _p(vc), _p(kmask), _p(cos), _p(sin), _p(out), B, Lmax, nq, nkv, HD,
                                      int(pos0), _p(pos_dev), int(window), float(scale), float(softcap or 0.0), _dt(qkv), _stream()),
            "vidi_attn_text_decode")
+
+
+def attn_text_decode_merge2(qkv, kc, vc, kmask, cos, sin, out, merge_a, merge_b, *, B, Lmax, nq, nkv, HD, window, scale, softcap, R, Rpad,
+                            pos0=0, pos_dev=None):
+    """attn_text_decode + attn_merge2 in one launch; merge_x = (opart, ml, out, W, zero_out)"""
+    lib = load_library()
+    if pos_dev is not None and (pos_dev.dtype != torch.int32 or not pos_dev.is_cuda):
+        raise VidiHipError("attn_text_decode_merge2: pos_dev must be a CUDA int32 tensor")
+    (oa, mla, outa, wa, za), (ob, mlb, outb, wb, zb) = merge_a, merge_b
+    if outa.stride(0) != outb.stride(0):
+        raise VidiHipError("attn_text_decode_merge2: the two merge outputs must share the row stride")
+    _check(lib.vidi_attn_text_decode_merge2(_p(qkv), qkv.stride(0), _p(kc), _p(vc), _p(kmask), _p(cos), _p(sin), _p(out), B, Lmax, nq, nkv, HD,
+                                            int(pos0), _p(pos_dev), int(window), float(scale), float(softcap or 0.0),
+                                            _p(oa), _p(mla), _p(outa), wa, 1 if za else 0, _p(ob), _p(mlb), _p(outb), wb, 1 if zb else 0,
+                                            R, Rpad, outa.stride(0), _dt(qkv), _stream()), "vidi_attn_text_decode_merge2")
 
 
 def rope_cache(qkv, qr, kc, vc, cos, sin, *, B, Lq, Lmax, nq, nkv, HD, pos0=0, pos_dev=None):
