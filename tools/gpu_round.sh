@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: GPU parity suite (with the tolerance-slack audit), smoke, bench, rocprofv3 kernel stats, PMC traffic passes.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tests|bench|prof|pmc|smoke ...]   (default: all)
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tests|bench|prof|pmc|smoke|decode|variants|mfma ...]   (default: tests smoke bench prof pmc)
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
@@ -51,6 +51,14 @@ for l in open("gpurun_out/lab_res.jsonl"):
 for k in sorted(acc): print(k, [round(x) for x in acc[k]])
 PY
   ;;
+decode)
+  # decode step: per-switch end-to-end A/B on one engine, the cross-attention launch and the skinny projections against lab builds
+  timeout 600 python tools/ab_decode.py e2e 32 4 > $OUT/ab_decode_e2e.jsonl 2> $OUT/ab_decode_e2e.err; echo "decode rc=$?"; cat $OUT/ab_decode_e2e.jsonl
+  libs=$(ls vidi_amd/libvidi_hip_*.so 2>/dev/null)
+  if [ -n "$libs" ]; then
+    timeout 300 python tools/ab_decode.py cross vidi_amd/libvidi_hip.so $libs > $OUT/ab_decode_cross.jsonl 2> $OUT/ab_decode_cross.err; cat $OUT/ab_decode_cross.jsonl
+    timeout 300 python tools/ab_decode.py gemv vidi_amd/libvidi_hip.so $libs > $OUT/ab_decode_gemv.jsonl 2> $OUT/ab_decode_gemv.err; cat $OUT/ab_decode_gemv.jsonl
+  fi ;;
 abln)
   timeout 900 python tools/ab_ln_fold.py 1440 3 > $OUT/ab_ln_fold.jsonl 2> $OUT/ab_ln_fold.err; echo "abln rc=$?"; cat $OUT/ab_ln_fold.jsonl ;;
 dist2)
