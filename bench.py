@@ -35,8 +35,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=3600, help="video frames (1 fps); 3600 = BASELINE 60-min config")
+    ap.add_argument("--frames", type=int, default=3600, help="video frames; 3600 @1 fps = BASELINE 60-min config")
+    ap.add_argument("--fps", type=float, default=1.0, help="sampling rate of the frames: the video lasts frames / fps seconds, which sizes the "
+                                                           "30-s audio windows and the mel length (BASELINE configs[4]: 3600 frames @2 fps = 30 min)")
     ap.add_argument("--prompt-len", type=int, default=39)
+    ap.add_argument("--ragged-prompts", type=int, nargs=2, default=None, metavar=("MIN", "MAX"),
+                    help="--queries prompts of lengths MIN..MAX (evenly spread, right-padded with an attention mask) instead of equal "
+                         "lengths (SURVEY 8d config 5: 24 52)")
     ap.add_argument("--decode-steps", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -49,6 +54,24 @@ def parse():
     ap.add_argument("--no-preproc", action="store_true", help="skip the extra (untimed-in-`value`) GPU preprocessing leg")
     ap.add_argument("--src-hw", type=int, nargs=2, default=[480, 854], help="decoded frame size fed to the preprocessing leg")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: re-executes itself as N ranks (one per GPU) under torch.distributed.run and relays
+    rank 0's JSON line.  Under torchrun (WORLD_SIZE set) this is never reached.  Test mode: VIDI_DIST_BACKEND=gloo lets the N ranks
+    share GPU 0 of a one-GPU box (RCCL refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    ngpu = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ngpu < a.gpus:
+        if env.get("VIDI_DIST_BACKEND") != "gloo":
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {ngpu} GPU(s) visible (set VIDI_DIST_BACKEND=gloo to run the ranks on one GPU as a test)")
+        env.setdefault("VIDI_FORCE_DEVICE", "0")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 from vidi_amd.shard import shard          # noqa: E402  (the product's frame / window partition; host integer logic)
@@ -64,7 +87,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False):
+def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False, windows=None):
     """The reference has no CPU path (FA2 is hard-required), so the baseline is the CPU oracle (oracle/vidi_oracle.py, eager
     PyTorch) on the host cores, timed on the slices SURVEY 8(d) prescribes and extrapolated linearly in (frames x layers),
     (tokens x layers), (windows x layers):  SigLIP 32 frames x 2 layers, LLM mm-stream 4 096 tokens x 2 layers, text->mm cross-attention
@@ -94,7 +117,7 @@ def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False):
     w32 = init_random_weights(small, seed=3, dtype=torch.float32, device="cpu")
     names = {f.name for f in dataclasses.fields(O.OracleConfig)}
     ocfg = O.OracleConfig(**{k: v for k, v in small.to_dict().items() if k in names}, vis_select_layer=small.mm_vision_select_layer)
-    C = math.ceil(T / 30)
+    C = math.ceil(T / 30) if windows is None else windows
     # algorithmic FLOPs of the slices (SURVEY 8d per-unit figures)
     Hv, Iv, Ns = cfg.vis_hidden_size, cfg.vis_intermediate_size, cfg.vis_side ** 2
     f_vis = (8 * Hv * Hv + 4 * Hv * Iv + 4 * Ns * Hv) * Ns                       # per frame-layer
@@ -168,7 +191,11 @@ def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, a.gpus) and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -200,8 +227,9 @@ def main():
 
     # ---- synthetic workload: resident in HBM before the timed region ----
     T = a.frames
-    Cw = math.ceil(T / 30)                                   # 30-s Whisper windows
-    audio_size = T * 100                                      # mel frames (100 per second)
+    secs = T / a.fps                                          # dataset/vid_utils.py:10-14 load_video(fps=...): T frames cover T / fps seconds
+    Cw = math.ceil(secs / 30)                                 # 30-s Whisper windows
+    audio_size = int(round(secs * 100))                       # mel frames (100 per second)
     f0, f1 = shard(T, world, rank)
     c0, c1 = shard(Cw, world, rank)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -209,9 +237,17 @@ def main():
     pixel = (torch.randn((f1 - f0, 3, S, S), generator=g, device=dev) * 0.5).clamp_(-1, 1).to(dtype)
     mel = (torch.randn((c1 - c0, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g, device=dev) * 0.3).to(dtype)
     gi = torch.Generator().manual_seed(2)
-    ids = torch.randint(1000, min(200000, cfg.vocab_size), (a.queries, a.prompt_len + 1), generator=gi)
+    plens = [a.prompt_len] * a.queries
+    if a.ragged_prompts is not None:
+        lo, hi = a.ragged_prompts
+        plens = [lo + round(i * (hi - lo) / max(1, a.queries - 1)) for i in range(a.queries)]
+    ids = torch.randint(1000, min(200000, cfg.vocab_size), (a.queries, max(plens) + 1), generator=gi)
     ids[:, 0] = cfg.bos_token_id
     ids[:, 4] = -200
+    amask = None
+    if len(set(plens)) > 1:                                    # right-padded batch (multimodal.py:413-432 re-pads on the right)
+        amask = torch.arange(ids.shape[1])[None, :] < (torch.tensor(plens)[:, None] + 1)
+        ids = torch.where(amask, ids, torch.full_like(ids, cfg.pad_token_id if cfg.pad_token_id is not None else 0))
     if cfg.arch == "mistral":                                   # Vidi-7B: fixed pool x pool tokens per frame (learned Conv2DPool)
         Nv = T * cfg.mm_image_pool_size ** 2
     else:
@@ -222,7 +258,7 @@ def main():
     one = torch.ones(1, dtype=torch.int32, device=dev)         # sample-level "any non-zero input" flag (synthetic: true)
 
     from vidi_amd.model import strip_image_token
-    idt, mask, pos = strip_image_token(ids)
+    idt, mask, pos = strip_image_token(ids, amask)
     stage_ms = {}
     checks = []            # (first-token logits, argmax) of every timed step: verified after the timed region (finite, identical)
 
@@ -362,11 +398,12 @@ def main():
             for k, v in fam.items()}
 
     res = {
-        "metric": "video-tokens/sec (prefill), Vidi1.5-9B 1h@1fps" if cfg.arch != "mistral" else "video-tokens/sec (prefill), Vidi-7B", "value": value, "unit": "video-tokens/s",
+        "metric": f"video-tokens/sec (prefill), Vidi1.5-9B {'1h' if secs == 3600 else f'{secs / 60:g}min'}@{a.fps:g}fps" if cfg.arch != "mistral" else "video-tokens/sec (prefill), Vidi-7B", "value": value, "unit": "video-tokens/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (random frames/mel/prompt, random-init weights)",
-        "config": {"workload": f"{'Vidi-7B' if cfg.arch == 'mistral' else 'Vidi1.5-9B'} prefill, {T} frames@1fps 384px (+{Cw} audio windows, {a.prompt_len}-token prompt)",
-                   "frames": T, "video_tokens": Nv, "audio_tokens": Na, "prompt_tokens": a.prompt_len,
+        "config": {"workload": f"{'Vidi-7B' if cfg.arch == 'mistral' else 'Vidi1.5-9B'} prefill, {T} frames@{a.fps:g}fps 384px (+{Cw} audio windows, "
+                               + (f"{a.prompt_len}-token prompt)" if len(set(plens)) == 1 and a.queries == 1 else f"{a.queries} prompts of {min(plens)}..{max(plens)} tokens sharing the video)"),
+                   "frames": T, "fps": a.fps, "video_tokens": Nv, "audio_tokens": Na, "prompt_tokens": plens[0] if len(set(plens)) == 1 else plens,
                    "parallelism": f"frame-shard x{world} (K/V shards resident, LSE-merged cross-attention)" if world > 1 else "single GPU"},
         # one video, `queries` prompts answered together: the encode + stream prefill is shared
         "sec_per_query": (ms_per_step / 1e3 + a.decode_steps * t_decode) / a.queries, "decode_ms_per_token": t_decode * 1e3,
@@ -386,7 +423,7 @@ def main():
             H0, W0 = a.src_hw
             gp = torch.Generator(device=dev).manual_seed(7)
             frames_u8 = torch.randint(0, 256, (T, H0, W0, 3), dtype=torch.uint8, device=dev, generator=gp)
-            pcm = torch.randn(T * 16000, device=dev, generator=gp) * 0.1
+            pcm = torch.randn(int(round(secs * 16000)), device=dev, generator=gp) * 0.1
             fp = FramePreprocessor(cfg.vis_image_size, dtype=dtype, device=dev, frames_per_chunk=512)
             lm = LogMelExtractor(n_mels=cfg.aud_num_mel_bins, dtype=dtype, device=dev)
             fp(frames_u8[:8]); lm(pcm[: 480000 * 2]); torch.cuda.synchronize()
@@ -396,14 +433,14 @@ def main():
             torch.cuda.synchronize()
             t_pre = time.perf_counter() - tp0
             assert px2.shape == pixel.shape and mel2.shape == mel.shape and alen == audio_size
-            res["preproc"] = {"ms_per_video": t_pre * 1e3, "source": f"{T} frames {H0}x{W0} RGB uint8 + {T} s PCM, resident in HBM",
+            res["preproc"] = {"ms_per_video": t_pre * 1e3, "source": f"{T} frames {H0}x{W0} RGB uint8 + {secs:g} s PCM, resident in HBM",
                               "value_incl_preproc": Nv / (ms_per_step / 1e3 + t_pre)}
             del frames_u8, pcm, px2, mel2
         except Exception as e:
             res["preproc"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(cfg, T, Nv, Na, a.prompt_len)
+            res["cpu_baseline"] = cpu_baseline(cfg, T, Nv, Na, max(plens), windows=Cw)
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
         except Exception as e:      # never lose the GPU line to a host-side problem
             res["cpu_baseline"] = {"error": repr(e)}

@@ -408,7 +408,11 @@ __global__ __launch_bounds__(256) void attn_text_decode_merge2_kernel(AttnTextDe
         attn_text_decode_body<T, HD>(tp, blockIdx.x % tp.nkv, blockIdx.x / tp.nkv);
         return;
     }
-    __shared__ float s_m[256], s_l[256];
+    // the merge role's (m, l) staging lives at the head of the launch's DYNAMIC allocation (sized for the T2T role, never below 2 KB):
+    // a static array on top of it would push a T2T plan of exactly 64 KB over the limit
+    extern __shared__ float s_mrg[];
+    float* s_m = s_mrg;
+    float* s_l = s_mrg + 256;
     const int mb = blockIdx.x - nt;
     const int r = mb % a.R, kvh = (mb / a.R) % a.nkv, set = mb / (a.R * a.nkv);
     const AttnMergeParams& p = set == 0 ? a : b;
@@ -421,6 +425,7 @@ int vidi_attn_text_decode_merge2_dispatch(const AttnTextDecodeParams& tp, size_t
     if (HD != 256 && HD != 128) return VIDI_ERR_SHAPE;
     const int nt = tp.nkv * tp.B;
     const dim3 grid(nt + 2 * a.nkv * a.R);
+    if (lds < 2 * 256 * sizeof(float)) lds = 2 * 256 * sizeof(float);       // the merge role's staging
     if (dtype == VIDI_DT_BF16) {
         if (HD == 256) hipLaunchKernelGGL((attn_text_decode_merge2_kernel<BF16, 256>), grid, dim3(256), lds, st, tp, a, b, nt);
         else hipLaunchKernelGGL((attn_text_decode_merge2_kernel<BF16, 128>), grid, dim3(256), lds, st, tp, a, b, nt);

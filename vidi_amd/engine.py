@@ -7,7 +7,9 @@ views, copies and index tensors.  The structure follows the reference call stack
   mm_stream_prefill (diagonal V2V/A2A stream)  <- lmm/dattn/gemma.py:183-202 (x42), 59-65 (caches)
   text_forward (T2T + T2V + T2A)               <- lmm/dattn/gemma.py:160-238, 267-424, 562-569
 
-Design choices that differ from the reference on purpose (results identical):
+Design choices that differ from the reference on purpose (the first three give identical results; the weight folds re-round
+weights once at load time and are tolerance-level deviations — each has a switch whose off arm keeps the reference's rounding
+points, and both arms are held to the goldens):
   * the multimodal stream is query-independent, so it is run ONCE per video for all layers
     (`MMState`) and shared by every query/decoding step; the reference interleaves it with the
     text prefill layer by layer (gemma.py:362-406) and re-multiplies the embeds every step.
@@ -15,6 +17,10 @@ Design choices that differ from the reference on purpose (results identical):
     cross-attention kernel's tile layout; `repeat_kv` is never materialised.
   * layer L-1's stream update (gemma.py:196-202 on the last layer) is dead in the reference and
     skipped here.
+  * VIDI_LN_FOLD (default on): the towers' LayerNorm weights are multiplied into the consuming projection, Wf = T(W * gamma) —
+    one extra rounding per weight; the reference multiplies the T-rounded LayerNorm output by the unfused weights.
+  * VIDI_FOLD_REPKV (default on): the multimodal stream's o_proj(repeat_kv(V)) uses wo_kv = T(sum_g Wo block) — the G column blocks
+    summed in fp32 and rounded once; the error (about one ulp per weight) feeds every later layer's K/V cache.
 """
 from __future__ import annotations
 
@@ -129,6 +135,7 @@ class VidiEngine:
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._ws: Dict[str, torch.Tensor] = {}
         self.pg, self.world, self.rank = None, 1, 0
+        self.sharded = False                            # set_dist(): the key-sharded cross-attention path (world > 1, or forced for a one-rank RCCL test)
         self.n_collectives = 0                          # data-path all-gathers issued (one per decoder layer per forward when sharded)
 
     # -----------------------------------------------------------------------------------------
@@ -364,7 +371,9 @@ class VidiEngine:
         ws = {"st": self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32) if fold else None,
               "part": self._buf("vis_part", (2 * Mmax * ((Hv + 127) // 128),), dtype=torch.float32) if fold else None,
               "h": None if fold else self._buf("vis_h", (Mmax, Hv)),
-              "yqk": self._buf("vis_qk", (Mmax, 2 * Hv)), "vt": self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True),
+              # Q|K rows + V^T planes of the Vt attention arm; the default arm (head-major q|k|v + transpose-read attention) needs neither
+              "yqk": None if (fold and self.attn_rm) else self._buf("vis_qk", (Mmax, 2 * Hv)),
+              "vt": None if (fold and self.attn_rm) else self._buf("vis_vt", (min(T, fc), nh, hd, Npad), zero=True),
               "qkv": self._buf("vis_qkv", (Mmax, 3 * Hv)) if (fold and self.attn_rm) else None,
               "ao": self._buf("vis_ao", (Mmax, Hv)), "f1": self._buf("vis_f1", (Mmax, V["ipad"]))}
         pixel = pixel.to(self.dtype).contiguous()
@@ -455,7 +464,8 @@ class VidiEngine:
         ws = {"st": self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32) if fold else None,
               "part": self._buf("aud_part", (2 * nb * N * ((Da + 127) // 128),), dtype=torch.float32) if fold else None,
               "h": None if fold else self._buf("aud_h", (nb * N, Da)),
-              "yqk": self._buf("aud_qk", (nb * N, 2 * Da)), "vt": self._buf("aud_vt", (nb, nh, hd, Npad), zero=True),
+              "yqk": None if (fold and self.attn_rm) else self._buf("aud_qk", (nb * N, 2 * Da)),
+              "vt": None if (fold and self.attn_rm) else self._buf("aud_vt", (nb, nh, hd, Npad), zero=True),
               "qkv": self._buf("aud_qkv", (nb * N, 3 * Da)) if (fold and self.attn_rm) else None,
               "ao": self._buf("aud_ao", (nb * N, Da)), "f1": self._buf("aud_f1", (nb * N, cfg.aud_ffn_dim))}
         mel = mel.to(self.dtype).contiguous()
@@ -540,12 +550,12 @@ class VidiEngine:
         ntile = ntot // 64
         st = MMState(n_img=n_img, n_aud=n_aud, img_start=0, aud_start=aud_start, ntile64=ntile)
         st.g_img, st.g_aud = n_img, n_aud
-        if self.world > 1:                              # modality presence is a global property
+        if self.sharded:                                # modality presence is a global property
             import torch.distributed as dist
             t = torch.tensor([n_img, n_aud], dtype=torch.int64, device=self.dev if dist.get_backend(self.pg) != "gloo" else "cpu")
             dist.all_reduce(t, group=self.pg)
             st.g_img, st.g_aud = int(t[0]), int(t[1])
-        if ntot == 0 and self.world == 1:
+        if ntot == 0 and not self.sharded:
             return st
         Lr = cfg.num_hidden_layers
         X = torch.zeros((ntot, H), dtype=self.dtype, device=self.dev)
@@ -599,11 +609,11 @@ class VidiEngine:
         if check_masks:
             # one host sync per VIDEO (the reference syncs per layer per step: xattn.py:214-215)
             for name, m in (("img", img_mask), ("aud", aud_mask)):
-                if m is None and self.world == 1:
+                if m is None and not self.sharded:
                     continue
                 nv = int(m.sum().item()) if m is not None and m.numel() else 0
                 nv_global = nv
-                if self.world > 1:                     # "sample has any valid key" is a global property
+                if self.sharded:                       # "sample has any valid key" is a global property
                     import torch.distributed as dist
                     t = torch.tensor([nv], dtype=torch.int64, device=self.dev if dist.get_backend(self.pg) != "gloo" else "cpu")
                     dist.all_reduce(t, group=self.pg)
@@ -753,6 +763,9 @@ class VidiEngine:
         self.pg = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # VIDI_FORCE_SHARDED=1: a one-rank group still goes through shard -> partial form -> all-gather -> merge, so the RCCL branch of
+        # the exchange can be exercised on a one-GPU box (tests/test_gpu_dist.py)
+        self.sharded = self.world > 1 or os.environ.get("VIDI_FORCE_SHARDED", "0") == "1"
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         import torch.distributed as dist
@@ -825,7 +838,7 @@ class VidiEngine:
                           pos_dev=ts.pos_dev if dyn else None)
             # decode with both modalities on one GPU: the T2T launch is held back and issued together with the merge of the
             # cross-attention partials (vidi_attn_text_decode_merge2) after the T2V + T2A partial pass
-            t2t_with_merge = (t2t_fused and self.decode_tail and self.cross_dual and self.world == 1 and hd in (128, 256)
+            t2t_with_merge = (t2t_fused and self.decode_tail and self.cross_dual and not self.sharded and hd in (128, 256)
                               and mm is not None and mm.g_img > 0 and mm.g_aud > 0)
             if t2t_with_merge:
                 pass
@@ -844,7 +857,7 @@ class VidiEngine:
             k = 1
             qraw = qkv[:, :nqd]
             G = nq // nkv
-            if self.world > 1:
+            if self.sharded:
                 outs = {}
                 if has_img:
                     outs["img"] = att[k * M: (k + 1) * M]; k += 1
@@ -946,9 +959,13 @@ class VidiEngine:
     def make_decode_graph(self, ts: TextState, mm: Optional[MMState], first_ids: torch.Tensor):
         """Runs ONE decode step eagerly on a side stream (warm-up, consumes `first_ids`), then captures the step in
         a hipGraph.  Returns (next_ids_after_warmup, replay) where replay(ids) -> next ids advances the caches by
-        one token per call.  Single-GPU only: the sharded path has a host-driven collective per layer."""
-        if self.world > 1:
-            raise RuntimeError("graph-captured decode is single-GPU")
+        one token per call.  Sharded (one process per GPU): the per-layer all-gathers of the partials are RCCL launches on the
+        capture stream, so the whole step — 42 exchanges included — is one graph launch per token; the gloo test transport moves
+        the partials through the host and cannot be captured."""
+        if self.sharded:
+            import torch.distributed as dist
+            if dist.get_backend(self.pg) != "nccl":
+                raise RuntimeError("graph-captured decode over shards needs the RCCL backend (the gloo test transport is host-driven)")
         if ts.past_len + 2 > ts.Lmax:
             raise RuntimeError("text KV cache exhausted")
         ts.pos_dev = torch.tensor([ts.past_len], dtype=torch.int32, device=self.dev)
@@ -961,7 +978,8 @@ class VidiEngine:
         torch.cuda.current_stream().wait_stream(side)
         ts.past_len += 1
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # sharded: other threads of the process (the process group's watchdog) may touch the runtime while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.sharded else "global"):
             g_out = self.decode_step_dyn(g_in, ts, mm)
 
         def replay(ids: torch.Tensor) -> torch.Tensor:

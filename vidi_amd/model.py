@@ -169,7 +169,7 @@ class VidiForCausalLM:
         fi = mi = fa = ma = None
         nz = eng.normalizer
         kw_i, kw_a = {}, {}
-        if eng.world > 1:
+        if getattr(eng, "sharded", eng.world > 1):
             from .shard import video_shard
             sh = video_shard(0 if img is None else int(img.shape[0]), 0 if aud is None else int(aud.shape[0]), eng.world, eng.rank)
             if img is not None:
@@ -185,6 +185,23 @@ class VidiForCausalLM:
         st = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
         st.image_attention_mask, st.audio_attention_mask = mi, ma
         return st
+
+    # ---- process-group helpers of the sharded path ----
+    def _backend(self) -> str:
+        import torch.distributed as dist
+        return dist.get_backend(self.engine.pg)
+
+    def _bcast0(self, t: torch.Tensor) -> torch.Tensor:
+        """rank 0's value of a small tensor on every rank of the engine's group"""
+        import torch.distributed as dist
+        pg = self.engine.pg
+        src = dist.get_global_rank(pg, 0) if pg is not None else 0
+        if self._backend() == "gloo" and t.is_cuda:                 # CPU-transport test mode
+            c = t.cpu()
+            dist.broadcast(c, src=src, group=pg)
+            return c.to(t.device)
+        dist.broadcast(t, src=src, group=pg)
+        return t
 
     # ---- text prefill + greedy decode ----
     def _prefill(self, ids: torch.Tensor, mask: torch.Tensor, pos: torch.Tensor, mm: Optional[MMState], max_new: int):
@@ -270,13 +287,16 @@ class VidiForCausalLM:
             return sample(warp_logits(logits, kwargs.get("temperature"), kwargs.get("top_k"), kwargs.get("top_p")),
                           kwargs.get("generator"))
 
-        nxt = pick(last)
+        # sharded + sampling: the replicated text streams must draw the SAME token on every rank (each rank has its own RNG state, and
+        # a divergent token or stop decision would mix partials of different queries in the next all-gather or strand a rank in it)
+        sync_pick = do_sample and eng.world > 1
+        nxt = self._bcast0(pick(last)) if sync_pick else pick(last)
         n_done = 0
         # VIDI_DECODE_GRAPH=1: decode steps are replayed from a hipGraph (device-side cache position, no per-launch
         # host work).  Measured on MI355X (60-min video): replay 19.3 ms/token vs 21.0 eager, capture 126 ms —
         # it only pays for generations of ~80+ tokens, so it is opt-in; the sharded path stays eager.
-        use_graph = (not do_sample and eng.world == 1 and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
-                     and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1")
+        use_graph = (not do_sample and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
+                     and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1" and (eng.world == 1 or self._backend() == "nccl"))
         replay = None
         for step in range(max_new):
             nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
@@ -295,7 +315,7 @@ class VidiForCausalLM:
             posn = ts.n_valid.clone()                                  # HF: position = cumsum(mask) - 1 of the new token
             ts.n_valid += 1
             hn = eng.text_forward(emb, posn, ts, mm_state, Lq=1)
-            nxt = pick(hn)
+            nxt = self._bcast0(pick(hn)) if sync_pick else pick(hn)
         return out[:, :n_done]
 
     # ---- forward (gemma.py:484-601): prefill-style call returning logits ----
