@@ -21,11 +21,14 @@ def main(out_path):
     rank = int(os.environ.get("RANK", "0"))
     dt = torch.bfloat16
     cfg = tiny()
-    if world > 1:
-        dist.init_process_group("gloo")
+    backend = os.environ.get("VIDI_DIST_BACKEND", "gloo")
+    grouped = world > 1 or os.environ.get("VIDI_FORCE_SHARDED", "0") == "1"       # one rank + forced shards: the RCCL branch on a one-GPU box
+    if grouped:
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     model = VidiForCausalLM(cfg, init_random_weights(cfg, seed=3, dtype=dt), dtype=dt, device="cuda:0")
     eng = model.engine
-    if world > 1:
+    if grouped:
         eng.set_dist(None)
     T, C, audio_size = 4, 2, 173
     px = seeded((T, 3, cfg.vis_image_size, cfg.vis_image_size), 200, 0.5).clamp(-1, 1).to(dt)
@@ -42,11 +45,35 @@ def main(out_path):
     hn2 = eng.text_forward(eng.embed_tokens(nxt), torch.tensor([idt.shape[1]]).cuda(), ts, mm, Lq=1)
     toks = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=6, do_sample=False)
     toks_cached = model.generate(ids, mm_state=mm, max_new_tokens=6, do_sample=False)
+    # BASELINE configs[4] shape: a batch of 8 ragged prompts (right-padded, attention mask) against the one sharded video
+    g = torch.Generator().manual_seed(5)
+    lens = [5, 6, 7, 8, 9, 10, 11, 12]
+    bids = torch.randint(20, cfg.vocab_size - 1, (8, max(lens)), generator=g)
+    bids[:, 0] = 2
+    bids[:, 3] = -200
+    bmask = torch.arange(max(lens))[None, :] < torch.tensor(lens)[:, None]
+    n1 = eng.n_collectives
+    toks8 = model.generate(bids, mm_state=mm, attention_mask=bmask, max_new_tokens=4, do_sample=False)
+    coll8 = eng.n_collectives - n1
+    # sampled decoding under shards: every rank must leave the loop with the same tokens (rank 0's draw is broadcast)
+    gs = torch.Generator(device="cuda:0").manual_seed(100 + rank)               # DIFFERENT RNG state per rank on purpose
+    toks_s = model.generate(ids, mm_state=mm, max_new_tokens=5, do_sample=True, temperature=1.0, top_k=8, generator=gs)
+    if grouped:
+        allt = [None] * world
+        dist.all_gather_object(allt, toks_s.cpu().tolist())
+        assert all(t == allt[0] for t in allt), allt
+    # graph-captured decode over shards (RCCL launches inside the captured step); the gloo transport is host-driven
+    toks_graph = None
+    if not grouped or backend == "nccl":
+        os.environ["VIDI_DECODE_GRAPH"], os.environ["VIDI_DECODE_GRAPH_MIN"] = "1", "2"
+        toks_graph = model.generate(ids, mm_state=mm, max_new_tokens=6, do_sample=False).cpu()
+        os.environ["VIDI_DECODE_GRAPH"] = "0"
     if rank == 0:
-        torch.save({"prefill": hn.float().cpu(), "decode": hn2.float().cpu(), "g_img": int(mm.g_img), "g_aud": int(mm.g_aud),
+        torch.save({"tokens8": toks8.cpu(), "collectives8": coll8, "tokens_graph": toks_graph, "sharded": bool(eng.sharded),
+                    "prefill": hn.float().cpu(), "decode": hn2.float().cpu(), "g_img": int(mm.g_img), "g_aud": int(mm.g_aud),
                     "n_img_local": int(mm.n_img), "n_aud_local": int(mm.n_aud), "tokens": toks.cpu(), "tokens_cached": toks_cached.cpu(),
                     "collectives_per_forward": per_forward, "layers": cfg.num_hidden_layers}, out_path)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(world, out):
+def _launch(world, out, env=None):
     worker = os.path.join(HERE, "dist_worker.py")
     if world == 1:
         cmd = [sys.executable, worker, out]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", "29533", worker, out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, **(env or {})})
     assert r.returncode == 0, r.stderr[-3000:]
     return torch.load(out)
 
@@ -42,3 +42,25 @@ def test_two_rank_sharded_prefill_matches_single_rank():
     assert torch.equal(a["tokens"], a["tokens_cached"])
     assert torch.equal(a["tokens"][:, :1], b["tokens"][:, :1])                # first token: margin-independent in this seeded case
     print("greedy tokens single-rank", a["tokens"].tolist(), "two ranks", b["tokens"].tolist())   # later tokens may flip on a 1-ulp tie
+    # 8 ragged prompts against the sharded video: same first tokens as one rank, still one collective per layer per forward
+    assert torch.equal(a["tokens8"][:, :1], b["tokens8"][:, :1]), (a["tokens8"].tolist(), b["tokens8"].tolist())
+    assert b["collectives8"] == b["layers"] * b["tokens8"].shape[1] and a["collectives8"] == 0
+    assert torch.equal(a["tokens_graph"], a["tokens"])                       # graph-replayed decode == eager decode (one rank)
+
+
+def test_rccl_exchange_on_one_rank_matches_unsharded():
+    """The `nccl` (= RCCL) branch of the per-layer exchange on the one GPU of the box: a one-rank group with VIDI_FORCE_SHARDED=1 goes
+    video shard -> local split-KV partials -> packed partial form -> `all_gather_into_tensor` through RCCL -> merge of the world's
+    partials, eagerly and captured in the decode hipGraph, and must reproduce the unsharded engine."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _launch(1, os.path.join(d, "w1.pt"))
+        b = _launch(1, os.path.join(d, "w1s.pt"), env={"VIDI_FORCE_SHARDED": "1", "VIDI_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1",
+                                                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534"})
+    assert b["sharded"] and not a["sharded"]
+    assert b["collectives_per_forward"] == b["layers"] and a["collectives_per_forward"] == 0
+    # one rank holds every key: the only difference is the partial form (fp32 numerator, m, l) taking a trip through the exchange buffer
+    report("rccl one-rank prefill hidden", b["prefill"], a["prefill"], 5e-2 * a["prefill"].std().item(), 3e-2)
+    report("rccl one-rank decode hidden", b["decode"], a["decode"], 5e-2 * a["decode"].std().item(), 3e-2)
+    assert torch.equal(b["tokens"][:, :1], a["tokens"][:, :1]) and torch.equal(b["tokens8"][:, :1], a["tokens8"][:, :1])
+    assert torch.equal(b["tokens_cached"], b["tokens"])
+    assert b["tokens_graph"] is not None and torch.equal(b["tokens_graph"], b["tokens"])      # 42... layers' exchanges replayed from the graph

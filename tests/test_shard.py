@@ -86,11 +86,25 @@ def _worker(rank, world, port, frames, windows, audio_size, ret):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         eng.set_dist(None)
     model = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=eng)
-    px = seeded((frames, 3, cfg.vis_image_size, cfg.vis_image_size), 200, 0.5).clamp(-1, 1)
+    px = seeded((abs(frames), 3, cfg.vis_image_size, cfg.vis_image_size), 200, 0.5).clamp(-1, 1)
     mel = seeded((windows, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 201, 0.3)
     ids = torch.tensor([[2, 21, 22, -200, 23, 24, 25]], dtype=torch.int64)
-    out = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=5, do_sample=False)
-    ret.put((rank, out.tolist(), getattr(eng, "last_shard", None)))
+    if frames < 0:
+        # BASELINE configs[4] shape on the host logic: 8 ragged prompts (right-padded + attention mask) answered together against ONE
+        # sharded video, greedy and sampled (every rank seeds its own RNG differently: rank 0's draw must reach all of them)
+        g = torch.Generator().manual_seed(5)
+        lens = [5, 6, 7, 8, 9, 10, 11, 12]
+        bids = torch.randint(20, cfg.vocab_size - 1, (8, max(lens)), generator=g)
+        bids[:, 0], bids[:, 3] = 2, -200
+        bmask = torch.arange(max(lens))[None, :] < torch.tensor(lens)[:, None]
+        mm = model.encode_mm_state([px], [mel], [audio_size])
+        out = model.generate(bids, mm_state=mm, attention_mask=bmask, max_new_tokens=4, do_sample=False)
+        smp = model.generate(bids[:2], mm_state=mm, attention_mask=bmask[:2], max_new_tokens=4, do_sample=True, top_k=5,
+                             generator=torch.Generator().manual_seed(1000 + rank))
+        ret.put((rank, out.tolist(), smp.tolist()))
+    else:
+        out = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=5, do_sample=False)
+        ret.put((rank, out.tolist(), getattr(eng, "last_shard", None)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -121,6 +135,16 @@ def test_generate_under_set_dist_shards_the_video_and_reproduces_single_rank(wor
         assert toks == ref, (rank, toks, ref)
         f0, f1 = S.shard(frames, world, rank)
         assert sh == dict(kind="img", local=f1 - f0, off=f0, total=frames)          # what the product handed this rank's engine
+
+
+def test_batch_of_eight_ragged_queries_under_set_dist():
+    """8 prompts of different lengths share one sharded video (world 2): greedy tokens equal the single-rank run on every rank, and a
+    SAMPLED generation ends with identical tokens on both ranks although their RNG states differ (rank 0's draw is broadcast)."""
+    ref = _run(1, -5, 2, 173)[0]
+    got = _run(2, -5, 2, 173)
+    for rank, toks, smp in got:
+        assert toks == ref[1], (rank, toks, ref[1])
+    assert got[0][2] == got[1][2], (got[0][2], got[1][2])
 
 
 def test_split_key_slices_of_the_dual_cross_attention_launch():
