@@ -92,3 +92,80 @@ def test_checkpoint_dir_to_answer_string(tmp_path, monkeypatch):
     assert sc["vision"]["iou"] > 0.99 and sc["vision"]["precision"] > 0.999 and sc["vision"]["recall"] > 0.999
     assert sc["vision+audio"]["iou"] < 0.01 and sc["vision+audio"]["precision"] < 0.01 and sc["vision+audio"]["recall"] < 0.01
     assert 0.49 < sc["overall"]["precision"] < 0.51 and 0.49 < sc["overall"]["iou"] < 0.51
+
+
+def _reference_script(arch):
+    """the reference's unmodified inference.py: from the checkout ($VIDI_REFERENCE_DIR, default /root/reference) where there is one, else
+    from the copy `__graft_entry__.build()` staged under oracle/_ref/ (git-ignored test input that travels to the GPU box)"""
+    import __graft_entry__ as GE
+    root = os.environ.get("VIDI_REFERENCE_DIR", "/root/reference")
+    for p in (os.path.join(root, GE.REFERENCE_CLI[arch]), os.path.join(GE.ROOT, "oracle", "_ref", "reference_cli", arch, "inference.py")):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+@pytest.mark.parametrize("arch,compat,drop,preset", [("vidi15", "compat", "vidi", "tiny"), ("vidi7b", "compat_7b", "model", "tiny_7b")])
+def test_reference_ask_drives_the_hip_engine(arch, compat, drop, preset, tmp_path, monkeypatch):
+    """SURVEY 8 a19 / north_star "drops into inference.py unchanged", composed on the GPU: the reference's OWN `ask()` (its inference.py
+    imported unmodified, `vidi.*` / `model.*` resolving to vidi_amd/compat*) drives the HIP engine — checkpoint directory ->
+    `load_pretrained_model` (through the reference's import path) -> `.half().cuda()` tensors -> `model.generate` -> its regex /
+    HH:MM:SS formatting — and returns the string vidi_amd/inference.py returns for the same model and media.  Only the media decoders
+    (decord / ffmpeg / ffprobe) are replaced."""
+    import importlib.util
+    import json
+    import sys
+    path = _reference_script(arch)
+    if path is None:
+        pytest.skip("the reference's inference.py is neither checked out nor staged (run __graft_entry__.build() in the build container)")
+    from vidi_amd import config as C, inference as OURS
+    from vidi_amd.weights import init_random_weights
+    cfg = getattr(C, preset)(sliding_window=64) if arch == "vidi15" else getattr(C, preset)()
+    w = init_random_weights(cfg, seed=9, dtype=torch.float16)
+    ckpt = str(tmp_path / "ckpt")
+    write_checkpoint(ckpt, cfg, w)
+    write_tokenizer(ckpt, cfg.vocab_size, mistral=arch == "vidi7b")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vidi_amd", compat))
+    for k in [k for k in sys.modules if k == drop or k.startswith(drop + ".")]:
+        del sys.modules[k]
+    try:
+        spec = importlib.util.spec_from_file_location("ref_inference_gpu_" + compat, path)
+        INF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(INF)                                              # <- the reference's file, unmodified
+        model, tok, ip, ap = INF.load_pretrained_model(ckpt)                      # the name the script imported from vidi.model.builder / model.builder
+        assert type(model).__module__ == "vidi_amd.model" and model.engine.__class__.__name__ == "VidiEngine"
+        model.config.mm_splits = 32                                               # inference.py:87
+        frames, audio = media(21)
+        length = 5025.7
+        for mod, getlen in ((INF, "get_length"), (OURS, "get_media_length")):
+            monkeypatch.setattr(mod, "load_video", lambda p: frames)
+            monkeypatch.setattr(mod, "load_audio", lambda p, sr: audio)
+            monkeypatch.setattr(mod, getlen, lambda p: length)
+        monkeypatch.setattr(os.path, "exists", lambda p: True)
+        seen = {}
+        gen = model.generate
+        def spy(*a, **k):
+            seen["images"], seen["n"] = k["images"], seen.get("n", 0) + 1
+            seen["out"] = gen(*a, **k)
+            return seen["out"]
+        monkeypatch.setattr(model, "generate", spy)
+        rows = []
+        for q in ("a dog running.", "a cat sleeping."):
+            ref = INF.ask(q, "video.mp4", model, tok, ip, ap)                      # the reference's own function on the HIP engine
+            ref_tokens = seen["out"].cpu().tolist()
+            assert seen["images"].is_cuda and seen["images"].dtype == torch.float16
+            ours = OURS.ask(q, "video.mp4", model, tok, ip, ap, arch=arch)
+            assert seen["out"].cpu().tolist() == ref_tokens                         # same kernels, same inputs: the same tokens
+            assert ref == ours and len(ref) > 0, (ref, ours)
+            rows.append({"arch": arch, "query": q, "reference_inference_py": ref, "vidi_amd_inference_py": ours, "new_tokens": len(ref_tokens[0])})
+        assert seen["n"] == 4
+        rec = os.environ.get("VIDI_CLI_RECORD")
+        if rec:
+            with open(rec, "a") as f:
+                for r in rows:
+                    f.write(json.dumps({**r, "script": path, "engine": "VidiEngine (libvidi_hip.so)", "device": torch.cuda.get_device_name(0)}) + "\n")
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == drop or k.startswith(drop + ".")]:
+            del sys.modules[k]

@@ -897,3 +897,130 @@ def test_attn_text_decode_merge2_equals_the_two_launches(hip, dt, nq, nkv, HD, B
     for x, y in zip(*res):
         assert torch.isfinite(x.float()).all()
         assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused decode entry points against the ORACLE at Gemma2-9B dims (their unfused HIP twins are oracle-checked above and the fused
+# forms are held to the twins; these close the loop so that a defect shared by a twin pair cannot pass)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,K,N,nsrc,glu", [(1, 3584, 8192, 1, False), (1, 3584, 14336, 3, True), (4, 3584, 8192, 1, False), (2, 3584, 14336, 3, True)])
+def test_gemv_norm2_vs_oracle(hip, dt, M, K, N, nsrc, glu):
+    """vidi_gemv_norm2 / vidi_gemv_glu_norm2 = the Gemma2 norm pair of DattnGemma2DecoderLayer (gemma.py:236-237 + :118, resp. :120-121 +
+    the next layer's :162) followed by q|k|v resp. gate/up + GeGLU (modeling_gemma2.py:79-82), against the fp32 oracle functions"""
+    eps = 1e-6
+    srcs = [seeded((M, K), 140 + i, dtype=dt) for i in range(3)]
+    res = seeded((M, K), 143, dtype=dt)
+    w1 = seeded((K,), 144, 0.1, dtype=dt); w2 = seeded((K,), 145, 0.1, dtype=dt)
+    s = sum(t.float() for t in srcs[:nsrc])
+    y1_ref = res.float() + O.gemma_rmsnorm(s, w1.float(), eps)
+    x_ref = O.gemma_rmsnorm(y1_ref.to(dt).float(), w2.float(), eps)               # the stream is stored in the dtype between the norms
+    if glu:
+        gate = seeded((N, K), 146, 0.05, dtype=dt); up = seeded((N, K), 147, 0.05, dtype=dt)
+        w = torch.stack([gate.view(N // 32, 32, K), up.view(N // 32, 32, K)], dim=1).reshape(2 * N, K).contiguous()     # engine._pack layout
+        xr = x_ref.to(dt).float()
+        out_ref = O.gelu_tanh(O.linear(xr, gate.float())) * O.linear(xr, up.float())
+    else:
+        w = seeded((N, K), 146, 0.05, dtype=dt)
+        out_ref = O.linear(x_ref.to(dt).float(), w.float())
+    y1 = torch.full((M, K), float("nan"), dtype=dt, device="cuda"); out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    a, b, c = (dev(t) for t in srcs)
+    args = (a, b if nsrc >= 2 else None, c if nsrc >= 3 else None, dev(res), dev(w1), dev(w2), y1, dev(w), out)
+    if glu:
+        hip.gemv_glu_norm2(*args, eps=eps, act=hip.ACT_GELU_TANH)
+    else:
+        hip.gemv_norm2(*args, eps=eps)
+    # residual stream: one norm + one add, rounded once; projection: K = 3584 fp32 accumulation of dtype-rounded normalised rows
+    report("gemv_norm2 vs oracle: residual stream", y1, y1_ref, *tol(dt, y1_ref.std().item()))
+    report("gemv_norm2 vs oracle: projection", out, out_ref, *tol(dt, out_ref.std().item(), k=2 if glu else 1))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attn_cross2_vs_oracle(hip, dt):
+    """vidi_attn_cross2 + vidi_attn_merge2 (T2V and T2A of one decode step, Gemma2-9B head geometry: 8 kv heads x 256, G = 2) against
+    flash-attn's published definition (`sdpa_reference`, xattn.py:141-263) on both modalities' keys, image keys partly masked"""
+    HD, nkv, G, Lq, Na, Nb, za, zb = 256, 8, 2, 1, 3000, 1100, 5, 2
+    nq = nkv * G
+    start_b = (Na + 63) // 64 * 64
+    ntile = (start_b + Nb + 63) // 64
+    q = seeded((Lq, nq, HD), 150, dtype=dt)
+    ka = seeded((Na, nkv, HD), 151, dtype=dt); va = seeded((Na, nkv, HD), 152, dtype=dt)
+    kb = seeded((Nb, nkv, HD), 153, dtype=dt); vb = seeded((Nb, nkv, HD), 154, dtype=dt)
+    mask_a = torch.ones(Na, dtype=torch.bool); mask_a[5: Na: 7] = False
+    scale, cap = HD ** -0.5, 50.0
+    ref_a = _cross_ref(q, ka, va, mask_a, scale, cap, G)
+    ref_b = _cross_ref(q, kb, vb, torch.ones(Nb, dtype=torch.bool), scale, cap, G)
+    kc_a, vt_a = pack_kv_cache(ka, va, ntile, 0)
+    kc_b, vt_b = pack_kv_cache(kb, vb, ntile, start_b)
+    kc, vtc = dev(kc_a + kc_b), dev(vt_a + vt_b)                                    # disjoint regions of one cache (zeros elsewhere)
+    ma = torch.zeros((Na + 63) // 64 * 64, dtype=torch.uint8); ma[:Na] = mask_a.to(torch.uint8)
+    R = Lq * G
+    Rpad = 32
+    wa = hip.attn_cross_workspace(za, nkv, Rpad, HD, "cuda"); wb = hip.attn_cross_workspace(zb, nkv, Rpad, HD, "cuda")
+    hip.attn_cross2(dev(q.reshape(Lq, nq * HD).contiguous()), kc, vtc, dict(mask=dev(ma), opart=wa[0], ml=wa[1], key_start=0, n_keys=Na, zsplit=za),
+                    dict(mask=None, opart=wb[0], ml=wb[1], key_start=start_b, n_keys=Nb, zsplit=zb),
+                    R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD, ntile64=ntile, scale=scale, softcap=cap)
+    oa = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda"); ob = torch.zeros_like(oa)
+    hip.attn_merge2(wa[0], wa[1], oa, za, False, wb[0], wb[1], ob, zb, False, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+    report("attn_cross2 vs oracle: image keys", oa, ref_a, *tol(dt, 0.05, k=2))
+    report("attn_cross2 vs oracle: audio keys", ob, ref_b, *tol(dt, 0.05, k=2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("pos,window,dyn", [(70, 0, False), (200, 64, True), (5883, 0, False)])
+def test_attn_text_decode_merge2_vs_oracle(hip, dt, pos, window, dyn):
+    """vidi_attn_text_decode_merge2 at Gemma2-9B head geometry: (a) the T2T role = RoPE of the new q / k, cache append, causal (windowed)
+    softcapped attention over the text cache (modeling_gemma2.py:248-288 under FA2), (b) the merge role = the LSE identity over the
+    split-KV partials (`merge_partials`).  pos = 5883 is the largest position whose score plan fills the kernel's 64 KB of LDS exactly
+    (lcap 5884): the merge role's staging shares that allocation."""
+    nq, nkv, HD, B = 16, 8, 256, 1
+    G, kvd = nq // nkv, nkv * HD
+    Lmax = max(256, pos + 2) if not dyn else 256
+    if pos == 5883:
+        assert hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=HD, Lmax=Lmax, window=window, pos0=pos)
+        assert not hip.attn_text_decode_fits(nq=nq, nkv=nkv, HD=HD, Lmax=Lmax + 8, window=window, pos0=pos + 4)
+    qkv = seeded((B, nq * HD + 2 * kvd), 160, dtype=dt)
+    cos, sin = O.rope_cos_sin(torch.full((B, 1), pos), HD, 10000.0, dt)
+    kc0 = seeded((B, Lmax, kvd), 161, dtype=dt); vc0 = seeded((B, Lmax, kvd), 162, dtype=dt)
+    kmask = torch.ones((B, Lmax), dtype=torch.uint8); kmask[0, 2: pos: 5] = 0
+    sc, cap = HD ** -0.5, 50.0
+    # ---- oracle: T2T ----
+    qn = qkv[:, : nq * HD].float().view(B, 1, nq, HD).transpose(1, 2)
+    kn = qkv[:, nq * HD: nq * HD + kvd].float().view(B, 1, nkv, HD).transpose(1, 2)
+    vn = qkv[:, nq * HD + kvd:].float().view(B, 1, nkv, HD).transpose(1, 2)
+    qr, kr = O.apply_rope(qn, kn, cos.float(), sin.float())
+    kr = kr.to(dt).float()                                                          # the cache stores the dtype
+    kk = torch.cat([kc0[:, :pos].float().view(B, pos, nkv, HD).transpose(1, 2), kr], dim=2)
+    vv = torch.cat([vc0[:, :pos].float().view(B, pos, nkv, HD).transpose(1, 2), vn], dim=2)
+    kj = torch.arange(pos + 1)[None, :]
+    allowed = kj <= pos
+    if window:
+        allowed = allowed & (kj >= pos - window)
+    km = kmask[:, : pos + 1].bool().clone(); km[:, pos] = True
+    allowed = allowed[None, None] & km[:, None, None, :]
+    add = torch.zeros(allowed.shape); add[~allowed] = float("-inf")
+    ref_t = O.sdpa_reference(qr, O.repeat_kv(kk, G), O.repeat_kv(vv, G), sc, cap, add).transpose(1, 2).reshape(B, nq * HD)
+    # ---- oracle: merge of the partials (running maxima are kept in log2 units by the kernels) ----
+    R, Rpad, WA, WB = B * G, 32, 5, 3
+    g = torch.Generator().manual_seed(163)
+    parts, refs = [], []
+    for W in (WA, WB):
+        op = torch.randn((W, nkv, Rpad, HD), generator=g)
+        m2 = torch.randn((W, nkv, Rpad), generator=g) * 3
+        l = torch.rand((W, nkv, Rpad), generator=g) + 0.5
+        m2[0, :, 0] = float("-inf")                                                 # an empty partial
+        merged = O.merge_partials(op, m2 * math.log(2.0), l)                        # [nkv, Rpad, HD]
+        refs.append(merged[:, :R].reshape(nkv, B, G, HD).permute(1, 0, 2, 3).reshape(B, nq * HD))
+        parts.append((dev(op), dev(torch.stack([m2, l], dim=-1).contiguous())))
+    kc, vc = dev(kc0.clone()), dev(vc0.clone())
+    o_t = torch.full((B, nq * HD), float("nan"), dtype=dt, device="cuda")
+    oa = torch.full_like(o_t, float("nan")); ob = torch.full_like(o_t, float("nan"))
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device="cuda") if dyn else None
+    hip.attn_text_decode_merge2(dev(qkv), kc, vc, dev(kmask), dev(cos.reshape(B, HD).contiguous()), dev(sin.reshape(B, HD).contiguous()), o_t,
+                                (parts[0][0], parts[0][1], oa, WA, False), (parts[1][0], parts[1][1], ob, WB, False), R=R, Rpad=Rpad,
+                                B=B, Lmax=Lmax, nq=nq, nkv=nkv, HD=HD, window=window, scale=sc, softcap=cap, pos0=pos, pos_dev=pos_dev)
+    report("attn_text_decode_merge2 vs oracle: T2T", o_t, ref_t, *tol(dt, 0.3, k=2))
+    report("attn_text_decode_merge2 vs oracle: appended K", kc[:, pos].float().cpu(), kr.transpose(1, 2).reshape(B, kvd), *tol(dt, 1.0))
+    assert torch.equal(vc[:, pos].cpu().view(torch.int16), qkv[:, nq * HD + kvd:].contiguous().view(torch.int16))
+    report("attn_text_decode_merge2 vs oracle: image merge", oa, refs[0], *tol(dt, refs[0].std().item()))
+    report("attn_text_decode_merge2 vs oracle: audio merge", ob, refs[1], *tol(dt, refs[1].std().item()))

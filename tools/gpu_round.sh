@@ -10,8 +10,10 @@ what=${@:-tests smoke bench prof pmc}
 for w in $what; do
 case $w in
 tests)
-  rm -f $OUT/tol_audit.jsonl
-  VIDI_TEST_REPORT=$OUT/tol_audit.jsonl timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest.log 2>&1
+  rm -f $OUT/tol_audit.jsonl $OUT/reference_cli.jsonl
+  # VIDI_CLI_RECORD: tests/test_gpu_cli.py writes the answer strings of the reference's own inference.py (staged by __graft_entry__.build()
+  # under oracle/_ref/) and of vidi_amd/inference.py, both driving the HIP engine
+  VIDI_CLI_RECORD=$OUT/reference_cli.jsonl VIDI_TEST_REPORT=$OUT/tol_audit.jsonl timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest.log 2>&1
   echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $OUT/smoke.log ;;
@@ -32,8 +34,9 @@ attn)
   timeout 600 python tools/ab_attn.py vidi_amd/libvidi_hip.so $(ls vidi_amd/libvidi_hip_attn*.so) > $OUT/ab_attn.jsonl 2> $OUT/ab_attn.err; echo "attn rc=$?"; cat $OUT/ab_attn.jsonl ;;
 variants)
   # regression sweep of the other bench configurations on the current build (BASELINE configs[1], [4]-shape, Vidi-7B, fp16, graph decode)
-  for v in "--frames 300" "--queries 8" "--preset vidi_7b" "--dtype fp16" "--decode-graph"; do
-    n=$(echo $v | tr -d ' -' ); timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-preproc $v > $OUT/bench_$n.json 2> $OUT/bench_$n.err; echo "bench $v rc=$?"
+  # "cfg4": BASELINE configs[4] on one GPU — 30 min @2 fps (3 600 frames, 60 audio windows), 8 ragged prompts sharing the video, 128 decoded tokens
+  for v in "--frames 300" "--queries 8" "--preset vidi_7b" "--dtype fp16" "--decode-graph" "--fps 2 --queries 8 --ragged-prompts 24 52 --decode-steps 128"; do
+    n=$(echo $v | tr -d ' -' | cut -c1-24); timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-preproc $v > $OUT/bench_$n.json 2> $OUT/bench_$n.err; echo "bench $v rc=$?"
     python tools/show_bench.py $OUT/bench_$n.json 2>/dev/null | grep -E "value|stages"
   done ;;
 labres)
@@ -64,8 +67,10 @@ abln)
 dist2)
   # two ranks sharing the one GPU of the box (gloo transport; RCCL refuses two ranks on one device): the torchrun / sharded code path
   # of bench.py end to end, on a 10-minute video so both ranks fit
-  VIDI_DIST_BACKEND=gloo VIDI_FORCE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
-      bench.py --gpus 2 --frames 600 --steps 1 --warmup 1 --no-preproc > $OUT/bench_dist2.json 2> $OUT/bench_dist2.err; echo "dist2 rc=$?"
+  # (bench.py launches its own ranks: no torchrun on the command line)
+  VIDI_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --frames 600 --steps 1 --warmup 1 --no-preproc > $OUT/bench_dist2.json 2> $OUT/bench_dist2.err; echo "dist2 rc=$?"
+  VIDI_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --frames 600 --fps 2 --queries 8 --ragged-prompts 24 52 --decode-steps 64 --steps 1 --warmup 1 --no-preproc \
+      > $OUT/bench_dist2_q8.json 2> $OUT/bench_dist2_q8.err; echo "dist2 q8 rc=$?"
   timeout 600 python bench.py --frames 600 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
   python tools/show_bench.py $OUT/bench_dist2.json $OUT/bench_dist1.json 2>/dev/null | grep -E "value|stages" ;;
 chunk)
