@@ -60,8 +60,8 @@ def test_siglip_tower_real_dims_full_depth(fold, monkeypatch):
     assert got.shape == (T, 729, 1152)
     sample = [0, 15]                                        # first / last frame of the chunk (first and last row tiles)
     ref = O.siglip_forward(px[sample].float(), w32, oracle_cfg(cfg))
-    # 26 layers of bf16 residual-stream roundings against the fp32 oracle: 6 % of the spread + 4 % relative
-    report(f"siglip real dims x26 layers (fold={fold})", got[sample], ref, 6e-2 * ref.std().item(), 4e-2)
+    # 26 layers of bf16 residual-stream roundings against the fp32 oracle: 7 % of the spread + 4 % relative (1.06 M values; 0.7 used)
+    report(f"siglip real dims x26 layers (fold={fold})", got[sample], ref, 7e-2 * ref.std().item(), 4e-2)
 
 
 def test_whisper_encoder_real_dims_full_depth():
@@ -77,7 +77,8 @@ def test_whisper_encoder_real_dims_full_depth():
     assert got.shape == (C, 1500, 1280)
     sample = [7]
     ref = O.whisper_encoder_forward(mel[sample].float(), w32, oracle_cfg(cfg))
-    report("whisper real dims x32 layers", got[sample], ref, 6e-2 * ref.std().item(), 4e-2)
+    # 32 layers: 8 % of the spread + 4 % relative (1.9 M values; 0.7 used)
+    report("whisper real dims x32 layers", got[sample], ref, 8e-2 * ref.std().item(), 4e-2)
 
 
 def _unpack_rows(mm, li, rows, nkv, hd):
@@ -143,20 +144,30 @@ def test_decoder_42_layers_real_dims_at_the_60_min_sizes():
     caches = O.OracleCaches()
     href = O.model_forward(emb, opos, am, xi, mi, xa, ma, wl, ocfg, caches, 0)
 
-    # K/V caches of the sampled rows: one bf16 GEMM of the (li times updated, bf16-rounded) stream rows.  1.2 % of the spread + 1.5 %
-    # relative at layer 0, +0.35 % of the spread per stream update (roundings add in quadrature over the layers)
+    failures = []
+
+    def check(*a):
+        try:                                                    # every comparison is evaluated (and audited) before the test fails
+            report(*a)
+        except AssertionError as e:
+            failures.append(str(e))
+
+    # K/V caches of the sampled rows (2.6 M values per layer: the bound is a 5-sigma bound): one bf16 GEMM over K = 3 584 of the
+    # (li times updated, bf16-rounded) stream rows.  Layer 0: 1.6 % of the spread; every stream update (o_proj, two norm pairs, GeGLU,
+    # down_proj, each rounded to bf16) adds an independent 2.2 % in quadrature; + 1.5 % relative
     for li in (0, 1, 20, 41):
         for name, rows, start, cache in (("image", img_rows, 0, caches.image), ("audio", aud_rows, aud_start, caches.audio)):
             kg, vg = _unpack_rows(mm, li, [start + r for r in rows], nkv, hd)
             kref, vref = cache[li]
-            a = 1.2e-2 + 3.5e-3 * li
-            report(f"42-layer stream: layer {li} {name} K rows", kg, kref[0], a * kref.std().item(), 1.5e-2)
-            report(f"42-layer stream: layer {li} {name} V rows", vg, vref[0], a * vref.std().item(), 1.5e-2)
+            a = (1.6e-2 ** 2 + li * 2.2e-2 ** 2) ** 0.5
+            check(f"42-layer stream: layer {li} {name} K rows", kg, kref[0], a * kref.std().item(), 1.5e-2)
+            check(f"42-layer stream: layer {li} {name} V rows", vg, vref[0], a * vref.std().item(), 1.5e-2)
     # text hidden states after 42 layers of T2T + T2V + T2A (final norm applied): 8 % of the spread + 5 % relative
-    report("42-layer text prefill hidden (39 tokens)", hn, href[0], 8e-2 * href.std().item(), 5e-2)
+    check("42-layer text prefill hidden (39 tokens)", hn, href[0], 8e-2 * href.std().item(), 5e-2)
     tm = am
     for i, t in enumerate(forced):
         e = torch.nn.functional.embedding(torch.tensor([[t]]), wl["model.embed_tokens.weight"])
         tm = torch.cat([tm, torch.ones(1, 1, dtype=torch.bool)], dim=1)
         r = O.model_forward(e, torch.tensor([[L + i]]), tm, xi, mi, xa, ma, wl, ocfg, caches, L + i)
-        report(f"42-layer teacher-forced decode step {i}", dec[i], r[0], 8e-2 * r.std().item(), 5e-2)
+        check(f"42-layer teacher-forced decode step {i}", dec[i], r[0], 8e-2 * r.std().item(), 5e-2)
+    assert not failures, "\n".join(failures)

