@@ -48,7 +48,7 @@ def main():
             assert rc == 0, rc
         run_rm(); torch.cuda.synchronize()
         name = path + ":rm"
-        libs.append(name); outs[name], fns[name] = outs[path], run_rm
+        libs.append(name); outs[name], fns[name] = o, run_rm
         # the same kernel on a HEAD-MAJOR input ([3][B][H][N][D]: every head's key rows contiguous)
         hm = torch.randn((3 * B * H * N * D,), generator=g, device="cuda").to(torch.bfloat16)
         o2 = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
@@ -58,11 +58,13 @@ def main():
                    torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
         run_hm(); torch.cuda.synchronize()
-        libs.append(path + ":rm_headmajor"); outs[path + ":rm_headmajor"], fns[path + ":rm_headmajor"] = outs[path], run_hm
-    base = outs[libs[0]]
-    for path in [x for x in libs[1:] if ":rm" not in x]:
-        print(json.dumps({"lib": path, "bit_identical_to_first": bool(torch.equal(outs[path], base)),
-                          "max_abs_diff": float((outs[path].float() - base.float()).abs().max())}), flush=True)
+        libs.append(path + ":rm_headmajor"); outs[path + ":rm_headmajor"], fns[path + ":rm_headmajor"] = o2, run_hm
+    # every library's result per mode (Vt kernel, rm on row-major input, rm on head-major input) against the FIRST library's
+    for mode in ("", ":rm", ":rm_headmajor"):
+        same = [x for x in libs if (x.endswith(mode) if mode else ":rm" not in x)]
+        for path in same[1:]:
+            print(json.dumps({"lib": path, "bit_identical_to_first": bool(torch.equal(outs[path], outs[same[0]])),
+                              "max_abs_diff": float((outs[path].float() - outs[same[0]].float()).abs().max())}), flush=True)
     tot = {p: 0.0 for p in libs}
     rounds = 4
     for r in range(rounds):
