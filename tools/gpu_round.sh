@@ -13,7 +13,7 @@ tests)
   rm -f $OUT/tol_audit.jsonl $OUT/reference_cli.jsonl
   # VIDI_CLI_RECORD: tests/test_gpu_cli.py writes the answer strings of the reference's own inference.py (staged by __graft_entry__.build()
   # under oracle/_ref/) and of vidi_amd/inference.py, both driving the HIP engine
-  VIDI_CLI_RECORD=$OUT/reference_cli.jsonl VIDI_TEST_REPORT=$OUT/tol_audit.jsonl timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest.log 2>&1
+  VIDI_CLI_RECORD=$OUT/reference_cli.jsonl VIDI_TEST_REPORT=$OUT/tol_audit.jsonl timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 --durations=15 > $OUT/pytest.log 2>&1
   echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $OUT/smoke.log ;;
