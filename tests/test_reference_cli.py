@@ -179,3 +179,45 @@ def test_generate_eos_list_and_pad(monkeypatch):
     first = base[0].tolist().index(stop)
     out = model.generate(ids, images=video, audios=mel.unsqueeze(0), audio_sizes=[audio_size], max_new_tokens=12, eos_token_id=[999999, stop])
     assert out[0].tolist() == base[0, : first + 1].tolist()                        # stops right after the first listed eos
+
+
+def test_generate_hooks_logits_processor_stopping_criteria_streamer():
+    """HF generation hooks on the product's generate(): a logits processor that bans the greedy token changes the output from that step
+    on, a stopping criterion ends the rows it flags, a streamer receives every step's tokens; with transformers' own
+    LogitsProcessorList / StoppingCriteriaList objects (the types a caller of the reference model would pass)."""
+    from transformers import LogitsProcessorList, MaxLengthCriteria, StoppingCriteriaList
+    from transformers.generation.logits_process import SuppressTokensLogitsProcessor
+    model = build_model("tiny", seed=3)
+    frames, audio = media(12)
+    from vidi_amd import inference as OURS
+    cfg = model.config
+    ip, ap = processors(cfg)
+    video = OURS.process_images(frames, ip, cfg).unsqueeze(0)
+    mel, audio_size = OURS.process_audio(audio, ap)
+    ids = torch.tensor([[2, 21, 22, -200, 23, 24]])
+    kw = dict(images=video, audios=mel.unsqueeze(0), audio_sizes=[audio_size], max_new_tokens=8, eos_token_id=999999)
+    base = model.generate(ids, **kw)
+    assert base.shape == (1, 8)
+    banned = int(base[0, 2])
+    procs = LogitsProcessorList([SuppressTokensLogitsProcessor([banned], device="cpu")])
+    out = model.generate(ids, logits_processor=procs, **kw)
+    assert banned not in out[0].tolist()
+    first = base[0].tolist().index(banned)
+    assert out[0, :first].tolist() == base[0, :first].tolist() and int(out[0, first]) != banned
+    # HF's MaxLengthCriteria sees the NEW tokens only (the reference generates from inputs_embeds): stop after 3 of them
+    out = model.generate(ids, stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=3)]), **kw)
+    assert out.tolist() == base[:, :3].tolist()
+
+    class Collect:
+        def __init__(self):
+            self.toks, self.ended = [], False
+
+        def put(self, t):
+            self.toks.append(t.tolist())
+
+        def end(self):
+            self.ended = True
+
+    st = Collect()
+    out = model.generate(ids, streamer=st, **kw)
+    assert st.ended and [t[0] for t in st.toks] == out[0].tolist() == base[0].tolist()

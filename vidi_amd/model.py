@@ -279,30 +279,51 @@ class VidiForCausalLM:
         out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
         finished = torch.zeros(B, dtype=torch.bool, device=eng.dev)
         eos_t = torch.tensor(eos_list, dtype=torch.int64, device=eng.dev)
-        def pick(h):
+        # HF generation hooks (GenerationMixin semantics).  The reference drives HF's loop with `inputs_embeds` (gemma.py:646-655), so the
+        # `input_ids` these callables see hold the NEW tokens only ([B, 0] at the first step):
+        #   logits_processor  [callable(input_ids, scores) -> scores]   applied to the fp32 scores before the argmax / the sampling warpers
+        #   stopping_criteria [callable(input_ids, scores) -> bool | BoolTensor[B]]   rows it flags finish like rows that emitted EOS
+        #   streamer          .put(LongTensor[B]) per step, .end() after the last one
+        processors = list(kwargs.get("logits_processor") or [])
+        criteria = list(kwargs.get("stopping_criteria") or [])
+        streamer = kwargs.get("streamer")
+
+        def pick(h, step):
             logits, idx = eng.logits_argmax(h)                          # lm_head + final softcap (in place) + argmax
+            if processors:
+                logits = logits.float()
+                for proc in processors:
+                    logits = proc(out[:, :step], logits)
+                idx = torch.argmax(logits, dim=-1)
             if not do_sample:
-                return idx
+                return idx, logits
             from .sampling import sample, warp_logits
             return sample(warp_logits(logits, kwargs.get("temperature"), kwargs.get("top_k"), kwargs.get("top_p")),
-                          kwargs.get("generator"))
+                          kwargs.get("generator")), logits
 
         # sharded + sampling: the replicated text streams must draw the SAME token on every rank (each rank has its own RNG state, and
         # a divergent token or stop decision would mix partials of different queries in the next all-gather or strand a rank in it)
         sync_pick = do_sample and eng.world > 1
-        nxt = self._bcast0(pick(last)) if sync_pick else pick(last)
+        nxt, scores = pick(last, 0)
+        if sync_pick:
+            nxt = self._bcast0(nxt)
         n_done = 0
         # VIDI_DECODE_GRAPH=1: decode steps are replayed from a hipGraph (device-side cache position, no per-launch
         # host work).  Measured on MI355X (60-min video): replay 19.3 ms/token vs 21.0 eager, capture 126 ms —
         # it only pays for generations of ~80+ tokens, so it is opt-in; the sharded path stays eager.
-        use_graph = (not do_sample and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
+        use_graph = (not do_sample and not processors and not criteria and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
                      and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1" and (eng.world == 1 or self._backend() == "nccl"))
         replay = None
         for step in range(max_new):
             nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
             out[:, step] = nxt
             n_done = step + 1
+            if streamer is not None:
+                streamer.put(nxt.cpu())
             finished = finished | torch.isin(nxt, eos_t)
+            for crit in criteria:
+                stop = crit(out[:, :n_done], scores)
+                finished = finished | (stop.to(finished.device).bool() if torch.is_tensor(stop) else torch.full_like(finished, bool(stop)))
             if bool(finished.all()) or step == max_new - 1:          # one D2H sync per token, like HF's stopping criteria
                 break
             if use_graph:
@@ -315,7 +336,11 @@ class VidiForCausalLM:
             posn = ts.n_valid.clone()                                  # HF: position = cumsum(mask) - 1 of the new token
             ts.n_valid += 1
             hn = eng.text_forward(emb, posn, ts, mm_state, Lq=1)
-            nxt = self._bcast0(pick(hn)) if sync_pick else pick(hn)
+            nxt, scores = pick(hn, step + 1)
+            if sync_pick:
+                nxt = self._bcast0(nxt)
+        if streamer is not None:
+            streamer.end()
         return out[:, :n_done]
 
     # ---- forward (gemma.py:484-601): prefill-style call returning logits ----
