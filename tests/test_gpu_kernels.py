@@ -913,17 +913,24 @@ def test_gemv_norm2_vs_oracle(hip, dt, M, K, N, nsrc, glu):
     srcs = [seeded((M, K), 140 + i, dtype=dt) for i in range(3)]
     res = seeded((M, K), 143, dtype=dt)
     w1 = seeded((K,), 144, 0.1, dtype=dt); w2 = seeded((K,), 145, 0.1, dtype=dt)
-    s = sum(t.float() for t in srcs[:nsrc])
-    y1_ref = res.float() + O.gemma_rmsnorm(s, w1.float(), eps)
+    # the reference's rounding points: `text + image + audio` are dtype adds (gemma.py:236), Gemma2RMSNorm computes in fp32 and rounds its
+    # output once (modeling_gemma2.py:55-63), the residual add rounds again (gemma.py:237)
+    s = srcs[0].float()
+    for t in srcs[1:nsrc]:
+        s = (s + t.float()).to(dt).float()
+    y1_ref = res.float() + O.gemma_rmsnorm(s, w1.float(), eps).to(dt).float()
     x_ref = O.gemma_rmsnorm(y1_ref.to(dt).float(), w2.float(), eps)               # the stream is stored in the dtype between the norms
     if glu:
         gate = seeded((N, K), 146, 0.05, dtype=dt); up = seeded((N, K), 147, 0.05, dtype=dt)
         w = torch.stack([gate.view(N // 32, 32, K), up.view(N // 32, 32, K)], dim=1).reshape(2 * N, K).contiguous()     # engine._pack layout
         xr = x_ref.to(dt).float()
-        out_ref = O.gelu_tanh(O.linear(xr, gate.float())) * O.linear(xr, up.float())
+        g_ref, u_ref = O.linear(xr, gate.float()), O.linear(xr, up.float())
+        out_ref = O.gelu_tanh(g_ref) * u_ref
+        lin_std = g_ref.std().item()
     else:
         w = seeded((N, K), 146, 0.05, dtype=dt)
         out_ref = O.linear(x_ref.to(dt).float(), w.float())
+        lin_std = out_ref.std().item()
     y1 = torch.full((M, K), float("nan"), dtype=dt, device="cuda"); out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
     a, b, c = (dev(t) for t in srcs)
     args = (a, b if nsrc >= 2 else None, c if nsrc >= 3 else None, dev(res), dev(w1), dev(w2), y1, dev(w), out)
@@ -931,9 +938,21 @@ def test_gemv_norm2_vs_oracle(hip, dt, M, K, N, nsrc, glu):
         hip.gemv_glu_norm2(*args, eps=eps, act=hip.ACT_GELU_TANH)
     else:
         hip.gemv_norm2(*args, eps=eps)
-    # residual stream: one norm + one add, rounded once; projection: K = 3584 fp32 accumulation of dtype-rounded normalised rows
-    report("gemv_norm2 vs oracle: residual stream", y1, y1_ref, *tol(dt, y1_ref.std().item()))
-    report("gemv_norm2 vs oracle: projection", out, out_ref, *tol(dt, out_ref.std().item(), k=2 if glu else 1))
+    # residual stream: one norm + one add, rounded once
+    report("gemv_norm2 vs oracle: residual stream", y1, y1_ref, *tol(dt, y1_ref.std().item(), k=1.5))
+    # projection: its input row is the kernel's own normalised row rounded to the dtype, which differs from the oracle's rounding of ITS
+    # row by an ulp in a fraction of the K = 3 584 elements, on top of the output rounding: a linear output is within 2 % (bf16; 0.4 %
+    # fp16) of the outputs' spread + the usual relative part (a 5-sigma bound over 8-57 k outputs)
+    lin = (2e-2 if dt == torch.bfloat16 else 4e-3) * lin_std
+    if glu:
+        # gelu(gate) * up: the error of each factor is scaled by the other one, so the bound is per element:
+        #   |err| <= lin * (|gelu(gate)| + 1.13 |up|) + relative part     (1.13 = max |gelu'|)
+        scale = (O.gelu_tanh(g_ref).abs() + 1.13 * u_ref.abs() + 1e-3)
+        rt = tol(dt, 1.0, k=2)[1]
+        report("gemv_norm2 vs oracle: projection (error / per-element scale)", (out.float().cpu() - out_ref) / (lin * scale + rt * out_ref.abs()),
+               torch.zeros_like(out_ref), 1.0, 0.0)
+    else:
+        report("gemv_norm2 vs oracle: projection", out, out_ref, lin, tol(dt, 1.0)[1])
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -963,8 +982,8 @@ def test_attn_cross2_vs_oracle(hip, dt):
                     R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD, ntile64=ntile, scale=scale, softcap=cap)
     oa = torch.zeros((Lq, nq * HD), dtype=dt, device="cuda"); ob = torch.zeros_like(oa)
     hip.attn_merge2(wa[0], wa[1], oa, za, False, wb[0], wb[1], ob, zb, False, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
-    report("attn_cross2 vs oracle: image keys", oa, ref_a, *tol(dt, max(0.05, ref.std().item()), k=2))
-    report("attn_cross2 vs oracle: audio keys", ob, ref_b, *tol(dt, max(0.05, ref.std().item()), k=2))
+    report("attn_cross2 vs oracle: image keys", oa, ref_a, *tol(dt, max(0.05, ref_a.std().item()), k=2))
+    report("attn_cross2 vs oracle: audio keys", ob, ref_b, *tol(dt, max(0.05, ref_b.std().item()), k=2))
 
 
 @pytest.mark.parametrize("dt", DTYPES)

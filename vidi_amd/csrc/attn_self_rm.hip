@@ -33,32 +33,9 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
                                        // Measured (tools/ab_attn.py): 228 VGPRs -> 2 waves/SIMD, the compiler runs the two chains back
                                        // to back, 399 vs 636 useful TFLOP/s — the in-wave overlap needs a hand-built schedule.
 
-// Block geometry and tile hand-over (build knobs; tools/build_variant.sh + tools/ab_attn.py time the alternatives on one box):
-//   VIDI_ATTN_RM_NW    waves per block (32 queries each): 4 (default) or 6 (192-query blocks: 729 = 4 blocks, one K / V tile DMA serves six waves)
-//   VIDI_ATTN_RM_RING  K / V ring depth.  2 (default): ONE block barrier per 64-key tile says both "tile t has landed" and "tile t-1's
-//                      buffer is free" — every wave waits for the slowest wave of its block at every tile, while each of them shares its
-//                      SIMD with waves of other blocks (the per-tile rendezvous costs 27 % of the kernel, profiles/r2_notes.md).
-//                      >= 4: the hand-over goes through two LDS counters per ring slot instead (no barrier in the loop): a wave adds 1 to
-//                      ready[slot] once ITS pieces of the tile have landed (its own vmcnt) and 1 to done[slot] after its last read of the
-//                      tile; a reader polls ready[slot] = NW x (uses of the slot so far), a writer polls done[slot] before it DMAs over
-//                      the slot.  Tile t + 2 is requested in iteration t into the slot tile t + 2 - RING left, so with RING = 4 a wave
-//                      may run one tile ahead of or behind the slowest wave of its block before it has to wait.  LDS operations of one
-//                      wave execute in order (the counter add follows the reads it covers) and an LDS-DMA piece is in LDS when the
-//                      issuing wave's vmcnt says so.
-#ifndef VIDI_ATTN_RM_NW
-#define VIDI_ATTN_RM_NW 4
-#endif
-#ifndef VIDI_ATTN_RM_RING
-#define VIDI_ATTN_RM_RING 2
-#endif
-
 template <typename T, int D>
-__global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(AttnSelfRmParams p) {
-    constexpr int NW = VIDI_ATTN_RM_NW, NT = 64 * NW, NRING = VIDI_ATTN_RM_RING;
-    constexpr bool FLAGS = NRING > 2;
-    static_assert(NRING == 2 || NRING >= 4, "ring: 2 (barrier per tile) or >= 4 (counter hand-over)");
-    static_assert(NW == 4 || NRING > 2, "the barrier form keeps the 4-wave piece mapping");
-    constexpr int QS = VIDI_ATTN_RM_QS, QB = 32 * NW * QS;
+__global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
+    constexpr int QS = VIDI_ATTN_RM_QS, QB = 128 * QS;
     constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
     constexpr int NCH = D / 8;                 // 16-byte chunks per head row
     constexpr int DT = (D + 31) / 32;          // 32-wide output d tiles
@@ -87,9 +64,8 @@ __global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(Attn
     // the per-read immediate offsets apply to them too): the sum of the T-rounded P comes out of the matrix pipe, no VALU adds, no patch.
     constexpr bool kOnesRow = (DT * 32 > D);
     constexpr int CROWB = TAILC ? 16 : MROWB, CBYTES = kOnesRow ? 64 * CROWB : 0;
-    constexpr int RING = NRING * BUF > 32 * NW * ORW ? NRING * BUF : 32 * NW * ORW;
-    constexpr int FBYTES = FLAGS ? 2 * NRING * 4 : 0;                    // ready[NRING], done[NRING]
-    __shared__ __attribute__((aligned(16))) char smem[RING + CBYTES + FBYTES];   // K/V ring (+ the ones / zeros constant rows, + the hand-over counters)
+    constexpr int RING = 2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW;
+    __shared__ __attribute__((aligned(16))) char smem[RING + CBYTES];   // 2-deep K/V ring (+ the ones / zeros constant rows)
     auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +99,7 @@ __global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(Attn
     u32x4 qf[QS][KS];
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
-        const int qc = min(qt * QB + qs * 32 * NW + wave * 32 + l31, p.N - 1);
+        const int qc = min(qt * QB + qs * 128 + wave * 32 + l31, p.N - 1);
         const u16* qrow = p.QKV + (size_t)b * p.bs + (size_t)h * p.hs + (size_t)qc * p.ld;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -152,47 +128,45 @@ __global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(Attn
         const int row = pc * (64 / MCH) + lane / MCH;
         vrow[j] = row; vcol[j] = ((lane % MCH) ^ vswz(row)) * 8;
     }
-    // counter hand-over form: the NCH + MCH (+ 1) one-KB pieces of a tile are dealt round-robin to the waves (piece pp -> wave pp % NW);
-    // slot s of this wave is piece s * NW + wave: a K piece (64 chunks of the [64][NCH] image), a V main piece or the V tail piece
-    constexpr int NPIECE = NCH + MCH + (TAILC ? 1 : 0), PSLOTS = (NPIECE + NW - 1) / NW;
-    int prow[FLAGS ? PSLOTS : 1], pcol[FLAGS ? PSLOTS : 1], pdst[FLAGS ? PSLOTS : 1];
-    const u16* pbase[FLAGS ? PSLOTS : 1];
-    if constexpr (FLAGS) {
+#ifndef VIDI_ATTN_RM_SRD
+#define VIDI_ATTN_RM_SRD 0             // 1: tile DMA through buffer descriptors — the per-lane byte offsets are tile-invariant VGPRs and the tile
+#endif                                 // advance is a SCALAR offset, so a piece costs no vector address arithmetic (the pointer form spends
+                                       // v_add + v_min + v_mad_i64 + v_lshl_add per piece: ~20 of the loop's ~150 VALU instructions per tile);
+                                       // key rows past N are outside the descriptor's range and read as zeros instead of repeating row N - 1
+                                       // (both finite; their scores are masked to -inf and their probabilities are exactly 0)
+    __amdgpu_buffer_rsrc_t srdK, srdV;
+    unsigned kvo[KRND], vvo[VRND], tvo = 0;
+    if constexpr (VIDI_ATTN_RM_SRD != 0) {
+        const unsigned bytes = (unsigned)(((size_t)(p.N - 1) * p.ld + D) * 2);
+        srdK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase_ptr, 0, (int)bytes, 0x00020000);
+        srdV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase_ptr, 0, (int)bytes, 0x00020000);
 #pragma unroll
-        for (int sl = 0; sl < PSLOTS; ++sl) {
-            const int pp = sl * NW + wave;
-            if (pp < NCH) {
-                const int i = pp * 64 + lane, row = i / NCH, cs = i % NCH;
-                prow[sl] = row; pcol[sl] = (cs ^ kswz(row)) * 8; pdst[sl] = pp * 1024; pbase[sl] = kbase_ptr;
-            } else if (pp < NCH + MCH) {
-                const int pc = pp - NCH, row = pc * (64 / MCH) + lane / MCH;
-                prow[sl] = row; pcol[sl] = ((lane % MCH) ^ vswz(row)) * 8; pdst[sl] = KBYTES + pc * 1024; pbase[sl] = vbase_ptr;
-            } else {
-                prow[sl] = lane; pcol[sl] = MAINC; pdst[sl] = KBYTES + VMAIN; pbase[sl] = vbase_ptr;
-            }
-        }
+        for (int j = 0; j < KRND; ++j) kvo[j] = (unsigned)(krow[j] * p.ld + kcol[j]) * 2u;
+#pragma unroll
+        for (int j = 0; j < VRND; ++j) vvo[j] = (unsigned)(vrow[j] * p.ld + vcol[j]) * 2u;
+        tvo = (unsigned)(lane * p.ld + MAINC) * 2u;
     }
-    auto issue_dma_pieces = [&](int kb, int bufi) {
+    auto issue_dma_srd = [&](int kb, int bufi) {
+        char* sK = smem + bufi * BUF;
+        char* sV = sK + KBYTES;
+        const unsigned so = (unsigned)kb * (unsigned)p.ld * 2u;                 // wave-uniform: the tile's first key row
 #pragma unroll
-        for (int sl = 0; sl < PSLOTS; ++sl)
-            if (sl * NW + wave < NPIECE)
-                glds16(pbase[sl] + (size_t)min(kb + prow[sl], p.N - 1) * p.ld + pcol[sl], smem + bufi * BUF + pdst[sl]);
-    };
-    // hand-over counters: ready[0 .. NRING), done[NRING .. 2 NRING) — plain LDS instructions on their LDS byte address (a volatile
-    // generic pointer would be read with flat loads), the poll's wait inside the statement
-    const unsigned flg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + RING + CBYTES);
-    auto lds_count_at_least = [&](int idx, unsigned want) {                   // wave-uniform poll
-        while (true) {
-            unsigned v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flg + 4u * (unsigned)idx) : "memory");
-            if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= want) break;
-            __builtin_amdgcn_s_sleep(1);
+        for (int j = 0; j < KRND; ++j) {
+            const int ib = j * 256 + wave * 64;
+            if (ib < 64 * NCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdK, (__attribute__((address_space(3))) void*)(sK + ib * 16), 16, kvo[j], so, 0, 0);
         }
-    };
-    auto lds_count_add = [&](int idx) {
-        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(flg + 4u * (unsigned)idx), "v"(1u) : "memory");
+#pragma unroll
+        for (int j = 0; j < VRND; ++j) {
+            const int pc = j * 4 + wave;
+            if (pc < MCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sV + pc * 1024), 16, vvo[j], so, 0, 0);
+        }
+        if constexpr (TAILC != 0) {
+            if (wave == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sV + VMAIN), 16, tvo, so, 0, 0);
+        }
     };
     auto issue_dma = [&](int kb, int bufi) {
+        if constexpr (VIDI_ATTN_RM_SRD != 0) { issue_dma_srd(kb, bufi); return; }
         char* sK = smem + bufi * BUF;
         char* sV = sK + KBYTES;
 #pragma unroll
@@ -248,41 +222,21 @@ __global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(Attn
     const int ksw = kswz(l31);
     if constexpr (kOnesRow) {                            // constant rows: {1, 0, 0, 0 | 0 ...}
         const unsigned one1 = (unsigned)T::from_f32(1.0f);
-        for (int i = tid; i < CBYTES / 4; i += NT) *(unsigned*)(smem + RING + i * 4) = (i % (CROWB / 4) == 0) ? one1 : 0u;
+        for (int i = tid; i < CBYTES / 4; i += 256) *(unsigned*)(smem + RING + i * 4) = (i % (CROWB / 4) == 0) ? one1 : 0u;
     }
     constexpr int ROWD = D - (DT - 1) * 32;
-    if constexpr (FLAGS) {
-        if (tid < 2 * NRING) ((unsigned*)(smem + RING + CBYTES))[tid] = 0u;
-        __syncthreads();                                  // the counters (and the constant rows) exist before anyone adds or polls
-        issue_dma_pieces(0, 0);
-        if (ntiles > 1) issue_dma_pieces(64, 1);
-    } else {
-        issue_dma(0, 0);
-    }
+    issue_dma(0, 0);
 
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
-        const int slot = FLAGS ? t % NRING : (t & 1);
-        if constexpr (FLAGS) {
-            wait_vmcnt<0>();                              // every piece this wave has requested (tiles <= t + 1, asked for >= one tile ago) is in LDS
-            if (t == 0) lds_count_add(0);
-            if (t + 1 < ntiles) lds_count_add((t + 1) % NRING);
-            if (t + 2 < ntiles) {
-                const int s2 = (t + 2) % NRING;
-                lds_count_at_least(NRING + s2, (unsigned)(NW * ((t + 2) / NRING)));     // every wave has finished with the tile the slot held
-                issue_dma_pieces(kb + 128, s2);
-            }
-            lds_count_at_least(slot, (unsigned)(NW * (t / NRING + 1)));                 // tile t: every wave's pieces have landed
-        } else {
-            wait_vmcnt<0>();                              // my pieces of tile t have landed ...
-            __syncthreads();                              // ... everyone's have, and tile t-1's buffer is free
-            if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
-        }
-        const char* sK = smem + slot * BUF;
+        wait_vmcnt<0>();                                  // my pieces of tile t have landed ...
+        __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
+        if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
+        const char* sK = smem + (t & 1) * BUF;
         const __attribute__((address_space(3))) char* lds0 = (const __attribute__((address_space(3))) char*)smem;
         int va[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + slot * vstep[dt];
+        for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + (t & 1) * vstep[dt];
         const bool tail = (kb + 64 > p.N);
 
 #pragma unroll
@@ -349,7 +303,6 @@ __global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(Attn
             }
         }
       }
-        if constexpr (FLAGS) lds_count_add(NRING + slot);   // this wave's reads of tile t are behind it (LDS operations of a wave execute in order)
     }
 
 #pragma unroll
@@ -381,9 +334,9 @@ __global__ __launch_bounds__(64 * VIDI_ATTN_RM_NW) void attn_self_rm_kernel(Attn
                 }
         }
         __syncthreads();
-        for (int i = tid; i < 32 * NW * NCH; i += NT) {
+        for (int i = tid; i < 128 * NCH; i += 256) {
             const int row = i / NCH, c = i % NCH;
-            const int qq = qt * QB + qs * 32 * NW + row;
+            const int qq = qt * QB + qs * 128 + row;
             if (qq < p.N)
                 *(u32x4*)(p.O + ((size_t)b * p.N + qq) * p.ldo + h * D + c * 8) = *(const u32x4*)(smem + row * ORW + c * 16);
         }
@@ -394,9 +347,8 @@ int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipS
     if (p.B <= 0 || p.N <= 0 || p.H <= 0) return VIDI_ERR_SHAPE;
     if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8) || (p.bs % 8) || (p.hs % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)p.QKV & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
-    constexpr int QB = 32 * VIDI_ATTN_RM_NW * VIDI_ATTN_RM_QS;
-    const dim3 grid(((p.N + QB - 1) / QB) * p.H * p.B);
-#define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD>), grid, dim3(64 * VIDI_ATTN_RM_NW), 0, st, p)
+    const dim3 grid(((p.N + 128 * VIDI_ATTN_RM_QS - 1) / (128 * VIDI_ATTN_RM_QS)) * p.H * p.B);
+#define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD>), grid, dim3(256), 0, st, p)
     if (dtype == VIDI_DT_BF16) {
         if (D == 72) LAUNCH(BF16, 72); else if (D == 64) LAUNCH(BF16, 64); else if (D == 16) LAUNCH(BF16, 16);
         else if (D == 32) LAUNCH(BF16, 32); else return VIDI_ERR_SHAPE;
