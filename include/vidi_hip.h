@@ -252,6 +252,13 @@ int vidi_norm(int mode, const void* X, const float* XF32, const void* W, const v
 int vidi_resid_norm2(const void* A, const void* B, const void* C, const void* Res, const void* W1, const void* W2, void* Y1, void* Y2,
                      int rows, int H, long long ld, float eps, int dtype, void* stream);
 
+/* SiglipVisionEmbeddings (TP siglip/modeling_siglip.py:124-130, 178): Conv2d(3, N, kernel = stride = P, valid) over px:[T,3,S,S] + bias
+ * + position table pos:[(S/P)^2, N] -> Y:[T*(S/P)^2, N], ONE launch of the persistent GEMM whose activation loader reads the NCHW
+ * pixels directly (16-byte LDS-DMA pieces of 8 contiguous pixels; no im2col buffer).  W:[N, K] is the conv weight re-laid as
+ * k = (c*P + dy)*16 + dx (dx < P; columns dx >= P and k >= 3*P*16 are zero), K a multiple of 64 >= 3*P*16, P <= 16. */
+int vidi_patch_embed(const void* px, const void* W, const void* bias, const void* pos, void* Y, int T, int S, int P, int N, int K,
+                     int ldw, int ldy, int ldpos, int dtype, void* stream);
+
 /* ---- data movement / elementwise -------------------------------------------------------------- */
 /* SiglipVisionEmbeddings conv as GEMM input (TP siglip:124-130,178): px:[T,3,S,S] -> A:[T*(S/P)^2,Kpad] */
 int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, int dtype, void* stream);

@@ -15,6 +15,7 @@ HOT = {
     "gemm_w4_f16.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_modes.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_lnf.resources.txt": ["gemm_w4_kernel"],
+    "gemm_w4_patch.resources.txt": ["gemm_w4_kernel"],
     "attn_self.resources.txt": ["attn_self_kernel"],
     "attn_self_rm.resources.txt": ["attn_self_rm_kernel"],
     "attn_cross.resources.txt": ["attn_cross_kernel", "attn_cross2_kernel", "attn_merge"],

@@ -574,6 +574,34 @@ def test_im2col_matches_conv(hip):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,S,P,Hv", [(16, 384, 14, 1152), (3, 384, 14, 1152), (1, 98, 14, 64), (5, 98, 14, 96), (2, 64, 16, 32), (3, 40, 8, 64)])
+def test_patch_embed_reads_pixels_directly(hip, dt, T, S, P, Hv):
+    """vidi_patch_embed — SiglipVisionEmbeddings' Conv2d(kernel = stride = P, valid) + bias + position table with the GEMM's loader
+    gathering the patches from the NCHW pixels (4-byte-aligned 16-byte DMA pieces, 16-pixel runs whose surplus columns meet zero
+    weights) — against F.conv2d in fp32 on the same rounded inputs, and against the im2col + GEMM form it replaces.  SigLIP-so400m dims
+    (384 px, 14-px patches -> 27 x 27, 6 unused pixel columns / rows), the tiny tower, a patch as wide as the run (P = 16) and P = 8."""
+    side = S // P
+    n = side * side
+    px = seeded((T, 3, S, S), 170, dtype=dt); w = seeded((Hv, 3, P, P), 171, 0.05, dtype=dt)
+    b = seeded((Hv,), 172, 0.1, dtype=dt); pos = seeded((n, Hv), 173, 0.1, dtype=dt)
+    conv = F.conv2d(px.float(), w.float(), stride=P).flatten(2).transpose(1, 2).reshape(T * n, Hv) + b.float()
+    ref = conv.to(dt).float() + pos.float().repeat(T, 1)          # the conv output is a dtype tensor before the table is added (siglip:178)
+    w16 = hip.patch_embed_weight(dev(w), P)
+    assert w16.shape == (Hv, (3 * P * 16 + 63) // 64 * 64) and float(w16.view(Hv, -1)[:, 3 * P * 16:].abs().max() if w16.shape[1] > 3 * P * 16 else 0) == 0.0
+    out = torch.full((T * n, Hv), float("nan"), dtype=dt, device="cuda")
+    hip.patch_embed(dev(px), w16, dev(b), dev(pos), out, T=T, S=S, P=P)
+    report("patch_embed vs conv2d", out, ref, *tol(dt, ref.std().item()))
+    # the form it replaces: im2col buffer + GEMM with the bias / position-table epilogue (same products, another summation order)
+    kp = (3 * P * P + 63) // 64 * 64
+    A = torch.zeros((T * n, kp), dtype=dt, device="cuda")
+    hip.im2col_patch(dev(px), A, T=T, S=S, P=P, Kpad=kp)
+    wp = torch.zeros((Hv, kp), dtype=dt, device="cuda"); wp[:, : 3 * P * P] = dev(w).reshape(Hv, -1)
+    old = hip.gemm(A, wp, dev(b), residual=dev(pos), rmod=n)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    report("patch_embed vs im2col + gemm", out, old.float(), 2 * ulp * ref.std().item(), 2 * ulp)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("side,hw", [(27, (28, 28)), (27, (10, 10)), (27, (26, 26)), (7, (28, 28)), (7, (10, 10))])
 def test_pool_s2d(hip, dt, side, hw):
     T, C, m = 3, 16, 2

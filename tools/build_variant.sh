@@ -12,3 +12,5 @@ obj=/tmp/vidi_variant_${name}.o
 objs=$(ls vidi_amd/csrc/build/*.o | grep -v "/${src%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vidi_amd/libvidi_hip_${name}.so $objs $obj
 echo vidi_amd/libvidi_hip_${name}.so
+# a variant that does not load (e.g. a kernel whose host launch stub was dropped) would only show on the GPU box: check here
+python -c "import ctypes, sys; ctypes.CDLL(sys.argv[1])" vidi_amd/libvidi_hip_${name}.so

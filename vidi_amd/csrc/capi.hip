@@ -44,6 +44,22 @@ int vidi_gemm(const void* X, const void* W, const void* bias, void* Y, const voi
     return vidi_gemm_dispatch(p, batch, MODE_PLAIN, repkv, tile_cfg, dtype, (hipStream_t)stream);
 }
 
+int vidi_patch_embed(const void* px, const void* W, const void* bias, const void* pos, void* Y, int T, int S, int P, int N, int K,
+                     int ldw, int ldy, int ldpos, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!px || !W || !bias || !pos || !Y) return VIDI_ERR_ARG;
+    if (T <= 0 || S <= 0 || P <= 0 || P > 16 || S < P) return VIDI_ERR_SHAPE;
+    if ((ldw % 8) || (ldy % 8) || (ldpos % 8)) return VIDI_ERR_ALIGN;
+    if (((uintptr_t)px & 3) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)pos & 15)) return VIDI_ERR_ALIGN;
+    const int side = S / P, n = side * side;
+    GemmParams p = base_params(px, W, bias, Y, pos, T * n, N, K, 0, ldw, ldy, ldpos, n);
+    p.pe_S = S; p.pe_P = P; p.pe_side = side;
+    p.pe_nmagic = (unsigned)(0x100000000ull / (unsigned)n) + 1u;
+    p.pe_smagic = (unsigned)(0x100000000ull / (unsigned)side) + 1u;
+    if ((unsigned long long)T * n * (unsigned long long)n >= 0x100000000ull) return VIDI_ERR_SHAPE;      // exact m / n by multiply-high
+    return vidi_w4_patch(p, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
                     int tile_cfg, int dtype, void* stream) {
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error

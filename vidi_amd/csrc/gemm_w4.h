@@ -51,7 +51,8 @@ struct W4Geom {
 template <bool BIAS, int ACT, int RES, bool LNF = false, bool STATS = false, bool HEADS = false>
 struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF, stats = STATS, heads = HEADS; };
 
-template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone>
+// PATCH: the X operand is gathered from NCHW pixels (GemmParams::pe_*): the SigLIP patch embedding without an im2col buffer
+template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone, bool PATCH = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     using G = W4Geom;
     constexpr int BN = G::BN, BM = G::BM, BK = G::BK, NT = G::NT, TN = G::TN, TM = G::TM, ROWB = G::ROWB, STAGE_BYTES = G::STAGE_BYTES;
@@ -92,6 +93,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         const unsigned nrec = bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes;
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
     };
+    // PATCH: per-lane byte offsets of the lane's 8 X rows (piece q covers row q*32 + r0) of the current / the next tile inside the pixel
+    // tensor — (frame, patch row, patch column) -> first pixel of the patch in channel 0, + the lane's half of the 16-pixel run — and the
+    // per-slice part: the lane's chunk cg0 of slice ks belongs to patch line rr = 4 ks + (cg0 >> 1) = (channel, dy)
+    unsigned pxo[PATCH ? 8 : 1], pxn[PATCH ? 8 : 1];
+    auto patch_rows = [&](int tm0, unsigned* dst) {
+        if constexpr (PATCH) {
+            const unsigned n = (unsigned)(p.pe_side * p.pe_side);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned m = (unsigned)min(tm0 + q * 32 + r0, p.M - 1);        // rows past M repeat the last patch (masked in the epilogue)
+                const unsigned f = __umulhi(m, p.pe_nmagic), rem = m - f * n;
+                const unsigned py = __umulhi(rem, p.pe_smagic), px = rem - py * (unsigned)p.pe_side;
+                dst[q] = (((f * 3u * (unsigned)p.pe_S + py * (unsigned)p.pe_P) * (unsigned)p.pe_S + px * (unsigned)p.pe_P) << 1) + (unsigned)(cg0 & 1) * 16u;
+            }
+        }
+    };
+    auto patch_koff = [&](int ks) -> unsigned {
+        const int rr = 4 * ks + (cg0 >> 1);
+        const int c = (rr >= p.pe_P ? 1 : 0) + (rr >= 2 * p.pe_P ? 1 : 0);
+        return (unsigned)(rr * p.pe_S + c * (p.pe_S - p.pe_P) * p.pe_S) << 1;            // channel c, line dy = rr - c P: (c S + dy) S pixels
+    };
     auto locate = [&](int vb, int& tm0, int& tn0, int& tbz) {
         const int b1 = vb % tiles_1;
         tbz = vb / tiles_1;
@@ -105,6 +127,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if constexpr (LAB::no_dma) return;
         constexpr bool NEXT = decltype(next_t)::value;
         const int k0 = ks * BK;
+        if constexpr (PATCH) {
+            if (q < 8) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(buf + BN * ROWB + (q * NT + wave * 64) * 16), 16,
+                                                         (int)((NEXT ? pxn[q] : pxo[q]) + patch_koff(ks)), 0, 0, 0);
+                return;
+            }
+        }
         if (q < 8) {
             int kx = k0;
             if constexpr (REPKV) kx = (k0 / (p.rep_g * p.rep_hd)) * p.rep_hd + (k0 % p.rep_hd);      // rep_hd % 64 == 0: the whole 64-wide slice maps together
@@ -476,7 +505,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     int vb = blockIdx.x;
     locate(vb, m0, n0, bz);
     srdW = make_srd(p.W + (size_t)n0 * p.ldw, p.N - n0, p.ldw);
-    srdX = make_srd(p.X + (long long)bz * p.bsX + (size_t)m0 * p.ldx, p.M - m0, p.ldx);
+    if constexpr (PATCH) {
+        // ONE descriptor over the whole pixel tensor (the row -> patch map is in the per-lane offsets): T * 3 * S * S pixels < 4 GB
+        const unsigned long long bytes = (unsigned long long)(p.M / (p.pe_side * p.pe_side)) * 3ull * p.pe_S * p.pe_S * 2ull;
+        srdX = srdXn = rsrc_of(p.X, bytes);
+        patch_rows(m0, pxo);
+    } else {
+        srdX = make_srd(p.X + (long long)bz * p.bsX + (size_t)m0 * p.ldx, p.M - m0, p.ldx);
+    }
     // head of the block's first tile: slices 0 and 1 in flight, slice 0 landed, its step-0 fragments in registers
 #pragma unroll
     for (int q = 0; q < 16; ++q) piece(smem, 0, q, FF{});
@@ -495,7 +531,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if (has_next) {
             locate(nvb, nm0, nn0, nbz);
             srdWn = make_srd(p.W + (size_t)nn0 * p.ldw, p.N - nn0, p.ldw);
-            srdXn = make_srd(p.X + (long long)nbz * p.bsX + (size_t)nm0 * p.ldx, p.M - nm0, p.ldx);
+            if constexpr (PATCH) patch_rows(nm0, pxn);
+            else srdXn = make_srd(p.X + (long long)nbz * p.bsX + (size_t)nm0 * p.ldx, p.M - nm0, p.ldx);
         }
         body(0, TT{}, FF{}, true);
         int kt = 1;
@@ -516,6 +553,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         stamp(3);
         if (!has_next) break;
         vb = nvb; m0 = nm0; n0 = nn0; bz = nbz; srdW = srdWn; srdX = srdXn;
+        if constexpr (PATCH) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pxo[q] = pxn[q];
+        }
         pb = (pb + nk) & 1;
         tpar ^= 1;
     }

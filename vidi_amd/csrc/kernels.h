@@ -45,6 +45,13 @@ struct GemmParams {
     // m = (frame, token) of M = frames * hm_seq -> Y[which][frame][head][token][d]: every head's key rows contiguous, so the attention's
     // K / V tiles are whole 128-byte lines.  hm_seq == 0: row-major.  hm_magic = floor(2^32 / hm_seq) + 1 (exact m / hm_seq for M * seq < 2^32).
     int hm_seq, hm_hd, hm_heads; unsigned hm_magic;
+    // patch-embedding loader (gemm_w4_kernel<..., PATCH = true>): X is the NCHW pixel tensor [T, 3, pe_S, pe_S]; output row m = (frame,
+    // patch row, patch column) reads its pe_P x pe_P patch of every channel straight from the pixels.  The contraction index is
+    // k = (c * pe_P + dy) * 16 + dx: one 32-byte run of 16 pixels per (channel, patch line) — the pe_P real ones and the first pixels of
+    // the next patch, whose weight columns are zero — so a 64-wide K slice is four patch lines and every 16-byte LDS-DMA piece is 8
+    // contiguous pixels (4-byte aligned: tools/micro/lds_dma_align_probe.hip).  pe_nmagic / pe_smagic: floor(2^32 / d) + 1 for d = the
+    // patches per frame / per patch line.  pe_S == 0: X is a row-major matrix.
+    int pe_S, pe_P, pe_side; unsigned pe_nmagic, pe_smagic;
 };
 
 struct AttnSelfParams {
@@ -112,6 +119,7 @@ int vidi_gemv_norm2_dispatch(const void* A, const void* B, const void* C, const 
                              int dtype, hipStream_t st);
 int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int dtype, hipStream_t st);
 int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t st);
+int vidi_w4_patch(const GemmParams& p, int dtype, hipStream_t st);            // gemm_w4_patch.hip
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);

@@ -200,8 +200,16 @@ class VidiEngine:
         Hv, Iv, P = cfg.vis_hidden_size, cfg.vis_intermediate_size, cfg.vis_patch_size
         Ivp = _round_up(Iv, 64)
         kp = _round_up(3 * P * P, 64)
-        pw = torch.zeros((Hv, kp), dtype=dt, device=dev)
-        pw[:, : 3 * P * P] = g(v + "embeddings.patch_embedding.weight").reshape(Hv, -1)
+        conv_w = g(v + "embeddings.patch_embedding.weight")
+        # patch embedding straight from the NCHW pixels (vidi_patch_embed: the persistent GEMM's loader gathers the patches; default) or
+        # through an im2col buffer + the generic GEMM (VIDI_PATCH_LOADER=0, the A/B arm; also patches wider than the loader's 16-pixel run)
+        self.patch_loader = os.environ.get("VIDI_PATCH_LOADER", "1") != "0" and P <= 16 and 3 * P * 16 >= 192
+        if self.patch_loader:
+            pw = hip.patch_embed_weight(conv_w, P)
+        else:
+            pw = torch.zeros((Hv, kp), dtype=dt, device=dev)
+            pw[:, : 3 * P * P] = conv_w.reshape(Hv, -1)
+        del conv_w
         self.vis = {"patch_w": pw, "patch_b": g(v + "embeddings.patch_embedding.bias"),
                     "pos": g(v + "embeddings.position_embedding.weight"), "kpad": kp, "ipad": Ivp, "layers": []}
         for i in range(cfg.vis_select_layers):
@@ -366,7 +374,7 @@ class VidiEngine:
         out = torch.empty((T * N, Hv), dtype=self.dtype, device=self.dev)
         fc = max(1, cfg.vis_frames_per_chunk)
         Mmax = min(T, fc) * N
-        A = self._buf("vis_A", (Mmax, V["kpad"]))
+        A = None if self.patch_loader else self._buf("vis_A", (Mmax, V["kpad"]))
         fold = self.ln_fold
         ws = {"st": self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32) if fold else None,
               "part": self._buf("vis_part", (2 * Mmax * ((Hv + 127) // 128),), dtype=torch.float32) if fold else None,
@@ -381,8 +389,11 @@ class VidiEngine:
             c1 = min(T, c0 + fc)
             Tc, M = c1 - c0, (c1 - c0) * N
             x = out[c0 * N: c1 * N]
-            hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
-            hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
+            if self.patch_loader:
+                hip.patch_embed(pixel[c0:c1], V["patch_w"], V["patch_b"], V["pos"], x, T=Tc, S=S, P=P)       # TP siglip:124-130, 178
+            else:
+                hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
+                hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
             if fold:
                 hip.row_stats(x, ws["st"], cfg.vis_ln_eps)
             for L in V["layers"]:

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vidi_scale": [_c_vp] * 2 + [_c_ll, _c_f, _c_int, _c_vp],
     "vidi_any_nonzero": [_c_vp, _c_ll, _c_vp, _c_int, _c_vp],
     "vidi_im2col_patch": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
+    "vidi_patch_embed": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_pool_s2d": [_c_vp] * 2 + [_c_int] * 8 + [_c_vp],
     "vidi_add_pos": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
     "vidi_add3": [_c_vp] * 4 + [_c_ll, _c_int, _c_vp],
@@ -117,6 +118,8 @@ def _work(name, a):
         return "gemm", 2.0 * a[5] * a[6] * a[7] * a[16], "flop"
     if name == "vidi_gemm_geglu":
         return "gemm", 2.0 * a[3] * (2 * a[4]) * a[5], "flop"
+    if name == "vidi_patch_embed":                      # the convolution's products: T (S/P)^2 patches x N x 3 P^2 (not the loader's padded K)
+        return "gemm", 2.0 * a[5] * (a[6] // a[7]) ** 2 * a[8] * 3 * a[7] * a[7], "flop"
     if name == "vidi_gemm_qkv_vt":
         return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
     if name == "vidi_gemm_qkv_vt_ln":
@@ -164,6 +167,8 @@ def _alg_bytes(name, a):
         return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6]) * a[16]
     if name == "vidi_gemm_geglu":
         return 2.0 * (a[3] * a[5] + 2 * a[4] * a[5] + a[3] * a[4])
+    if name == "vidi_patch_embed":                      # pixels + weight + output
+        return 2.0 * (a[5] * 3 * a[6] * a[6] + a[8] * a[9] + a[5] * (a[6] // a[7]) ** 2 * a[8])
     if name == "vidi_gemm_qkv_vt":
         return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6])
     if name == "vidi_gemm_qkv_vt_ln":
@@ -631,6 +636,23 @@ def resid_norm2(a, b, c, res, w1, w2, y1, y2, *, eps: float):
     _check(lib.vidi_resid_norm2(_p(a), _p(b), _p(c), _p(res), _p(w1), _p(w2), _p(y1), _p(y2), rows, H, a.stride(0), float(eps), _dt(a),
                                 _stream()), "vidi_resid_norm2")
     return y1, y2
+
+
+def patch_embed_weight(w: torch.Tensor, P: int) -> torch.Tensor:
+    """conv weight [N, 3, P, P] -> the GEMM weight vidi_patch_embed reads: [N, K], k = (c*P + dy)*16 + dx, zero elsewhere, K % 64 == 0"""
+    N = w.shape[0]
+    K = (3 * P * 16 + 63) // 64 * 64
+    out = torch.zeros((N, K), dtype=w.dtype, device=w.device)
+    out[:, : 3 * P * 16].view(N, 3 * P, 16)[:, :, :P] = w.reshape(N, 3 * P, P)
+    return out
+
+
+def patch_embed(px, w, bias, pos, out, *, T, S, P):
+    """SigLIP patch embedding (conv + bias + position table) straight from the NCHW pixels; `w` from patch_embed_weight()"""
+    _rowmajor(w, "w")
+    _check(load_library().vidi_patch_embed(_p(px), _p(w), _p(bias), _p(pos), _p(out), T, S, P, w.shape[0], w.shape[1], w.stride(0),
+                                           out.stride(0), pos.stride(0), _dt(px), _stream()), "vidi_patch_embed")
+    return out
 
 
 def im2col_patch(px, out, *, T, S, P, Kpad):
