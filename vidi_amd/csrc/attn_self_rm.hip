@@ -129,11 +129,13 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         vrow[j] = row; vcol[j] = ((lane % MCH) ^ vswz(row)) * 8;
     }
 #ifndef VIDI_ATTN_RM_SRD
-#define VIDI_ATTN_RM_SRD 0             // 1: tile DMA through buffer descriptors — the per-lane byte offsets are tile-invariant VGPRs and the tile
-#endif                                 // advance is a SCALAR offset, so a piece costs no vector address arithmetic (the pointer form spends
-                                       // v_add + v_min + v_mad_i64 + v_lshl_add per piece: ~20 of the loop's ~150 VALU instructions per tile);
-                                       // key rows past N are outside the descriptor's range and read as zeros instead of repeating row N - 1
-                                       // (both finite; their scores are masked to -inf and their probabilities are exactly 0)
+#define VIDI_ATTN_RM_SRD 1             // 1 (default): tile DMA through buffer descriptors — the per-lane byte offsets are tile-invariant and the
+#endif                                 // tile advance is a SCALAR offset, so a piece costs no vector address arithmetic (the pointer form, 0,
+                                       // spends v_add + v_min + v_mad_i64 + v_lshl_add per piece: 26 VALU instructions per tile); key rows past N
+                                       // are outside the descriptor's range and read as zeros instead of repeating row N - 1 (both finite; their
+                                       // scores are masked to -inf, their probabilities are exactly 0).  Same-box A/B, N = 729, d = 72, 360
+                                       // frames: 654.9 -> 686.7 useful TFLOP/s on head-major input, 598.1 -> 629.6 on row-major, bit-identical
+                                       // (profiles/r3_ab_attn_srd.jsonl)
     __amdgpu_buffer_rsrc_t srdK, srdV;
     if constexpr (VIDI_ATTN_RM_SRD != 0) {
         const unsigned bytes = (unsigned)(((size_t)(p.N - 1) * p.ld + D) * 2);
