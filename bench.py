@@ -71,7 +71,14 @@ def self_launch(a):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
+    # rank 0's JSON line is relayed alone: transports (gloo) print connection chatter on the ranks' stdout
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            print(line)
+        elif line.strip():
+            print(line, file=sys.stderr)
+    raise SystemExit(r.returncode)
 
 
 from vidi_amd.shard import shard          # noqa: E402  (the product's frame / window partition; host integer logic)
