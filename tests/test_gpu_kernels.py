@@ -599,7 +599,7 @@ def test_patch_embed_reads_pixels_directly(hip, dt, T, S, P, Hv):
     old = hip.gemm(A, wp, dev(b), residual=dev(pos), rmod=n)
     ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
     # two roundings (conv + bias, then + position): a 1-ulp flip at the first can leave the results 2 ulps apart
-    report("patch_embed vs im2col + gemm", out, old.float(), 3 * ulp * ref.std().item(), 3 * ulp)
+    report("patch_embed vs im2col + gemm", out, old.float(), 4 * ulp * ref.std().item(), 4 * ulp)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
