@@ -6,7 +6,7 @@ name=$1; src=$2; shift 2
 cd "$(dirname "$0")/.."
 python -c "from vidi_amd.build import build; build(verbose=False)"
 extra=""
-case $src in attn_self.hip|attn_self_rm.hip|attn_cross.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+case $src in attn_self.hip|attn_cross.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; attn_self_rm.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans";; esac
 obj=/tmp/vidi_variant_${name}.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $extra "$@" -c vidi_amd/csrc/$src -o $obj
 objs=$(ls vidi_amd/csrc/build/*.o | grep -v "/${src%.hip}.o")

@@ -17,7 +17,11 @@ HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "gemm_w4.h", "gemm_w4_launch.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]      # (+ the resource-usage remark, see _compile)
 # MFMA results in architectural VGPRs: without this hipcc parks the attention accumulators in AGPRs and copies them
 # to VGPRs and back around every softmax step (attn_self: 2192 v_accvgpr moves, 204 registers -> 0 moves, 150)
-EXTRA_FLAGS = {"attn_self.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attn_self_rm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attn_cross.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# -fno-honor-nans (encoder attention only): the softmax never produces a NaN (masked scores are -inf, every tile holds a valid key), and
+# without the flag every fmaxf canonicalises its operands first (v_max_f32 x, x, x: 10 of the loop's ~130 vector instructions per tile):
+# +1.3 % on the kernel, bit-identical (profiles/r3_ab_attn_nonans.jsonl)
+EXTRA_FLAGS = {"attn_self.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attn_self_rm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"],
+               "attn_cross.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run[qs]));
+                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run[qs]));      // (as packed pairs, v_pk_fma_f32: measured 2 % slower)
                 pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run[qs]));
                 if constexpr (!kOnesRow) { ps0 += pv[r]; ps1 += pv[r + 1]; }
             }
