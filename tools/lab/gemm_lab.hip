@@ -71,7 +71,7 @@ static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; };   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh)
+struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; };   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh), 3 bias + GELU(erf)
 
 #define LATE(MODE, LAB) lab_launch<BF16, 256, 256, 2, 4, 2, MODE, false, SCHED_LATE, 16, LAB>
 #define W4(MODE, PERSIST, WAITMODE, LAB) lab_launch_w4<BF16, MODE, PERSIST, LAB>
@@ -97,6 +97,13 @@ static std::vector<Variant> variants() {
         {"w4p_br", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 0, 4, 1},
         {"late_bt", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 2},
         {"w4p_bt", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_TANH, 0>>, MODE_PLAIN, true, 0, 4, 2},
+        // N = 128 remainder column of the N = 1152 tower GEMMs (4.5 tiles of 256): candidates for a split launch
+        {"t128x128", lab_launch<BF16, 128, 128, 2, 2, 2, MODE_PLAIN, false, SCHED_RING, 32, LabNone>, MODE_PLAIN, true, 0, 4},
+        {"t128x256", lab_launch<BF16, 128, 256, 2, 4, 3, MODE_PLAIN, false, SCHED_RING, 32, LabNone>, MODE_PLAIN, true, 0, 4},
+        {"late128x256", lab_launch<BF16, 128, 256, 2, 4, 2, MODE_PLAIN, false, SCHED_LATE, 16, LabNone>, MODE_PLAIN, true, 0, 4},
+        {"t128x128_br", lab_launch<BF16, 128, 128, 2, 2, 2, MODE_PLAIN, false, SCHED_RING, 32, LabNone>, MODE_PLAIN, true, 0, 4, 1},
+        {"late128x256_br", lab_launch<BF16, 128, 256, 2, 4, 2, MODE_PLAIN, false, SCHED_LATE, 16, LabNone>, MODE_PLAIN, true, 0, 4, 1},
+        {"w4p_be", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_ERF, 0>>, MODE_PLAIN, true, 0, 4, 3},
         {"late_geglu", LATE(MODE_GEGLU, LabNone), MODE_GEGLU, true, 0, 4},
         {"w4p_geglu", W4(MODE_GEGLU, true, 0, LabNone), MODE_GEGLU, true, 0, 4},
     };
@@ -112,6 +119,7 @@ int main(int argc, char** argv) {
         {"siglip_qkv", 262440, 3456, 1152}, {"siglip_o", 262440, 1152, 1152}, {"siglip_fc1", 262440, 4352, 1152},
         {"siglip_fc2", 262440, 1152, 4352}, {"mm_kv", 126080, 4096, 3584}, {"mm_o", 126080, 3584, 4096},
         {"mm_down", 126080, 3584, 14336}, {"whisper_fc1", 180000, 5120, 1280}, {"sq8k", 8192, 8192, 8192}, {"mm_gateup", 126080, 28672, 3584},
+        {"o_n1024", 262440, 1024, 1152}, {"fc2_n1024", 262440, 1024, 4352}, {"o_rem128", 262440, 128, 1152}, {"fc2_rem128", 262440, 128, 4352},
     };
     std::vector<std::string> want;
     if (set == "quick") want = {"late", "w4s", "w4p", "w4pc"};
@@ -121,6 +129,7 @@ int main(int argc, char** argv) {
     else if (set == "geglu") want = {"late_geglu", "w4p_geglu"};
     else if (set == "epi") want = {"late", "w4p", "w4pc", "late_br", "w4p_br", "late_bt", "w4p_bt", "late_geglu", "w4p_geglu"};
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
+    else if (set == "split") want = {"w4p", "w4p_br", "t128x128", "t128x256", "late128x256", "t128x128_br", "late128x256_br"};
     else if (set == "store") want = {};
     else { want = {set}; }
     const char* only = getenv("LAB_SHAPE");
@@ -173,6 +182,7 @@ int main(int argc, char** argv) {
             p.dbg = dbg;
             if (v->epi == 1) { p.bias = Bv; p.R = R; p.ldr = sh.N; }
             if (v->epi == 2) { p.bias = Bv; p.act = ACT_GELU_TANH; }
+            if (v->epi == 3) { p.bias = Bv; p.act = ACT_GELU_ERF; }
             CK(hipMemset(Y, 0xff, ny * 2));
             CK(hipMemset(dbg, 0, 1024 * 64));
             int rc = v->fn(p, 0);

@@ -135,6 +135,44 @@ __device__ __forceinline__ f32x2_t gelu_tanh_2(f32x2_t x) {
     const f32x2_t d = one + f32x2_t{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};      // exp(-2u); +inf for very negative x -> result -0
     return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
+// NP pairs in lock-step, one arithmetic step at a time: every packed / transcendental instruction is followed by NP - 1 independent ones
+// before its result is used, so no hazard wait states (s_nop) separate dependent pairs — left to itself the compiler runs the chains of
+// an epilogue strip one after the other (535 s_nop per fc1 tile in the ISA).  Same arithmetic as gelu_tanh_2 element by element.
+#ifndef VIDI_GELU_LOCKSTEP
+#define VIDI_GELU_LOCKSTEP 1
+#endif
+template <int NP>
+__device__ __forceinline__ void gelu_tanh_pairs(f32x2_t* x) {
+#if VIDI_GELU_LOCKSTEP
+    const f32x2_t k0 = {VIDI_GELU_K0, VIDI_GELU_K0}, k1 = {VIDI_GELU_K1, VIDI_GELU_K1}, one = {1.0f, 1.0f};
+    f32x2_t w[NP];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = x[i] * x[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = __builtin_elementwise_fma(k1, w[i], k0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = x[i] * w[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = f32x2_t{__builtin_amdgcn_exp2f(w[i][0]), __builtin_amdgcn_exp2f(w[i][1])};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = one + w[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[i] = f32x2_t{__builtin_amdgcn_rcpf(w[i][0]), __builtin_amdgcn_rcpf(w[i][1])};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = x[i] * w[i];
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = gelu_tanh_2(x[i]);
+#endif
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float w = x * __builtin_fmaf(VIDI_GELU_K1, x * x, VIDI_GELU_K0);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
@@ -159,6 +197,59 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     const float q = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 1 - erf(z), z >= 0
     // x >= 0: 0.5x(2 - q);  x < 0: 0.5x q
     return 0.5f * x * (x >= 0.f ? 2.0f - q : q);
+}
+
+// erf-GELU of NP pairs in lock-step on packed fp32 math: the arithmetic of gelu_erf_f element by element (same operations, same
+// association, so the same bits), two elements per polynomial / product instruction and no hazard wait states between dependent steps
+template <int NP>
+__device__ __forceinline__ void gelu_erf_pairs(f32x2_t* x) {
+#if VIDI_GELU_LOCKSTEP
+    auto c2 = [](float c) { return f32x2_t{c, c}; };
+    f32x2_t z[NP], t[NP], p[NP];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) z[i] = f32x2_t{fabsf(x[i][0]), fabsf(x[i][1])} * c2(0.7071067811865476f);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) t[i] = __builtin_elementwise_fma(c2(0.3275911f), z[i], c2(1.0f));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) t[i] = f32x2_t{__builtin_amdgcn_rcpf(t[i][0]), __builtin_amdgcn_rcpf(t[i][1])};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(c2(1.061405429f), t[i], c2(-1.453152027f));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], c2(1.421413741f));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], c2(-0.284496736f));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], c2(0.254829592f));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { p[i] = p[i] * t[i]; z[i] = (c2(-1.4426950408889634f) * z[i]) * z[i]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) z[i] = f32x2_t{__builtin_amdgcn_exp2f(z[i][0]), __builtin_amdgcn_exp2f(z[i][1])};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = p[i] * z[i];                                         // q = 1 - erf(z), z >= 0
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const f32x2_t two_q = c2(2.0f) - p[i];
+        t[i] = f32x2_t{x[i][0] >= 0.f ? two_q[0] : p[i][0], x[i][1] >= 0.f ? two_q[1] : p[i][1]};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = (c2(0.5f) * x[i]) * t[i];
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = f32x2_t{gelu_erf_f(x[i][0]), gelu_erf_f(x[i][1])};
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

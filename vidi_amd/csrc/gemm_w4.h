@@ -312,14 +312,28 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             constexpr int b = decltype(bt)::value;
             const int mrow0 = em0 + wm * 128 + b * 16;               // first global row of the strip
             if constexpr (GLU) {
+                // the strip's 8 gate pairs (gate tiles a = 0, 1, 4, 5; up tiles a + 2 are consumed with them): rounded to T, activated in
+                // lock-step on packed fp32 math, rounded again and multiplied by the rounded up values
+                f32x2_t g[8];
 #pragma unroll
-                for (int a = 0; a < TN; ++a) {
-                    if ((a >> 1) & 1) continue;                       // up tiles are consumed with their gate tile
+                for (int i = 0; i < 4; ++i) {
+                    const int a = (i >> 1) * 4 + (i & 1);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) g[i * 2 + (e >> 1)] = f32x2_t{rnd<T>(aread(acc[a][b][e])), rnd<T>(aread(acc[a][b][e + 1]))};
+                }
+                if (glu_silu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = silu_2(g[i]);
+                } else {
+                    gelu_tanh_pairs<8>(g);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int a = (i >> 1) * 4 + (i & 1);
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e += 2) {                  // pairs: the activation's polynomial / products on packed fp32 math
-                        const f32x2_t g = {rnd<T>(aread(acc[a][b][e])), rnd<T>(aread(acc[a][b][e + 1]))};
-                        const f32x2_t act = glu_silu ? silu_2(g) : gelu_tanh_2(g);
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2_t act = g[i * 2 + (e >> 1)];
                         v[e] = rnd<T>(act[0]) * rnd<T>(aread(acc[a + 2][b][e]));
                         v[e + 1] = rnd<T>(act[1]) * rnd<T>(aread(acc[a + 2][b][e + 1]));
                     }
@@ -404,6 +418,29 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         constexpr bool emit_stats = (MODE == MODE_PLAIN) && EPI::stats && (EPI::res != 0);
         auto store = [&](int b) {
             const int mrow0 = em0 + wm * 128 + b * 16;
+            if constexpr (MODE == MODE_PLAIN && (act_tanh || act_erf)) {
+                // the activation of the whole strip first (on the T-rounded staged values, as below), 8 register pairs in lock-step
+#pragma unroll
+                for (int j0 = 0; j0 < NRD; j0 += 2) {
+                    f32x2_t xp[8];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float x[8];
+                        unpack8<T>(val[j0 + jj], x);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xp[jj * 4 + e] = f32x2_t{x[2 * e], x[2 * e + 1]};
+                    }
+                    if constexpr (act_tanh) gelu_tanh_pairs<8>(xp);
+                    else gelu_erf_pairs<8>(xp);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { x[2 * e] = xp[jj * 4 + e][0]; x[2 * e + 1] = xp[jj * 4 + e][1]; }
+                        val[j0 + jj] = pack8<T>(x);
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NRD; ++j) {
                 const int m = mrow0 + j * RPI + rr;
@@ -449,17 +486,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                     if constexpr (MODE == MODE_PLAIN) {
                         // the activation runs on the T-rounded staged values (same arithmetic as rounding first, then activating)
                         if constexpr (act_tanh) {
-                            float x[8];
-                            unpack8<T>(v, x);
-#pragma unroll
-                            for (int e = 0; e < 8; e += 2) { const f32x2_t y = gelu_tanh_2(f32x2_t{x[e], x[e + 1]}); x[e] = y[0]; x[e + 1] = y[1]; }
-                            v = pack8<T>(x);
-                        } else if constexpr (act_erf) {
-                            float x[8];
-                            unpack8<T>(v, x);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) x[e] = gelu_erf_f(x[e]);
-                            v = pack8<T>(x);
+                            // (applied to the whole strip above)
                         }
                         if constexpr (has_res) {
                             float x[8], r[8];
