@@ -71,7 +71,7 @@ static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; };   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh), 3 bias + GELU(erf)
+struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; };   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh), 3 bias + GELU(erf), 4 bias + residual + row statistics
 
 #define LATE(MODE, LAB) lab_launch<BF16, 256, 256, 2, 4, 2, MODE, false, SCHED_LATE, 16, LAB>
 #define W4(MODE, PERSIST, WAITMODE, LAB) lab_launch_w4<BF16, MODE, PERSIST, LAB>
@@ -103,6 +103,7 @@ static std::vector<Variant> variants() {
         {"late128x256", lab_launch<BF16, 128, 256, 2, 4, 2, MODE_PLAIN, false, SCHED_LATE, 16, LabNone>, MODE_PLAIN, true, 0, 4},
         {"t128x128_br", lab_launch<BF16, 128, 128, 2, 2, 2, MODE_PLAIN, false, SCHED_RING, 32, LabNone>, MODE_PLAIN, true, 0, 4, 1},
         {"late128x256_br", lab_launch<BF16, 128, 256, 2, 4, 2, MODE_PLAIN, false, SCHED_LATE, 16, LabNone>, MODE_PLAIN, true, 0, 4, 1},
+        {"w4p_brs", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 0, 4, 4},   // + per-strip row statistics
         {"w4p_be", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_ERF, 0>>, MODE_PLAIN, true, 0, 4, 3},
         {"late_geglu", LATE(MODE_GEGLU, LabNone), MODE_GEGLU, true, 0, 4},
         {"w4p_geglu", W4(MODE_GEGLU, true, 0, LabNone), MODE_GEGLU, true, 0, 4},
@@ -161,9 +162,9 @@ int main(int argc, char** argv) {
     for (const Shape& sh : shapes) {
         if (only && strcmp(only, sh.name)) continue;
         if (want.empty()) break;
-        u16 *X, *W, *Y, *R, *Bv;
+        u16 *X, *W, *Y, *R, *Bv; float* SP;
         const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
-        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2)); CK(hipMalloc(&R, ny * 2)); CK(hipMalloc(&Bv, (size_t)sh.N * 2));
+        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2)); CK(hipMalloc(&R, ny * 2)); CK(hipMalloc(&Bv, (size_t)sh.N * 2)); CK(hipMalloc(&SP, (size_t)sh.M * ((sh.N + 127) / 128) * 8));
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, R, ny, 0x5555u, 1.0f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, Bv, (size_t)sh.N, 0x7777u, 0.5f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, nx, 0x1234u, 1.7f, zero);
@@ -183,6 +184,7 @@ int main(int argc, char** argv) {
             if (v->epi == 1) { p.bias = Bv; p.R = R; p.ldr = sh.N; }
             if (v->epi == 2) { p.bias = Bv; p.act = ACT_GELU_TANH; }
             if (v->epi == 3) { p.bias = Bv; p.act = ACT_GELU_ERF; }
+            if (v->epi == 4) { p.bias = Bv; p.R = R; p.ldr = sh.N; p.stat_part = SP; CK(hipMemset(SP, 0, (size_t)sh.M * ((sh.N + 127) / 128) * 8)); }
             CK(hipMemset(Y, 0xff, ny * 2));
             CK(hipMemset(dbg, 0, 1024 * 64));
             int rc = v->fn(p, 0);
@@ -191,6 +193,7 @@ int main(int argc, char** argv) {
             CK(hipMemset(dsum, 0, 16));
             const size_t nyo = v->mode == MODE_GEGLU ? ny / 2 : ny;
             hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, Y, nyo, dsum);
+            if (v->epi == 4) hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, (const u16*)SP, (size_t)sh.M * ((sh.N + 127) / 128) * 4, dsum);   // the statistics too
             unsigned long long cs[2]; CK(hipMemcpy(cs, dsum, 16, hipMemcpyDeviceToHost));
             v->fn(p, 0);                                             // warm
             CK(hipEventRecord(e0));
@@ -222,7 +225,7 @@ int main(int argc, char** argv) {
             }
             fflush(stdout);
         }
-        CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y)); CK(hipFree(R)); CK(hipFree(Bv));
+        CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y)); CK(hipFree(R)); CK(hipFree(Bv)); CK(hipFree(SP));
     }
     return 0;
 }

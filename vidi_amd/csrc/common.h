@@ -36,6 +36,34 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// The same reduction for TWO values at once, as v_add_f32 with the DPP permutation ON the add (one instruction per value and step).  Written
+// with the builtin the compiler packs the two chains into v_pk_add_f32, which cannot carry a DPP modifier, and emits per step two zeroing
+// moves, two v_mov_b32_dpp and the packed add (20 instructions instead of 8 in the GEMM's statistics epilogue).  A VALU result needs two
+// wait states before a DPP read: the two chains alternate and one s_nop separates the steps.  Same additions in the same order.
+#ifndef VIDI_ROW16_ASM
+#define VIDI_ROW16_ASM 1
+#endif
+__device__ __forceinline__ void row16_sum2(float& a, float& b) {
+#if VIDI_ROW16_ASM
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+#else
+    a = row16_sum(a); b = row16_sum(b);
+#endif
+}
+
 // ---- scalar conversions -------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ u16 f32_to_bf16(float f) {   // round-to-nearest-even: hardware v_cvt_pk_bf16_f32

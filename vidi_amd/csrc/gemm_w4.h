@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                     }
                     float s1 = sa[0] + sa[1], s2 = sq[0] + sq[1];
                     if (!ok) { s1 = 0.f; s2 = 0.f; }
-                    s1 = row16_sum(s1); s2 = row16_sum(s2);               // the 16 lanes cc = 0..15 hold this row's 128 columns
+                    row16_sum2(s1, s2);                                    // the 16 lanes cc = 0..15 hold this row's 128 columns
                     const int strip = no0 >> 7;
                     if (cc == 0 && m < p.M && no0 < Nout)
                         *(f32x2_t*)(p.stat_part + ((size_t)m * ((Nout + 127) >> 7) + strip) * 2) = f32x2_t{s1, s2};

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void row_partials_kernel(const u16* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1 += x[e]; s2 = __builtin_fmaf(x[e], x[e], s2); }
     }
-    s1 = row16_sum(s1); s2 = row16_sum(s2);
+    row16_sum2(s1, s2);
     if (live && c == 0) *((f32x2_t*)part + idx) = f32x2_t{s1, s2};
 }
 
