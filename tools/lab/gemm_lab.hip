@@ -103,6 +103,9 @@ static std::vector<Variant> variants() {
         {"late128x256", lab_launch<BF16, 128, 256, 2, 4, 2, MODE_PLAIN, false, SCHED_LATE, 16, LabNone>, MODE_PLAIN, true, 0, 4},
         {"t128x128_br", lab_launch<BF16, 128, 128, 2, 2, 2, MODE_PLAIN, false, SCHED_RING, 32, LabNone>, MODE_PLAIN, true, 0, 4, 1},
         {"late128x256_br", lab_launch<BF16, 128, 256, 2, 4, 2, MODE_PLAIN, false, SCHED_LATE, 16, LabNone>, MODE_PLAIN, true, 0, 4, 1},
+        {"w4p_br_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 0, 4, 1},
+        {"w4p_bt_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_GELU_TANH, 0>>, MODE_PLAIN, true, 0, 4, 2},
+        {"w4p_brs_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 0, 4, 4},
         {"w4p_brs", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 0, 4, 4},   // + per-strip row statistics
         {"w4p_be", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_ERF, 0>>, MODE_PLAIN, true, 0, 4, 3},
         {"late_geglu", LATE(MODE_GEGLU, LabNone), MODE_GEGLU, true, 0, 4},
@@ -130,6 +133,7 @@ int main(int argc, char** argv) {
     else if (set == "geglu") want = {"late_geglu", "w4p_geglu"};
     else if (set == "epi") want = {"late", "w4p", "w4pc", "late_br", "w4p_br", "late_bt", "w4p_bt", "late_geglu", "w4p_geglu"};
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
+    else if (set == "stamps_epi") want = {"w4p_stamps", "w4p_br_stamps", "w4p_brs_stamps", "w4p_bt_stamps"};
     else if (set == "split") want = {"w4p", "w4p_br", "t128x128", "t128x256", "late128x256", "t128x128_br", "late128x256_br"};
     else if (set == "store") want = {};
     else { want = {set}; }
