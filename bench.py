@@ -68,6 +68,7 @@ def self_launch(a):
         if env.get("VIDI_DIST_BACKEND") != "gloo":
             raise SystemExit(f"bench.py --gpus {a.gpus}: only {ngpu} GPU(s) visible (set VIDI_DIST_BACKEND=gloo to run the ranks on one GPU as a test)")
         env.setdefault("VIDI_FORCE_DEVICE", "0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between the ranks' processes on this driver
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -355,7 +356,8 @@ def main():
     # --decode-graph: the step is captured once in a hipGraph (vidi_amd/engine.py:make_decode_graph) and replayed;
     # the capture (one eager step + graph build) is timed inside the leg, so s/query pays for it.
     torch.cuda.synchronize()
-    use_graph = world == 1 and a.decode_graph and a.decode_steps >= 2
+    # over shards the captured step includes the per-layer RCCL all-gathers (engine.make_decode_graph); the gloo test transport cannot be captured
+    use_graph = a.decode_graph and a.decode_steps >= 2 and (world == 1 or dist.get_backend() == "nccl")
     t_capture = 0.0
     td0 = time.perf_counter()
     if use_graph:
