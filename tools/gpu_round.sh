@@ -83,7 +83,7 @@ pmc)
   (cd /tmp && timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err); echo "fetch rc=$?"
   (cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err); echo "write rc=$?"
   F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
-  python tools/traffic_from_pmc.py "$F" "$W" $OUT/traffic.json 3600 vidi15_9b | head -c 1500
+  python tools/traffic_from_pmc.py "$F" "$W" $OUT/traffic.json 3600 vidi15_9b | head -c 4000
   # keep only the small summaries (the raw per-dispatch CSVs are tens of MB)
   rm -rf $OUT/pmc_fetch $OUT/pmc_write ;;
 esac
