@@ -259,6 +259,12 @@ int vidi_resid_norm2(const void* A, const void* B, const void* C, const void* Re
 int vidi_patch_embed(const void* px, const void* W, const void* bias, const void* pos, void* Y, int T, int S, int P, int N, int K,
                      int ldw, int ldy, int ldpos, int dtype, void* stream);
 
+/* Learned Conv2DPool of Vidi-7B (Vidi_7B/model/mm_vision/pool.py:19-26): Conv2d(C, N, kernel k, stride 1, valid, no bias) over the tower's
+ * token-major features f:[T, side*side, C] -> Y:[T*(side-k+1)^2, N], the k x k window gathered by the persistent GEMM's loader (64
+ * contiguous channels of one window position per K slice; no im2col buffer).  W:[N, k*k*C] with k index (dy*k + dx)*C + c (the layout
+ * vidi_im2col_nhwc + vidi_gemm used), C % 64 == 0. */
+int vidi_conv_window(const void* f, const void* W, void* Y, int T, int side, int C, int k, int N, int ldw, int ldy, int dtype, void* stream);
+
 /* ---- data movement / elementwise -------------------------------------------------------------- */
 /* SiglipVisionEmbeddings conv as GEMM input (TP siglip:124-130,178): px:[T,3,S,S] -> A:[T*(S/P)^2,Kpad] */
 int vidi_im2col_patch(const void* px, void* A, int T, int S, int P, int Kpad, int dtype, void* stream);

@@ -603,6 +603,29 @@ def test_patch_embed_reads_pixels_directly(hip, dt, T, S, P, Hv):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,side,C,k,N", [(12, 27, 1152, 14, 1152), (2, 27, 1152, 14, 1152), (3, 7, 64, 4, 64), (5, 9, 128, 3, 96), (1, 6, 64, 6, 32)])
+def test_conv_window_gathers_in_the_loader(hip, dt, T, side, C, k, N):
+    """vidi_conv_window — Vidi-7B's learned Conv2DPool conv (Vidi_7B/model/mm_vision/pool.py:19-26: Conv2d(C, C, k, stride 1, no bias)) with
+    the k x k window gathered from the token-major features by the GEMM's loader — against F.conv2d in fp32 on the same rounded inputs and
+    bit for bit against the im2col + GEMM form it replaces (same products, same order).  SigLIP-so400m dims (27 x 27, k = 14 -> 14 x 14
+    outputs, K = 225 792), the tiny tower, a window as large as the map."""
+    oc = side - k + 1
+    f = seeded((T, side * side, C), 180, dtype=dt); w = seeded((N, C, k, k), 181, (k * k * C) ** -0.5, dtype=dt)
+    ref = F.conv2d(f.float().reshape(T, side, side, C).permute(0, 3, 1, 2), w.float()).permute(0, 2, 3, 1).reshape(T * oc * oc, N)
+    wg = dev(w.permute(0, 2, 3, 1).reshape(N, -1).contiguous())
+    out = torch.full((T * oc * oc, N), float("nan"), dtype=dt, device="cuda")
+    hip.conv_window(dev(f), wg, out, T=T, side=side, C=C, k=k)
+    report("conv_window vs conv2d", out, ref, *tol(dt, ref.std().item()))
+    col = torch.empty((T * oc * oc, k * k * C), dtype=dt, device="cuda")
+    hip.im2col_nhwc(dev(f), col, T=T, side=side, C=C, k=k)
+    old = hip.gemm(col, wg, None, tile_cfg=5 if T * oc * oc >= 256 and N >= 64 else -1)
+    if T * oc * oc >= 256 and N >= 64:
+        assert torch.equal(out.view(torch.int16), old.view(torch.int16)), "same kernel body, same K order: bit-identical"
+    else:
+        report("conv_window vs im2col + gemm (another tile kernel)", out, old.float(), *tol(dt, ref.std().item()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("side,hw", [(27, (28, 28)), (27, (10, 10)), (27, (26, 26)), (7, (28, 28)), (7, (10, 10))])
 def test_pool_s2d(hip, dt, side, hw):
     T, C, m = 3, 16, 2

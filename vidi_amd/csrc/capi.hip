@@ -60,6 +60,23 @@ int vidi_patch_embed(const void* px, const void* W, const void* bias, const void
     return vidi_w4_patch(p, dtype, (hipStream_t)stream);
 }
 
+int vidi_conv_window(const void* f, const void* W, void* Y, int T, int side, int C, int k, int N, int ldw, int ldy, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!f || !W || !Y) return VIDI_ERR_ARG;
+    if (T <= 0 || side <= 0 || k <= 0 || k > side || C <= 0 || (C % 64)) return VIDI_ERR_SHAPE;
+    if ((ldw % 8) || (ldy % 8)) return VIDI_ERR_ALIGN;
+    if (((uintptr_t)f & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15)) return VIDI_ERR_ALIGN;
+    const int oc = side - k + 1, n = oc * oc;
+    GemmParams p = base_params(f, W, nullptr, Y, nullptr, T * n, N, k * k * C, 0, ldw, ldy, 0, 0);
+    p.pe_S = C; p.pe_P = k; p.pe_side = side;
+    p.pe_nmagic = (unsigned)(0x100000000ull / (unsigned)n) + 1u;
+    p.pe_smagic = (unsigned)(0x100000000ull / (unsigned)oc) + 1u;
+    p.pe_cmagic = (unsigned)(0x100000000ull / (unsigned)(C / 64)) + 1u;
+    p.pe_kmagic = (unsigned)(0x100000000ull / (unsigned)k) + 1u;
+    if ((unsigned long long)T * n * (unsigned long long)n >= 0x100000000ull) return VIDI_ERR_SHAPE;      // exact m / n by multiply-high
+    return vidi_w4_window(p, dtype, (hipStream_t)stream);
+}
+
 int vidi_gemm_geglu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy,
                     int tile_cfg, int dtype, void* stream) {
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error

@@ -51,8 +51,10 @@ struct W4Geom {
 template <bool BIAS, int ACT, int RES, bool LNF = false, bool STATS = false, bool HEADS = false>
 struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF, stats = STATS, heads = HEADS; };
 
-// PATCH: the X operand is gathered from NCHW pixels (GemmParams::pe_*): the SigLIP patch embedding without an im2col buffer
-template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone, bool PATCH = false>
+// PATCH: the X operand is gathered by the loader instead of read from a row-major matrix (GemmParams::pe_*):
+//   1  SigLIP patch embedding from NCHW pixels (no im2col buffer)
+//   2  k x k convolution window (stride 1, valid) over a token-major [frames, side*side, C] feature map: Vidi-7B's learned Conv2DPool
+template <typename T, int MODE, bool REPKV, bool PERSIST, typename EPI = Epi<false, ACT_NONE, 0>, typename LAB = LabNone, int PATCH = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     using G = W4Geom;
     constexpr int BN = G::BN, BM = G::BM, BK = G::BK, NT = G::NT, TN = G::TN, TM = G::TM, ROWB = G::ROWB, STAGE_BYTES = G::STAGE_BYTES;
@@ -96,9 +98,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     // PATCH: per-lane byte offsets of the lane's 8 X rows (piece q covers row q*32 + r0) of the current / the next tile inside the pixel
     // tensor — (frame, patch row, patch column) -> first pixel of the patch in channel 0, + the lane's half of the 16-pixel run — and the
     // per-slice part: the lane's chunk cg0 of slice ks belongs to patch line rr = 4 ks + (cg0 >> 1) = (channel, dy)
-    unsigned pxo[PATCH ? 8 : 1], pxn[PATCH ? 8 : 1];
+    unsigned pxo[PATCH != 0 ? 8 : 1], pxn[PATCH != 0 ? 8 : 1];
     auto patch_rows = [&](int tm0, unsigned* dst) {
-        if constexpr (PATCH) {
+        if constexpr (PATCH == 1) {
             const unsigned n = (unsigned)(p.pe_side * p.pe_side);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -107,12 +109,33 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                 const unsigned py = __umulhi(rem, p.pe_smagic), px = rem - py * (unsigned)p.pe_side;
                 dst[q] = (((f * 3u * (unsigned)p.pe_S + py * (unsigned)p.pe_P) * (unsigned)p.pe_S + px * (unsigned)p.pe_P) << 1) + (unsigned)(cg0 & 1) * 16u;
             }
+        } else if constexpr (PATCH == 2) {
+            // window mode: pe_S = channels C, pe_P = window k, pe_side = input side; output row m = (frame, oy, ox) of an oc x oc grid,
+            // oc = side - k + 1 (pe_nmagic / pe_smagic divide by oc*oc / oc): first input token of the window, + the lane's chunk
+            const unsigned oc = (unsigned)(p.pe_side - p.pe_P + 1), n = oc * oc;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned m = (unsigned)min(tm0 + q * 32 + r0, p.M - 1);
+                const unsigned f = __umulhi(m, p.pe_nmagic), rem = m - f * n;
+                const unsigned oy = __umulhi(rem, p.pe_smagic), ox = rem - oy * oc;
+                dst[q] = ((((f * (unsigned)p.pe_side + oy) * (unsigned)p.pe_side + ox) * (unsigned)p.pe_S) << 1) + (unsigned)cg0 * 16u;
+            }
         }
     };
+    // the K-slice part of the gather address.  Patch mode: the lane's chunk cg0 of slice ks belongs to patch line rr = 4 ks + (cg0 >> 1) =
+    // (channel, dy) -> a per-lane value.  Window mode: slice ks = 64 channels c0 .. of window position (dy, dx) = (ks * 64) / C -> the same
+    // for every lane (pe_cmagic divides by C / 64 slices per window position; pe_kmagic by k)
     auto patch_koff = [&](int ks) -> unsigned {
-        const int rr = 4 * ks + (cg0 >> 1);
-        const int c = (rr >= p.pe_P ? 1 : 0) + (rr >= 2 * p.pe_P ? 1 : 0);
-        return (unsigned)(rr * p.pe_S + c * (p.pe_S - p.pe_P) * p.pe_S) << 1;            // channel c, line dy = rr - c P: (c S + dy) S pixels
+        if constexpr (PATCH == 2) {
+            const unsigned spc = (unsigned)p.pe_S >> 6;                                   // slices per window position
+            const unsigned dd = __umulhi((unsigned)ks, p.pe_cmagic), c0 = ((unsigned)ks - dd * spc) << 6;
+            const unsigned dy = __umulhi(dd, p.pe_kmagic), dx = dd - dy * (unsigned)p.pe_P;
+            return (((dy * (unsigned)p.pe_side + dx) * (unsigned)p.pe_S) + c0) << 1;
+        } else {
+            const int rr = 4 * ks + (cg0 >> 1);
+            const int c = (rr >= p.pe_P ? 1 : 0) + (rr >= 2 * p.pe_P ? 1 : 0);
+            return (unsigned)(rr * p.pe_S + c * (p.pe_S - p.pe_P) * p.pe_S) << 1;        // channel c, line dy = rr - c P: (c S + dy) S pixels
+        }
     };
     auto locate = [&](int vb, int& tm0, int& tn0, int& tbz) {
         const int b1 = vb % tiles_1;
@@ -127,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if constexpr (LAB::no_dma) return;
         constexpr bool NEXT = decltype(next_t)::value;
         const int k0 = ks * BK;
-        if constexpr (PATCH) {
+        if constexpr (PATCH != 0) {
             if (q < 8) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(buf + BN * ROWB + (q * NT + wave * 64) * 16), 16,
                                                          (int)((NEXT ? pxn[q] : pxo[q]) + patch_koff(ks)), 0, 0, 0);
@@ -532,9 +555,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     int vb = blockIdx.x;
     locate(vb, m0, n0, bz);
     srdW = make_srd(p.W + (size_t)n0 * p.ldw, p.N - n0, p.ldw);
-    if constexpr (PATCH) {
+    if constexpr (PATCH != 0) {
         // ONE descriptor over the whole pixel tensor (the row -> patch map is in the per-lane offsets): T * 3 * S * S pixels < 4 GB
-        const unsigned long long bytes = (unsigned long long)(p.M / (p.pe_side * p.pe_side)) * 3ull * p.pe_S * p.pe_S * 2ull;
+        const int oc2 = (p.pe_side - p.pe_P + 1) * (p.pe_side - p.pe_P + 1);
+        const unsigned long long bytes = PATCH == 1 ? (unsigned long long)(p.M / (p.pe_side * p.pe_side)) * 3ull * p.pe_S * p.pe_S * 2ull
+                                                    : (unsigned long long)(p.M / oc2) * p.pe_side * p.pe_side * p.pe_S * 2ull;
         srdX = srdXn = rsrc_of(p.X, bytes);
         patch_rows(m0, pxo);
     } else {
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if (has_next) {
             locate(nvb, nm0, nn0, nbz);
             srdWn = make_srd(p.W + (size_t)nn0 * p.ldw, p.N - nn0, p.ldw);
-            if constexpr (PATCH) patch_rows(nm0, pxn);
+            if constexpr (PATCH != 0) patch_rows(nm0, pxn);
             else srdXn = make_srd(p.X + (long long)nbz * p.bsX + (size_t)nm0 * p.ldx, p.M - nm0, p.ldx);
         }
         body(0, TT{}, FF{}, true);
@@ -580,7 +605,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         stamp(3);
         if (!has_next) break;
         vb = nvb; m0 = nm0; n0 = nn0; bz = nbz; srdW = srdWn; srdX = srdXn;
-        if constexpr (PATCH) {
+        if constexpr (PATCH != 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) pxo[q] = pxn[q];
         }

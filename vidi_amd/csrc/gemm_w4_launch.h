@@ -5,7 +5,7 @@
 
 #define VIDI_W4_UNSUPPORTED (-100)      // epilogue combination not instantiated: the caller falls back to the 8-wave kernel
 
-template <typename T, int MODE, bool REPKV, typename EPI, bool PATCH = false>
+template <typename T, int MODE, bool REPKV, typename EPI, int PATCH = 0>
 static int launch_w4(const GemmParams& p, int batch, hipStream_t st) {
     auto kern = gemm_w4_kernel<T, MODE, REPKV, true, EPI, LabNone, PATCH>;
     static bool attr_done = false;

@@ -52,6 +52,10 @@ struct GemmParams {
     // contiguous pixels (4-byte aligned: tools/micro/lds_dma_align_probe.hip).  pe_nmagic / pe_smagic: floor(2^32 / d) + 1 for d = the
     // patches per frame / per patch line.  pe_S == 0: X is a row-major matrix.
     int pe_S, pe_P, pe_side; unsigned pe_nmagic, pe_smagic;
+    // window mode (PATCH = 2; Vidi-7B's learned Conv2DPool): X is the token-major feature map [frames, pe_side * pe_side, pe_S channels],
+    // output row m = (frame, oy, ox) of the (pe_side - pe_P + 1)^2 valid positions of a pe_P x pe_P window, k = (dy, dx, channel): a 64-wide
+    // K slice is 64 contiguous channels of one window position.  pe_cmagic / pe_kmagic: floor(2^32 / d) + 1 for d = pe_S / 64 and pe_P.
+    unsigned pe_cmagic, pe_kmagic;
 };
 
 struct AttnSelfParams {
@@ -120,6 +124,7 @@ int vidi_gemv_norm2_dispatch(const void* A, const void* B, const void* C, const 
 int vidi_gemv_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int dtype, hipStream_t st);
 int vidi_gemm_f32_dispatch(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t st);
 int vidi_w4_patch(const GemmParams& p, int dtype, hipStream_t st);            // gemm_w4_patch.hip
+int vidi_w4_window(const GemmParams& p, int dtype, hipStream_t st);           // gemm_w4_patch.hip
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);

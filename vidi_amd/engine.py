@@ -130,6 +130,8 @@ class VidiEngine:
         # multimodal stream: o_proj over repeat_kv(V) as one GEMM over V with the G column blocks of o_proj summed at load time
         # (VIDI_FOLD_REPKV=0: the repeat done by the GEMM's operand read, K twice as long)
         self.fold_repkv = os.environ.get("VIDI_FOLD_REPKV", "1") != "0"
+        # Vidi-7B's learned Conv2DPool: window gather in the GEMM loader (VIDI_POOL_LOADER=0: im2col + GEMM)
+        self.pool_loader = os.environ.get("VIDI_POOL_LOADER", "1") != "0"
         self.norm_mode = hip.NORM_MM if self.mistral else hip.NORM_GEMMA            # MistralRMSNorm == w * T(x_hat)
         self._pack(weights, free_source)
         self._rope_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -422,13 +424,20 @@ class VidiEngine:
             oc = side - k + 1
             oh = ow = pool
             pooled = torch.empty((T * oh * ow, Hv), dtype=self.dtype, device=self.dev)
-            fc = max(1, min(T, (1 << 30) // (oc * oc * k * k * Hv * 2)))              # im2col chunk <= 1 GiB
             f3 = f.reshape(T, side * side, Hv)
+            # the k x k window gathered by the GEMM's loader (vidi_conv_window; default) or an im2col buffer + the generic GEMM
+            # (VIDI_POOL_LOADER=0, the A/B arm: 88 MB of im2col rows per frame at k = 14, C = 1152)
+            loader = self.pool_loader and Hv % 64 == 0 and k * k * Hv >= 192
+            fc = max(1, min(T, 1024)) if loader else max(1, min(T, (1 << 30) // (oc * oc * k * k * Hv * 2)))      # one descriptor (< 4 GB) / im2col chunk <= 1 GiB
             for t0 in range(0, T, fc):
                 t1 = min(T, t0 + fc)
-                col = self._buf("pool_col", ((t1 - t0) * oc * oc, k * k * Hv))
-                hip.im2col_nhwc(f3[t0:t1], col, T=t1 - t0, side=side, C=Hv, k=k)
-                conv = hip.gemm(col, self.mm["img_pool_w"], None)
+                if loader:
+                    conv = self._buf("pool_conv", ((t1 - t0) * oc * oc, Hv))
+                    hip.conv_window(f3[t0:t1], self.mm["img_pool_w"], conv, T=t1 - t0, side=side, C=Hv, k=k)
+                else:
+                    col = self._buf("pool_col", ((t1 - t0) * oc * oc, k * k * Hv))
+                    hip.im2col_nhwc(f3[t0:t1], col, T=t1 - t0, side=side, C=Hv, k=k)
+                    conv = hip.gemm(col, self.mm["img_pool_w"], None)
                 hip.resize_bilinear_ac(conv, pooled[t0 * oh * ow: t1 * oh * ow], T=t1 - t0, s_in=oc, s_out=pool, C=Hv)
         else:
             hw = token_budget_hw(Ttot, side, pool, cfg.mm_max_tokens_base)                  # global T decides

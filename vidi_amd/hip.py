@@ -63,6 +63,7 @@ SIGNATURES = {
     "vidi_any_nonzero": [_c_vp, _c_ll, _c_vp, _c_int, _c_vp],
     "vidi_im2col_patch": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
     "vidi_patch_embed": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
+    "vidi_conv_window": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_pool_s2d": [_c_vp] * 2 + [_c_int] * 8 + [_c_vp],
     "vidi_add_pos": [_c_vp] * 4 + [_c_int] * 5 + [_c_vp],
     "vidi_add3": [_c_vp] * 4 + [_c_ll, _c_int, _c_vp],
@@ -120,6 +121,8 @@ def _work(name, a):
         return "gemm", 2.0 * a[3] * (2 * a[4]) * a[5], "flop"
     if name == "vidi_patch_embed":                      # the convolution's products: T (S/P)^2 patches x N x 3 P^2 (not the loader's padded K)
         return "gemm", 2.0 * a[5] * (a[6] // a[7]) ** 2 * a[8] * 3 * a[7] * a[7], "flop"
+    if name == "vidi_conv_window":                      # T (side-k+1)^2 outputs x N x k^2 C
+        return "gemm", 2.0 * a[3] * (a[4] - a[6] + 1) ** 2 * a[7] * a[6] * a[6] * a[5], "flop"
     if name == "vidi_gemm_qkv_vt":
         return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
     if name == "vidi_gemm_qkv_vt_ln":
@@ -167,6 +170,8 @@ def _alg_bytes(name, a):
         return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6]) * a[16]
     if name == "vidi_gemm_geglu":
         return 2.0 * (a[3] * a[5] + 2 * a[4] * a[5] + a[3] * a[4])
+    if name == "vidi_conv_window":                      # features + weight + output
+        return 2.0 * (a[3] * a[4] * a[4] * a[5] + a[7] * a[6] * a[6] * a[5] + a[3] * (a[4] - a[6] + 1) ** 2 * a[7])
     if name == "vidi_patch_embed":                      # pixels + weight + output
         return 2.0 * (a[5] * 3 * a[6] * a[6] + a[8] * a[9] + a[5] * (a[6] // a[7]) ** 2 * a[8])
     if name == "vidi_gemm_qkv_vt":
@@ -652,6 +657,14 @@ def patch_embed(px, w, bias, pos, out, *, T, S, P):
     _rowmajor(w, "w")
     _check(load_library().vidi_patch_embed(_p(px), _p(w), _p(bias), _p(pos), _p(out), T, S, P, w.shape[0], w.shape[1], w.stride(0),
                                            out.stride(0), pos.stride(0), _dt(px), _stream()), "vidi_patch_embed")
+    return out
+
+
+def conv_window(f, w, out, *, T, side, C, k):
+    """Conv2d(C, N, k, stride 1, valid) over token-major features f [T, side*side, C] -> out [T*(side-k+1)^2, N]; w [N, k*k*C] in (dy, dx, c) order"""
+    _rowmajor(w, "w")
+    _check(load_library().vidi_conv_window(_p(f), _p(w), _p(out), T, side, C, k, w.shape[0], w.stride(0), out.stride(0), _dt(f), _stream()),
+           "vidi_conv_window")
     return out
 
 
