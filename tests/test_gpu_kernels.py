@@ -603,12 +603,12 @@ def test_patch_embed_reads_pixels_directly(hip, dt, T, S, P, Hv):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("T,side,C,k,N", [(12, 27, 1152, 14, 1152), (2, 27, 1152, 14, 1152), (3, 7, 64, 4, 64), (5, 9, 128, 3, 96), (1, 6, 64, 6, 32)])
+@pytest.mark.parametrize("T,side,C,k,N", [(12, 27, 1152, 14, 1152), (2, 27, 1152, 14, 1152), (3, 7, 64, 4, 64), (5, 9, 128, 3, 96), (3, 6, 64, 6, 32), (2, 5, 256, 1, 64)])
 def test_conv_window_gathers_in_the_loader(hip, dt, T, side, C, k, N):
     """vidi_conv_window — Vidi-7B's learned Conv2DPool conv (Vidi_7B/model/mm_vision/pool.py:19-26: Conv2d(C, C, k, stride 1, no bias)) with
     the k x k window gathered from the token-major features by the GEMM's loader — against F.conv2d in fp32 on the same rounded inputs and
     bit for bit against the im2col + GEMM form it replaces (same products, same order).  SigLIP-so400m dims (27 x 27, k = 14 -> 14 x 14
-    outputs, K = 225 792), the tiny tower, a window as large as the map."""
+    outputs, K = 225 792), the tiny tower (one K slice per window position), a window as large as the map (one output per frame), a 1 x 1 window."""
     oc = side - k + 1
     f = seeded((T, side * side, C), 180, dtype=dt); w = seeded((N, C, k, k), 181, (k * k * C) ** -0.5, dtype=dt)
     ref = F.conv2d(f.float().reshape(T, side, side, C).permute(0, 3, 1, 2), w.float()).permute(0, 2, 3, 1).reshape(T * oc * oc, N)

@@ -99,14 +99,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     // tensor — (frame, patch row, patch column) -> first pixel of the patch in channel 0, + the lane's half of the 16-pixel run — and the
     // per-slice part: the lane's chunk cg0 of slice ks belongs to patch line rr = 4 ks + (cg0 >> 1) = (channel, dy)
     unsigned pxo[PATCH != 0 ? 8 : 1], pxn[PATCH != 0 ? 8 : 1];
+    auto udiv = [](unsigned x, unsigned d, unsigned magic) { return d == 1u ? x : __umulhi(x, magic); };      // magic = floor(2^32 / d) + 1 does not exist for d = 1
     auto patch_rows = [&](int tm0, unsigned* dst) {
         if constexpr (PATCH == 1) {
             const unsigned n = (unsigned)(p.pe_side * p.pe_side);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const unsigned m = (unsigned)min(tm0 + q * 32 + r0, p.M - 1);        // rows past M repeat the last patch (masked in the epilogue)
-                const unsigned f = __umulhi(m, p.pe_nmagic), rem = m - f * n;
-                const unsigned py = __umulhi(rem, p.pe_smagic), px = rem - py * (unsigned)p.pe_side;
+                const unsigned f = udiv(m, n, p.pe_nmagic), rem = m - f * n;
+                const unsigned py = udiv(rem, (unsigned)p.pe_side, p.pe_smagic), px = rem - py * (unsigned)p.pe_side;
                 dst[q] = (((f * 3u * (unsigned)p.pe_S + py * (unsigned)p.pe_P) * (unsigned)p.pe_S + px * (unsigned)p.pe_P) << 1) + (unsigned)(cg0 & 1) * 16u;
             }
         } else if constexpr (PATCH == 2) {
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const unsigned m = (unsigned)min(tm0 + q * 32 + r0, p.M - 1);
-                const unsigned f = __umulhi(m, p.pe_nmagic), rem = m - f * n;
-                const unsigned oy = __umulhi(rem, p.pe_smagic), ox = rem - oy * oc;
+                const unsigned f = udiv(m, n, p.pe_nmagic), rem = m - f * n;
+                const unsigned oy = udiv(rem, oc, p.pe_smagic), ox = rem - oy * oc;
                 dst[q] = ((((f * (unsigned)p.pe_side + oy) * (unsigned)p.pe_side + ox) * (unsigned)p.pe_S) << 1) + (unsigned)cg0 * 16u;
             }
         }
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     auto patch_koff = [&](int ks) -> unsigned {
         if constexpr (PATCH == 2) {
             const unsigned spc = (unsigned)p.pe_S >> 6;                                   // slices per window position
-            const unsigned dd = __umulhi((unsigned)ks, p.pe_cmagic), c0 = ((unsigned)ks - dd * spc) << 6;
-            const unsigned dy = __umulhi(dd, p.pe_kmagic), dx = dd - dy * (unsigned)p.pe_P;
+            const unsigned dd = udiv((unsigned)ks, spc, p.pe_cmagic), c0 = ((unsigned)ks - dd * spc) << 6;
+            const unsigned dy = udiv(dd, (unsigned)p.pe_P, p.pe_kmagic), dx = dd - dy * (unsigned)p.pe_P;
             return (((dy * (unsigned)p.pe_side + dx) * (unsigned)p.pe_S) + c0) << 1;
         } else {
             const int rr = 4 * ks + (cg0 >> 1);
