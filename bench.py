@@ -187,7 +187,8 @@ def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False, windows=None):
                       "effective_tflops": (T * cfg.vis_select_layers * f_vis + (Nv + Na) * cfg.num_hidden_layers * f_llm +
                                            C * cfg.aud_num_layers * f_aud + (Nv + Na) * cfg.num_hidden_layers * f_x) / t_total / 1e12}
     best = max(legs, key=lambda n: legs[n]["value"])
-    return {"value": legs[best]["value"], "unit": "video-tokens/s", "cores": cores, "threads": legs[best]["threads"], "kind": "port",
+    # `cores` = the threads the winning leg actually ran on (the thread sweep picks them per leg); `host_threads` = what the box offers
+    return {"value": legs[best]["value"], "unit": "video-tokens/s", "cores": legs[best]["threads"], "host_threads": cores, "threads": legs[best]["threads"], "kind": "port",
             "dtype": best, "cpu_model": _cpu_model(),
             "sample": f"oracle (eager PyTorch, fp32 and bf16; the faster one is `value`) on {nf} frames x {vis_l} SigLIP layers, {ntok} tokens x "
                       f"{llm_l} LLM stream layers, {nwin} Whisper windows x {aud_l} layers, x-attn Lq={prompt_len} over {nk} keys x {x_calls} calls; "
