@@ -114,6 +114,28 @@ def test_vidi15_against_reference_execution(dt):
     check_case(model, D, "C", dt, n_new=2)
 
 
+@pytest.mark.parametrize("which", ["vidi15", "vidi7b"])
+def test_exact_rounding_arms_against_reference_execution(which, monkeypatch):
+    """The default engine re-rounds some weights once at load time (LayerNorm gains folded into the tower projections, the repeat_kv column
+    blocks of the stream's o_proj summed) and gathers the patch / pool windows in the GEMM loader; each of those has a switch whose OFF arm
+    keeps the reference's own rounding points and data path.  The goldens hold for that arm too (bf16)."""
+    from vidi_amd.config import tiny, tiny_7b
+    for env in ("VIDI_LN_FOLD", "VIDI_FOLD_REPKV", "VIDI_PATCH_LOADER", "VIDI_POOL_LOADER", "VIDI_STREAM_NORM2"):
+        monkeypatch.setenv(env, "0")
+    dt = torch.bfloat16
+    if which == "vidi15":
+        D = np.load(os.path.join(GOLD, "reference_dattn.npz"))
+        model = build(tiny(sliding_window=64), dt)
+        assert not model.engine.ln_fold and not model.engine.fold_repkv and not model.engine.patch_loader
+        check_case(model, D, "A", dt, n_new=6, min_agree=5)
+        check_case(model, D, "B", dt, n_new=0, with_mask=True)
+    else:
+        D = np.load(os.path.join(GOLD, "reference_dattn_7b.npz"))
+        model = build(tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64), dt)
+        assert not model.engine.ln_fold and not model.engine.fold_repkv and not model.engine.pool_loader
+        check_case(model, D, "A", dt, n_new=5)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_vidi7b_against_reference_execution(dt):
     from vidi_amd.config import tiny_7b
