@@ -58,3 +58,73 @@ def test_weight_shapes_cover_engine_needs():
     assert set(w) == set(weight_shapes(cfg))
     assert w["model.mm_rand_pos_t.mlp.0.weight"].dtype == torch.float32
     assert abs(float(w["model.mm_rand_llm_norm.weight"][0]) - cfg.mm_std) < 1e-7
+
+
+def _umulhi(a, b):
+    return (a * b) >> 32
+
+
+def test_patch_embed_weight_layout_and_gather_addresses():
+    """vidi_patch_embed's contract, emulated on the host: the re-laid weight (`hip.patch_embed_weight`: k = (c*P + dy)*16 + dx, zero
+    elsewhere) times the rows the loader gathers — slice ks, chunk cg of output row m = (frame, py, px) reads 8 pixels at
+    ((f*3*S + py*P)*S + px*P) + (rr*S + c*(S - P)*S) + 8*(cg & 1), rr = 4 ks + (cg >> 1), c = (rr >= P) + (rr >= 2P) — equals the
+    convolution; pixels past the frame / the tensor are finite garbage or zeros that only meet zero weight columns."""
+    import torch.nn.functional as F
+    from vidi_amd.hip import patch_embed_weight
+    for (T, S, P, Hv) in [(2, 98, 14, 8), (1, 384, 14, 4), (2, 64, 16, 4), (3, 40, 8, 4)]:
+        side = S // P
+        n = side * side
+        g = torch.Generator().manual_seed(S + P)
+        px = torch.randn((T, 3, S, S), generator=g)
+        w = torch.randn((Hv, 3, P, P), generator=g)
+        w16 = patch_embed_weight(w, P)
+        K = w16.shape[1]
+        assert K % 64 == 0 and K >= 3 * P * 16 and float(w16.view(Hv, -1, 16)[:, :, P:].abs().max() if P < 16 else 0.0) == 0.0
+        flat = torch.cat([px.reshape(-1), torch.full((4096,), 7.0)])       # what lies behind the tensor must not matter
+        rows = torch.zeros((T * n, K))
+        for m in range(0, T * n, max(1, (T * n) // 23)):                   # a sample of output rows (first, last, frame boundaries)
+            f, rem = divmod(m, n)
+            py, pxx = divmod(rem, side)
+            base = (f * 3 * S + py * P) * S + pxx * P
+            for ks in range(K // 64):
+                for cg in range(8):
+                    rr = 4 * ks + (cg >> 1)
+                    c = int(rr >= P) + int(rr >= 2 * P)
+                    off = base + rr * S + c * (S - P) * S + 8 * (cg & 1)
+                    rows[m, ks * 64 + cg * 8: ks * 64 + cg * 8 + 8] = flat[off: off + 8]
+        ref = F.conv2d(px, w, stride=P).flatten(2).transpose(1, 2).reshape(T * n, Hv)
+        sel = list(range(0, T * n, max(1, (T * n) // 23)))
+        assert torch.allclose((rows @ w16.T)[sel], ref[sel], atol=2e-4, rtol=1e-4)
+
+
+def test_conv_window_gather_addresses():
+    """vidi_conv_window's contract (Vidi-7B's learned Conv2DPool): slice ks of output row m = (frame, oy, ox) is 64 contiguous channels
+    c0 .. of window position (dy, dx) = divmod((ks * 64) // C, k) of the token-major [T, side*side, C] map, divisions by multiply-high
+    with magic = floor(2^32 / d) + 1 (d = 1 handled apart)."""
+    import torch.nn.functional as F
+    udiv = lambda x, d: x if d == 1 else _umulhi(x, (2 ** 32) // d + 1)          # noqa: E731
+    for (T, side, C, k, N) in [(2, 7, 64, 4, 8), (1, 27, 128, 14, 4), (3, 5, 192, 2, 8), (3, 6, 64, 6, 4), (2, 5, 256, 1, 4)]:
+        oc = side - k + 1
+        n = oc * oc
+        g = torch.Generator().manual_seed(side * 100 + k)
+        f = torch.randn((T, side * side, C), generator=g)
+        w = torch.randn((N, C, k, k), generator=g)
+        wg = w.permute(0, 2, 3, 1).reshape(N, -1)
+        flat = f.reshape(-1)
+        K = k * k * C
+        out = torch.zeros((T * n, N))
+        for m in range(T * n):
+            fr = udiv(m, n); rem = m - fr * n
+            oy = udiv(rem, oc); ox = rem - oy * oc
+            assert (fr, oy, ox) == (m // n, (m % n) // oc, (m % n) % oc)
+            base = ((fr * side + oy) * side + ox) * C
+            row = torch.zeros(K)
+            for ks in range(K // 64):
+                spc = C >> 6
+                dd = udiv(ks, spc); c0 = (ks - dd * spc) << 6
+                dy = udiv(dd, k); dx = dd - dy * k
+                koff = (dy * side + dx) * C + c0
+                row[ks * 64: ks * 64 + 64] = flat[base + koff: base + koff + 64]
+            out[m] = wg @ row
+        ref = F.conv2d(f.reshape(T, side, side, C).permute(0, 3, 1, 2), w).permute(0, 2, 3, 1).reshape(T * n, N)
+        assert torch.allclose(out, ref, atol=5e-3, rtol=1e-4)
