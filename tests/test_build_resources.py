@@ -69,3 +69,22 @@ def test_hot_kernels_do_not_spill(report):
         limit = 72 if "gemm_w4_kernel" in name else (8 if ("gemm_kernel" in name or "attn_cross2_kernel" in name) else 0)    # (cross2: two parameter blocks)
         assert res.get("SGPRs Spill", 0) <= limit, (name, res.get("SGPRs Spill"), limit)
     assert checked > 0
+
+
+def test_encoder_attention_occupancy():
+    """the d = 72 instantiation runs two query sets per wave in <= 256 registers (two waves per SIMD); every other head dim one set in
+    <= 168 (three waves per SIMD) — a register more on either side halves / cuts the resident waves with no functional symptom"""
+    path = os.path.join(BUILD, "attn_self_rm.resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("no resource report")
+    seen = 0
+    for name, res in parse(path).items():
+        m = re.search(r"attn_self_rm_kernelI\w+?Li(\d+)ELi(\d)E", name)
+        if not m:
+            continue
+        d, qs = int(m.group(1)), int(m.group(2))
+        assert qs == (2 if d == 72 else 1), name
+        assert res["Occupancy"] >= (2 if qs == 2 else 3), (name, res)
+        assert res["LDS Size"] <= 65536, (name, res)
+        seen += 1
+    assert seen == 8

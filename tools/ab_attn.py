@@ -34,6 +34,7 @@ def main():
     qkv = torch.cat([qk, vt.new_zeros((B * N, H * D))], dim=1)
     Vrm = torch.randn((B, N, H, D), generator=g, device="cuda").to(torch.bfloat16)
     qkv[:, 2 * H * D:] = Vrm.reshape(B * N, H * D)
+    hm = torch.randn((3 * B * H * N * D,), generator=g, device="cuda").to(torch.bfloat16)      # ONE head-major input for every library
     for path in list(libs):
         lib = ctypes.CDLL(path)
         if not hasattr(lib, "vidi_attn_self_rm"):
@@ -50,7 +51,6 @@ def main():
         name = path + ":rm"
         libs.append(name); outs[name], fns[name] = o, run_rm
         # the same kernel on a HEAD-MAJOR input ([3][B][H][N][D]: every head's key rows contiguous)
-        hm = torch.randn((3 * B * H * N * D,), generator=g, device="cuda").to(torch.bfloat16)
         o2 = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
 
         def run_hm(f=f, o2=o2, hm=hm):

@@ -2,7 +2,7 @@
 # SQ stall accounting of the encoder-attention kernel (two PMC passes over tools/ab_attn.py on the shipped library): where the wave-cycles
 # of attn_self_rm_kernel go — parked (s_waitcnt / barrier), issue-stalled, or issuing — and the LDS conflict share.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out
-CMD="python $GRAFT_REPO_ROOT/tools/ab_attn.py $GRAFT_REPO_ROOT/vidi_amd/libvidi_hip.so --frames 360"
+CMD="python $GRAFT_REPO_ROOT/tools/ab_attn.py $GRAFT_REPO_ROOT/${VIDI_PMC_LIB:-vidi_amd/libvidi_hip.so} --frames 360"      # VIDI_PMC_LIB: a variant library (tools/build_variant.sh)
 (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_attn1 -o a -- $CMD > /dev/null 2> $OUT/pmc_attn1.err)
 (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_attn2 -o a -- $CMD > /dev/null 2> $OUT/pmc_attn2.err)
 python - <<'PY'

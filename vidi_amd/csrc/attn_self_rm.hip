@@ -27,15 +27,47 @@
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
-#ifndef VIDI_ATTN_RM_QS
-#define VIDI_ATTN_RM_QS 1              // query sets of 32 per wave (lab knob): 2 = a 256-query block, each wave runs two independent
-#endif                                 // softmax / PV chains against every K / V tile (half the rendezvous and tile DMA per query).
-                                       // Measured (tools/ab_attn.py): 228 VGPRs -> 2 waves/SIMD, the compiler runs the two chains back
-                                       // to back, 399 vs 636 useful TFLOP/s — the in-wave overlap needs a hand-built schedule.
+#ifndef VIDI_ATTN_RM_QS72
+#define VIDI_ATTN_RM_QS72 2            // query sets of 32 per wave in the d = 72 instantiation (SigLIP): 2 = a 256-query block whose waves run
+#endif                                 // TWO softmax / PV chains against every K / V tile, software-pipelined by hand (see the tile body): the
+                                       // K / V fragments are read from LDS once for both, the tile DMA and the rendezvous are per 256 queries, and
+                                       // the matrix work of one chain is issued between the softmax instructions of the other.  238 VGPRs -> two
+                                       // waves per SIMD.  Left to the compiler the two chains ran back to back (399 vs 636 useful TFLOP/s in
+                                       // round 2); pipelined: 714 -> 747 on the SigLIP shape, bit-identical (profiles/r3_ab_attn_pipe.jsonl).
+                                       // Every other head dim keeps one set per wave (three waves per SIMD).
+template <int D> constexpr int attn_rm_qs() { return D == 72 ? VIDI_ATTN_RM_QS72 : 1; }
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
-    constexpr int QS = VIDI_ATTN_RM_QS, QB = 128 * QS;
+#ifndef VIDI_ATTN_RM_TRASM
+#define VIDI_ATTN_RM_TRASM 1           // 1: the V transpose reads are inline asm.  Through the builtin the compiler cannot tell that the LDS-DMA
+#endif                                 // of tile t + 1 (issued at the top of tile t) writes the OTHER ring slot and puts `s_waitcnt vmcnt(0)` in
+                                       // front of the first transpose read of every tile: the prefetch was waited for one instruction after its
+                                       // issue.  As asm the reads carry no memory operand; their completion is waited for explicitly (tr_wait).
+// one 64-bit LDS transpose read; OFF is an instruction immediate
+#define VIDI_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+// every LDS read issued so far has returned; the 12 raw halves pass through so that their consumers are ordered behind the wait
+template <int N>
+__device__ __forceinline__ void tr_wait(u32x2 (&r)[12]) {
+    static_assert(N == 4 || N == 8 || N == 12, "halves in use");
+    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]));
+}
+template <int V> struct IntC { static constexpr int value = V; };
+#ifndef VIDI_ATTN_RM_FLATDMA
+#define VIDI_ATTN_RM_FLATDMA 1         // d = 72, two query sets: the tile DMA as five branch-free instructions per wave (see issue_dma_flat)
+#endif
+#ifndef VIDI_ATTN_RM_VF0
+#define VIDI_ATTN_RM_VF0 2             // softmax chunk of step 1 after which the V fragments of sub-tile 0 are requested
+#endif
+#ifndef VIDI_ATTN_RM_PRE1
+#define VIDI_ATTN_RM_PRE1 2            // matrix instructions placed before the running-max branch of a pipelined step (steps 1 and 4 / 2 and 3)
+#endif
+#ifndef VIDI_ATTN_RM_PRE2
+#define VIDI_ATTN_RM_PRE2 3
+#endif
+template <typename T, int D, int QS>
+__global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams p) {      // (QS = 2: two waves per SIMD, 256 registers)
+    constexpr int QB = 128 * QS;
     constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
     constexpr int NCH = D / 8;                 // 16-byte chunks per head row
     constexpr int DT = (D + 31) / 32;          // 32-wide output d tiles
@@ -65,7 +97,9 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     constexpr bool kOnesRow = (DT * 32 > D);
     constexpr int CROWB = TAILC ? 16 : MROWB, CBYTES = kOnesRow ? 64 * CROWB : 0;
     constexpr int RING = 2 * BUF > 128 * ORW ? 2 * BUF : 128 * ORW;
-    __shared__ __attribute__((aligned(16))) char smem[RING + CBYTES];   // 2-deep K/V ring (+ the ones / zeros constant rows)
+    static_assert(RING + CBYTES <= 65536, "static LDS");
+    __shared__ __attribute__((aligned(16))) char smem[RING + CBYTES];   // 2-deep K/V ring (+ the ones / zeros constant rows); a 3-deep ring
+                                                                        // (tile t + 2 in flight) measured 4 % slower: the DMA latency is covered
     auto kswz = [](int r) { return NCH == 8 ? ((r >> 1) & 7) : (NCH == 4 ? ((r >> 2) & 3) : 0); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +139,9 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         for (int s = 0; s < KS; ++s) {
             const int c = 2 * s + hi;
             qf[qs][s] = (c < NCH) ? *(const u32x4*)(qrow + c * 8) : u32x4{0, 0, 0, 0};
+        }
+        if constexpr (QS == 2 && D == 72) {      // the tail bias rides in contraction chunk 9 (see load_kf)
+            if (hi) qf[qs][KS - 1][0] = (unsigned)T::from_f32(1.0f);
         }
     }
 
@@ -164,7 +201,32 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             if (wave == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sV + VMAIN), 16, (unsigned)(lane * p.ld + MAINC) * 2u, so, 0, 0);
         }
     };
+    // d = 72, two query sets: the same 18 pieces (9 K + 8 V + the V tail) as exactly FIVE instructions per wave and no branches — the
+    // wave-dependent choices (which piece, its LDS address, which descriptor) are made once, here.  Slot 2 of waves 0-1 is K piece 8, of
+    // waves 2-3 the V tail: both are fetched twice (same bytes to the same LDS address), which costs 2 KB of L2 reads per tile and saves
+    // ~25 scalar instructions and 10 branches per tile and wave (the loop is instruction-issue-bound).
+    constexpr bool kFlatDma = (QS == 2 && D == 72 && VIDI_ATTN_RM_SRD != 0 && VIDI_ATTN_RM_FLATDMA != 0);
+    unsigned fvo2 = 0;
+    int fdst2 = 0;
+    __amdgpu_buffer_rsrc_t srdM = srdK;
+    if constexpr (kFlatDma) {
+        static_assert(!kFlatDma || (KRND == 3 && VRND == 2 && MCH == 8 && TAILC == 8), "piece map of d = 72");
+        const int i2 = 512 + lane;                                   // K piece 8: chunks 512 .. 575 (no swizzle at 9 chunks per row)
+        fvo2 = wave < 2 ? (unsigned)((i2 / NCH) * p.ld + (i2 % NCH) * 8) * 2u : (unsigned)(lane * p.ld + MAINC) * 2u;
+        fdst2 = wave < 2 ? 8 * 1024 : KBYTES + VMAIN;
+        srdM = wave < 2 ? srdK : srdV;
+    }
+    auto issue_dma_flat = [&](int kb, auto bufi) {
+        char* sK = smem + bufi * BUF;
+        const unsigned so = (unsigned)kb * (unsigned)p.ld * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdK, (__attribute__((address_space(3))) void*)(sK + wave * 1024), 16, (unsigned)(krow[0] * p.ld + kcol[0]) * 2u, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdK, (__attribute__((address_space(3))) void*)(sK + 4096 + wave * 1024), 16, (unsigned)(krow[1] * p.ld + kcol[1]) * 2u, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdM, (__attribute__((address_space(3))) void*)(sK + fdst2), 16, (int)fvo2, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sK + KBYTES + wave * 1024), 16, (unsigned)(vrow[0] * p.ld + vcol[0]) * 2u, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sK + KBYTES + 4096 + wave * 1024), 16, (unsigned)(vrow[1] * p.ld + vcol[1]) * 2u, so, 0, 0);
+    };
     auto issue_dma = [&](int kb, int bufi) {
+        if constexpr (kFlatDma) { issue_dma_flat(kb, bufi); return; }
         if constexpr (VIDI_ATTN_RM_SRD != 0) { issue_dma_srd(kb, bufi); return; }
         char* sK = smem + bufi * BUF;
         char* sV = sK + KBYTES;
@@ -212,9 +274,12 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-    float m_run[QS], l_run[QS];                          // m_run in base-2 logit units (score * scale * log2 e)
+    // running maximum in base-2 logit units (score * scale * log2 e), kept as the two values the loop uses every sub-tile — its negative
+    // (the addend of the exponent FMAs) and the rescale threshold m + TAU — so that the common no-rescale case costs one multiply and
+    // one compare after the max tree (the loop is issue-bound: every instruction counts)
+    float nm_run[QS], thr_run[QS], l_run[QS];
 #pragma unroll
-    for (int qs = 0; qs < QS; ++qs) { m_run[qs] = -INFINITY; l_run[qs] = 0.f; }
+    for (int qs = 0; qs < QS; ++qs) { nm_run[qs] = INFINITY; thr_run[qs] = -INFINITY; l_run[qs] = 0.f; }
     const float sc = p.scale * 1.4426950408889634f;      // fold log2(e): softmax in base 2
 
     const int ntiles = (p.N + 63) / 64;
@@ -230,14 +295,134 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         const int kb = t * 64;
         wait_vmcnt<0>();                                  // my pieces of tile t have landed ...
         __syncthreads();                                  // ... everyone's have, and tile t-1's buffer is free
+        const int slot = t & 1;
         if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
-        const char* sK = smem + (t & 1) * BUF;
+        const char* sK = smem + slot * BUF;
         const __attribute__((address_space(3))) char* lds0 = (const __attribute__((address_space(3))) char*)smem;
         int va[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + (t & 1) * vstep[dt];
+        for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + slot * vstep[dt];
         const bool tail = (kb + 64 > p.N);
 
+      if constexpr (QS == 2 && D == 72) {
+        // ---- two query sets, software-pipelined by hand: the matrix work of one set is issued between the softmax VALU of the other ----
+        // items (set, 32-key sub-tile) in the order (A,0) (B,0) (A,1) (B,1); step i runs the softmax of item i on the VALU while the
+        // matrix pipe takes QK^T of item i+1 and PV of item i-1.  K fragments of a sub-tile are read ONCE for both sets, so are V's.
+        // Source order = the intended issue order (a matrix instruction leads every chunk of two probabilities); the compiler's own placement inside
+        // a basic block measured better than sched_group_barrier patterns (-2 %), so only two things are pinned: the exponentials stay in their
+        // step's block (LLVM would sink them to their users in the next one), and the rare rescale is out of line.
+        auto QKm = [&](int s, const u32x4 (&kf)[KS], int qs, f32x16& S) __attribute__((always_inline)) { S = T::mfma32(kf[s], qf[qs][s], s == 0 ? zero16 : S); };
+        auto PVm = [&](int j, const u32x4 (&vf)[DT][2], int qs, const u32x4& pf0, const u32x4& pf1) __attribute__((always_inline)) {
+            const int dt = j % DT, m = j / DT;
+            o[qs][dt] = T::mfma32(vf[dt][m], m ? pf1 : pf0, o[qs][dt]);
+        };
+        auto load_kf = [&](int u, u32x4 (&kf)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kf[s] = *(const u32x4*)(sK + (u * 32 + l31) * ROWB + (((2 * s + hi) ^ ksw) << 4));
+            // keys past N, without a branch and without touching the scores: d = 72 leaves contraction chunk 9 (the hi lanes of the last
+            // k-step) empty; Q carries 1.0 in its first slot, K a bias: 0 for a real key, -inf for one past N — the matrix pipe adds it
+            // (x + 0 = x exactly; x - inf = -inf: what masking the score would have given)
+            constexpr unsigned NEG_INF = T::id == VIDI_DT_BF16 ? 0xff80u : 0xfc00u;      // -inf in T
+            const unsigned bias = (kb + u * 32 + l31 >= p.N) ? NEG_INF : 0u;
+            kf[KS - 1][0] = hi ? bias : kf[KS - 1][0];
+        };
+        u32x2 vraw[12];
+        auto load_vf = [&](int u, u32x4 (&vf)[DT][2]) __attribute__((always_inline)) {
+            static_assert(DT * 4 <= 12, "raw halves");
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int rowb = dt * 32 < MAINC ? MROWB : 16;
+                    if constexpr (VIDI_ATTN_RM_TRASM != 0) {
+                        const unsigned a = (unsigned)(uintptr_t)(lds0 + va[dt]);
+                        VIDI_TR_READ(vraw[(dt * 2 + m) * 2], a, (u * 32 + 16 * m) * rowb);
+                        VIDI_TR_READ(vraw[(dt * 2 + m) * 2 + 1], a, (u * 32 + 16 * m + 8) * rowb);
+                    } else {
+                        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m) * rowb));
+                        const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m + 8) * rowb));
+                        const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
+                        vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                    }
+                }
+        };
+        auto vf_ready = [&](u32x4 (&vf)[DT][2]) __attribute__((always_inline)) {        // before the first PV of a sub-tile
+            if constexpr (VIDI_ATTN_RM_TRASM != 0) {
+                tr_wait<DT * 4>(vraw);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const u32x2 a = vraw[(dt * 2 + m) * 2], c = vraw[(dt * 2 + m) * 2 + 1];
+                        vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                    }
+            }
+        };
+        constexpr float TAU = 8.0f;
+        // running max of an item (+ the rare rescale): ends in a branch.  NPRE matrix instructions go in front of it.
+        auto sm_a = [&](int qs, f32x16& S, auto&& M, auto npre) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < decltype(npre)::value; ++c) M(c);
+            float mx = S[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+            mx = xhalf_max(mx);
+            float mxs = mx * sc;
+            if (__builtin_expect(__any(mxs > thr_run[qs]), 0)) {
+                asm volatile("" : "+v"(mxs));                    // (keeps the rare path's arithmetic inside the branch: LLVM speculates it above)
+                const float m_cand = fmaxf(-nm_run[qs], mxs);
+                const float alpha = fast_exp2(-nm_run[qs] - m_cand);
+                nm_run[qs] = -m_cand; thr_run[qs] = m_cand + TAU;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
+            }
+        };
+        // exponentials + packing of an item in 8 chunks of 2 probabilities; matrix instruction M(c) leads chunk c
+        auto sm_b = [&](int qs, const f32x16& S, u32x4& pf0, u32x4& pf1, auto&& M) __attribute__((always_inline)) {
+            unsigned w[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                M(c);
+                const float e0 = fast_exp2(__builtin_fmaf(S[2 * c], sc, nm_run[qs]));
+                const float e1 = fast_exp2(__builtin_fmaf(S[2 * c + 1], sc, nm_run[qs]));
+                w[c] = pack2<T>(e0, e1);
+            }
+#pragma unroll
+            for (int c = 8; c < 12; ++c) M(c);           // (matrix instructions beyond the 8 chunks, if the step has more)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(w[c]));       // keep the exponentials in THIS block (they are pure: LLVM sinks them to their users)
+            pf0 = u32x4{w[0], w[1], w[2], w[3]}; pf1 = u32x4{w[4], w[5], w[6], w[7]};
+        };
+        constexpr int P1 = VIDI_ATTN_RM_PRE1, P2 = VIDI_ATTN_RM_PRE2;
+        u32x4 kf[KS], vf[DT][2], pa0, pa1, pb0, pb1;
+        f32x16 SA, SB;
+        load_kf(0, kf);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) QKm(s, kf, 0, SA);
+        // step 1: softmax (A,0)  ||  QK (B,0)  [KS]
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < KS) QKm(i, kf, 1, SB); };
+          sm_a(0, SA, M, IntC<P1>{});
+          sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P1); if (c + P1 == KS - 1) load_kf(1, kf); if (c == VIDI_ATTN_RM_VF0) load_vf(0, vf); }); }
+        // step 2: softmax (B,0)  ||  PV (A,0) [2 DT], QK (A,1) [KS]
+        vf_ready(vf);
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
+          sm_a(1, SB, M, IntC<P2>{});
+          sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P2); }); }
+        // step 3: softmax (A,1)  ||  PV (B,0), QK (B,1); V fragments of sub-tile 1 replace sub-tile 0's once its last PV has been issued
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB); };
+          sm_a(0, SA, M, IntC<P2>{});
+          sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P2); if (c + P2 == 2 * DT - 1) load_vf(1, vf); }); }
+        // step 4: softmax (B,1)  ||  PV (A,1)
+        vf_ready(vf);
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); };
+          sm_a(1, SB, M, IntC<P1>{});
+          sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P1); }); }
+        // step 5: PV (B,1)
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) PVm(j, vf, 1, pb0, pb1);
+      } else
 #pragma unroll
       for (int qs = 0; qs < QS; ++qs) {
         f32x16 s2[2];
@@ -252,17 +437,28 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
         VIDI_ATTN_RM_PRIO_LO(1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            // (the asm reads are invisible to the compiler's lgkmcnt accounting: a K fragment consumed after them would wait for them too)
+            if constexpr (VIDI_ATTN_RM_TRASM != 0) { if (u == 0) __builtin_amdgcn_sched_barrier(0); }
             // A fragments of the PV MFMAs: contraction slots 8 hi + {0..3 | 4..7} of MFMA 0 hold keys 4 hi + {0..3} and 8 + 4 hi + {0..3}
             // of the sub-tile (where the swapped QK^T left them in pv[0..7]); MFMA 1 the same 16 keys further
             u32x4 vf[DT][2];
+            u32x2 vraw[12];
+            static_assert(DT * 4 <= 12, "raw halves");
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m) * (dt * 32 < MAINC ? MROWB : 16)));
-                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m + 8) * (dt * 32 < MAINC ? MROWB : 16)));
-                    const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
-                    vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                    const int rowb = dt * 32 < MAINC ? MROWB : 16;
+                    if constexpr (VIDI_ATTN_RM_TRASM != 0) {
+                        const unsigned a = (unsigned)(uintptr_t)(lds0 + va[dt]);
+                        VIDI_TR_READ(vraw[(dt * 2 + m) * 2], a, (u * 32 + 16 * m) * rowb);
+                        VIDI_TR_READ(vraw[(dt * 2 + m) * 2 + 1], a, (u * 32 + 16 * m + 8) * rowb);
+                    } else {
+                        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m) * rowb));
+                        const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m + 8) * rowb));
+                        const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
+                        vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                    }
                 }
             if (tail) {
 #pragma unroll
@@ -275,10 +471,12 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s2[u][r]);
             mx = xhalf_max(mx);
             constexpr float TAU = 8.0f;
-            const float m_cand = fmaxf(m_run[qs], mx * sc);
-            if (__any(m_cand > m_run[qs] + TAU)) {                 // also the very first sub-tile (m_run = -inf)
-                const float alpha = fast_exp2(m_run[qs] - m_cand); // 0 on the first sub-tile (o = l = 0 there)
-                m_run[qs] = m_cand;
+            float mxs = mx * sc;
+            if (__builtin_expect(__any(mxs > thr_run[qs]), 0)) {      // also the very first sub-tile (m = -inf)
+                asm volatile("" : "+v"(mxs));                      // (keeps the rare path's arithmetic inside the branch: LLVM speculates it above)
+                const float m_cand = fmaxf(-nm_run[qs], mxs);
+                const float alpha = fast_exp2(-nm_run[qs] - m_cand); // 0 on the first sub-tile (o = l = 0 there)
+                nm_run[qs] = -m_cand; thr_run[qs] = m_cand + TAU;
                 l_run[qs] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
@@ -289,12 +487,22 @@ __global__ __launch_bounds__(256) void attn_self_rm_kernel(AttnSelfRmParams p) {
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, -m_run[qs]));      // (as packed pairs, v_pk_fma_f32: measured 2 % slower)
-                pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, -m_run[qs]));
+                pv[r] = fast_exp2(__builtin_fmaf(s2[u][r], sc, nm_run[qs]));      // (as packed pairs, v_pk_fma_f32: measured 2 % slower)
+                pv[r + 1] = fast_exp2(__builtin_fmaf(s2[u][r + 1], sc, nm_run[qs]));
                 if constexpr (!kOnesRow) { ps0 += pv[r]; ps1 += pv[r + 1]; }
             }
             const u32x4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
             if constexpr (!kOnesRow) l_run[qs] += ps0 + ps1;
+            if constexpr (VIDI_ATTN_RM_TRASM != 0) {                 // the V fragments have had the whole softmax to arrive
+                tr_wait<DT * 4>(vraw);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const u32x2 a = vraw[(dt * 2 + m) * 2], c = vraw[(dt * 2 + m) * 2 + 1];
+                        vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                    }
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 o[qs][dt] = T::mfma32(vf[dt][0], pf0, o[qs][dt]);
@@ -346,8 +554,8 @@ int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipS
     if (p.B <= 0 || p.N <= 0 || p.H <= 0) return VIDI_ERR_SHAPE;
     if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8) || (p.bs % 8) || (p.hs % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)p.QKV & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
-    const dim3 grid(((p.N + 128 * VIDI_ATTN_RM_QS - 1) / (128 * VIDI_ATTN_RM_QS)) * p.H * p.B);
-#define LAUNCH(TT, DD) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD>), grid, dim3(256), 0, st, p)
+#define LAUNCH(TT, DD) do { constexpr int QB = 128 * attn_rm_qs<DD>();                                                                \
+        hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD, attn_rm_qs<DD>()>), dim3(((p.N + QB - 1) / QB) * p.H * p.B), dim3(256), 0, st, p); } while (0)
     if (dtype == VIDI_DT_BF16) {
         if (D == 72) LAUNCH(BF16, 72); else if (D == 64) LAUNCH(BF16, 64); else if (D == 16) LAUNCH(BF16, 16);
         else if (D == 32) LAUNCH(BF16, 32); else return VIDI_ERR_SHAPE;
