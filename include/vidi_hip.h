@@ -147,7 +147,11 @@ int vidi_attn_self(const void* QK, const void* Vt, void* O, int B, int N, int Np
  *   row-major  [B*N, ld]            bs = 0 (-> N*ld), hs = 0 (-> D), koff / voff = column offsets            (vidi_gemm / vidi_gemm_ln output)
  *   head-major [3][B][H][N][D]      ld = D, bs = H*N*D, hs = N*D, koff = B*H*N*D, voff = 2*B*H*N*D           (vidi_gemm_ln_heads output)
  * Head-major makes every K / V tile whole 128-byte lines (+12 % on this kernel).  O:[B*N, ldo] row-major, head h at column h*D.
- * Same results as vidi_attn_self (bit-identical: same MFMA operands in the same slots). */
+ * Same results as vidi_attn_self (bit-identical: same MFMA operands in the same slots).
+ * scale > 0: softmax(scale * q.k).  scale <= 0: the caller has folded scale * log2(e) into Q (e.g. into the q projection's weights): the
+ * kernel computes 2^(q.k) normalised — the same function, without a per-score multiply; with D = 72 the running maximum then rides
+ * in the spare contraction chunk of the QK^T product (rounded to the storage dtype), so the exponent's argument comes straight out of
+ * the matrix pipe. */
 int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int ld, long long koff, long long voff, long long bs, long long hs,
                       int ldo, float scale, int dtype, void* stream);
 

@@ -44,10 +44,14 @@ def _tower_cfg(**over):
     return tiny(**over)
 
 
-@pytest.mark.parametrize("fold", ["1", "0"], ids=["ln_fold", "ln_plain"])
+@pytest.mark.parametrize("fold", ["1", "1u", "0"], ids=["ln_fold", "ln_fold_unscaled_q", "ln_plain"])
 def test_siglip_tower_real_dims_full_depth(fold, monkeypatch):
+    """(ln_fold: the default arm — LayerNorms folded, softmax scale folded into q, maximum inside the contraction; ln_fold_unscaled_q:
+    VIDI_ATTN_PRESCALE=0; ln_plain: no folds)"""
     from test_gpu_model import make, oracle_cfg
     dt = torch.bfloat16
+    if fold == "1u":
+        monkeypatch.setenv("VIDI_ATTN_PRESCALE", "0"); fold = "1"
     monkeypatch.setenv("VIDI_LN_FOLD", fold)
     cfg = _tower_cfg(vis_image_size=384, vis_patch_size=14, vis_hidden_size=1152, vis_intermediate_size=4304, vis_num_layers=27,
                      vis_num_heads=16, vis_frames_per_chunk=16)

@@ -403,6 +403,37 @@ def test_attn_self_rm(hip, dt, D, N, H, B):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("D,N,H,B", [(72, 729, 3, 2), (72, 729, 16, 9), (72, 64, 2, 8), (72, 50, 2, 3), (72, 300, 4, 2), (64, 1500, 2, 1), (16, 49, 4, 3)])
+def test_attn_self_rm_prescaled_q(hip, dt, D, N, H, B):
+    """scale <= 0: Q already carries scale * log2(e) (the towers fold it into the q projection's weights).  d = 72 then takes the running
+    maximum inside the QK^T contraction (the kernel's spare contraction chunk) and the exponent needs no FMA; every other head dim runs
+    the ordinary body with a unit scale.  Checked against the oracle on the SAME rounded Q (softmax of q'.k * ln 2), with planted score
+    outliers late in the key range so that the running maximum moves by more than the lazy-rescale threshold after the first tile, and
+    with large negative scores everywhere (the first sub-tile must establish the maximum, not assume 0)."""
+    import math
+    Hd = H * D
+    q = seeded((B, N, H, D), 40, dtype=dt); k = seeded((B, N, H, D), 41, dtype=dt); v = seeded((B, N, H, D), 42, 1.0, dtype=dt) + 0.25
+    if N >= 300:
+        k[:, N - 7] = (q[:, 5].float() * 6.0).to(dt)              # a key aligned with query 5 of every head: a late, large maximum
+    sc2 = D ** -0.5 * math.log2(math.e)
+    for shift in (0.0, -40.0):                                     # -40: every score far below zero (constant offset through one q/k column pair)
+        qq, kk = q.clone(), k.clone()
+        if shift:
+            qq[..., 0] = 4.0; kk[..., 0] = shift / 4.0 / sc2
+        qs = (qq.float() * sc2).to(dt)
+        ref = O.sdpa_reference(qs.float().transpose(1, 2), kk.float().transpose(1, 2), v.float().transpose(1, 2), math.log(2.0))
+        ref = ref.transpose(1, 2).reshape(B * N, Hd)
+        hm = torch.stack([qs.permute(0, 2, 1, 3), kk.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)]).contiguous()
+        out = torch.zeros((B * N, Hd), dtype=dt).cuda()
+        hip.attn_self_rm(dev(hm), out, B=B, N=N, H=H, D=D, scale=0.0, head_major=True)
+        report(f"attn_self_rm prescaled D{D} N{N} shift{shift}", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
+        # the ordinary form on the same operands (scale = ln 2 -> unit factor in base 2): same math, different max rounding
+        out2 = torch.zeros((B * N, Hd), dtype=dt).cuda()
+        hip.attn_self_rm(dev(hm), out2, B=B, N=N, H=H, D=D, scale=math.log(2.0), head_major=True)
+        report(f"attn_self_rm prescaled vs scaled form D{D} N{N} shift{shift}", out, out2.float().cpu(), *tol(dt, max(0.05, ref.std().item()), k=2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("seq,frames,heads,hd,K,cfg", [(729, 18, 16, 72, 1152, -1), (49, 3, 4, 16, 192, -1), (49, 3, 4, 16, 192, 0), (1500, 9, 20, 64, 1280, 5)])
 def test_gemm_ln_heads_is_gemm_ln_rearranged(hip, dt, seq, frames, heads, hd, K, cfg):
     """the head-major q/k/v projection equals the row-major one with its columns / rows regrouped: Y[which][frame][head][token][d]"""

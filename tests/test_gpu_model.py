@@ -301,7 +301,7 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
     cfg, eng, w32, dt = tiny_setup
     names = {"ln_fold": "VIDI_LN_FOLD", "attn_rm": "VIDI_ATTN_RM", "stream_norm2": "VIDI_STREAM_NORM2", "fold_repkv": "VIDI_FOLD_REPKV",
              "decode_attn": "VIDI_DECODE_ATTN", "cross_dual": "VIDI_CROSS_DUAL", "decode_norm_gemv": "VIDI_DECODE_NORM_GEMV",
-             "decode_tail": "VIDI_DECODE_TAIL", "patch_loader": "VIDI_PATCH_LOADER"}
+             "decode_tail": "VIDI_DECODE_TAIL", "patch_loader": "VIDI_PATCH_LOADER", "attn_prescale": "VIDI_ATTN_PRESCALE"}
     assert all(getattr(eng, n) for n in names), "the fixture engine runs the default arms"
     for env in names.values():
         monkeypatch.setenv(env, "0")

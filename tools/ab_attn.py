@@ -35,6 +35,8 @@ def main():
     Vrm = torch.randn((B, N, H, D), generator=g, device="cuda").to(torch.bfloat16)
     qkv[:, 2 * H * D:] = Vrm.reshape(B * N, H * D)
     hm = torch.randn((3 * B * H * N * D,), generator=g, device="cuda").to(torch.bfloat16)      # ONE head-major input for every library
+    hm_ps = hm.clone()                                                                          # the same input with scale * log2(e) folded into Q
+    hm_ps[: B * H * N * D] = (hm[: B * H * N * D].float() * (D ** -0.5 * 1.4426950408889634)).to(torch.bfloat16)
     for path in list(libs):
         lib = ctypes.CDLL(path)
         if not hasattr(lib, "vidi_attn_self_rm"):
@@ -59,8 +61,17 @@ def main():
             assert rc == 0, rc
         run_hm(); torch.cuda.synchronize()
         libs.append(path + ":rm_headmajor"); outs[path + ":rm_headmajor"], fns[path + ":rm_headmajor"] = o2, run_hm
+        # head-major with the scale folded into Q by the caller (scale = 0): d = 72 takes the max inside the contraction
+        o3 = torch.empty((B * N, H * D), dtype=torch.bfloat16, device="cuda")
+
+        def run_ps(f=f, o3=o3, hm=hm_ps):
+            rc = f(hm.data_ptr(), o3.data_ptr(), B, N, H, D, D, B * H * N * D, 2 * B * H * N * D, H * N * D, N * D, H * D, 0.0, 0,
+                   torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        run_ps(); torch.cuda.synchronize()
+        libs.append(path + ":rm_prescaled"); outs[path + ":rm_prescaled"], fns[path + ":rm_prescaled"] = o3, run_ps
     # every library's result per mode (Vt kernel, rm on row-major input, rm on head-major input) against the FIRST library's
-    for mode in ("", ":rm", ":rm_headmajor"):
+    for mode in ("", ":rm", ":rm_headmajor", ":rm_prescaled"):
         same = [x for x in libs if (x.endswith(mode) if mode else ":rm" not in x)]
         for path in same[1:]:
             print(json.dumps({"lib": path, "bit_identical_to_first": bool(torch.equal(outs[path], outs[same[0]])),

@@ -65,9 +65,10 @@ template <int V> struct IntC { static constexpr int value = V; };
 #ifndef VIDI_ATTN_RM_PRE2
 #define VIDI_ATTN_RM_PRE2 3
 #endif
-template <typename T, int D, int QS>
+template <typename T, int D, int QS, bool PS>
 __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams p) {      // (QS = 2: two waves per SIMD, 256 registers)
     constexpr int QB = 128 * QS;
+    static_assert(!PS || (QS == 2 && D == 72), "the max-in-the-contraction form needs the spare contraction chunk of d = 72");
     constexpr int KS = (D + 15) / 16;          // k16 steps of the QK^T contraction
     constexpr int NCH = D / 8;                 // 16-byte chunks per head row
     constexpr int DT = (D + 31) / 32;          // 32-wide output d tiles
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
             const int c = 2 * s + hi;
             qf[qs][s] = (c < NCH) ? *(const u32x4*)(qrow + c * 8) : u32x4{0, 0, 0, 0};
         }
-        if constexpr (QS == 2 && D == 72) {      // the tail bias rides in contraction chunk 9 (see load_kf)
+        if constexpr (QS == 2 && D == 72) {      // the tail bias rides in contraction chunk 9 (see load_kf); PS: so does -max (slot 1, 0 at first)
             if (hi) qf[qs][KS - 1][0] = (unsigned)T::from_f32(1.0f);
         }
     }
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
     // one compare after the max tree (the loop is issue-bound: every instruction counts)
     float nm_run[QS], thr_run[QS], l_run[QS];
 #pragma unroll
-    for (int qs = 0; qs < QS; ++qs) { nm_run[qs] = INFINITY; thr_run[qs] = -INFINITY; l_run[qs] = 0.f; }
-    const float sc = p.scale * 1.4426950408889634f;      // fold log2(e): softmax in base 2
+    for (int qs = 0; qs < QS; ++qs) { nm_run[qs] = PS ? 0.f : INFINITY; thr_run[qs] = -INFINITY; l_run[qs] = 0.f; }
+    const float sc = p.scale > 0.f ? p.scale * 1.4426950408889634f : 1.0f;      // fold log2(e): softmax in base 2 (scale <= 0: Q carries it)
 
     const int ntiles = (p.N + 63) / 64;
     const int ksw = kswz(l31);
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
             // k-step) empty; Q carries 1.0 in its first slot, K a bias: 0 for a real key, -inf for one past N — the matrix pipe adds it
             // (x + 0 = x exactly; x - inf = -inf: what masking the score would have given)
             constexpr unsigned NEG_INF = T::id == VIDI_DT_BF16 ? 0xff80u : 0xfc00u;      // -inf in T
-            const unsigned bias = (kb + u * 32 + l31 >= p.N) ? NEG_INF : 0u;
+            constexpr unsigned ONE_HI = PS ? ((unsigned)(T::id == VIDI_DT_BF16 ? 0x3f80u : 0x3c00u) << 16) : 0u;      // PS: K's slot 1 = 1.0 (times Q's -max)
+            const unsigned bias = ((kb + u * 32 + l31 >= p.N) ? NEG_INF : 0u) | ONE_HI;
             kf[KS - 1][0] = hi ? bias : kf[KS - 1][0];
         };
         u32x2 vraw[12];
@@ -367,6 +369,26 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
             mx = xhalf_max(mx);
+            if constexpr (PS) {
+                // S already is (score - max~) in base-2 units: Q carries the scale (host contract: scale <= 0) and -max~ in contraction slot 73
+                // (K has 1.0 there), max~ = the running maximum ROUNDED TO T (any reference works as long as every term uses the same one).
+                // nm_run = -max~ (the slot's value, 0 before the first sub-tile), thr_run = -inf before the first sub-tile, then TAU.
+                if (__builtin_expect(__any(mx > thr_run[qs]), 0)) {
+                    asm volatile("" : "+v"(mx));
+                    const float m_new = T::to_f32(T::from_f32(mx - nm_run[qs]));          // max~ of everything seen so far
+                    const float delta = -nm_run[qs] - m_new;                               // exact: both are T values
+                    const float alpha = fast_exp2(delta + fminf(thr_run[qs], 0.f));       // 0 on the first sub-tile (o = 0 there; -max~ may be huge)
+                    nm_run[qs] = -m_new; thr_run[qs] = TAU;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[r] += delta;                            // this item's scores were formed with the old slot value
+                    if (hi) qf[qs][KS - 1][0] = (unsigned)T::from_f32(1.0f) | ((unsigned)T::from_f32(-m_new) << 16);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
+                }
+                return;
+            }
             float mxs = mx * sc;
             if (__builtin_expect(__any(mxs > thr_run[qs]), 0)) {
                 asm volatile("" : "+v"(mxs));                    // (keeps the rare path's arithmetic inside the branch: LLVM speculates it above)
@@ -385,8 +407,8 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 M(c);
-                const float e0 = fast_exp2(__builtin_fmaf(S[2 * c], sc, nm_run[qs]));
-                const float e1 = fast_exp2(__builtin_fmaf(S[2 * c + 1], sc, nm_run[qs]));
+                const float e0 = PS ? fast_exp2(S[2 * c]) : fast_exp2(__builtin_fmaf(S[2 * c], sc, nm_run[qs]));
+                const float e1 = PS ? fast_exp2(S[2 * c + 1]) : fast_exp2(__builtin_fmaf(S[2 * c + 1], sc, nm_run[qs]));
                 w[c] = pack2<T>(e0, e1);
             }
 #pragma unroll
@@ -555,7 +577,10 @@ int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipS
     if ((p.ld % 8) || (p.koff % 8) || (p.voff % 8) || (p.ldo % 8) || (p.bs % 8) || (p.hs % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)p.QKV & 15) || ((uintptr_t)p.O & 15)) return VIDI_ERR_ALIGN;
 #define LAUNCH(TT, DD) do { constexpr int QB = 128 * attn_rm_qs<DD>();                                                                \
-        hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD, attn_rm_qs<DD>()>), dim3(((p.N + QB - 1) / QB) * p.H * p.B), dim3(256), 0, st, p); } while (0)
+        constexpr bool CAN_PS = (DD == 72 && attn_rm_qs<DD>() == 2);                                                                      \
+        const dim3 grid(((p.N + QB - 1) / QB) * p.H * p.B);                                                                               \
+        if (CAN_PS && p.scale <= 0.f) hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD, attn_rm_qs<DD>(), CAN_PS>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((attn_self_rm_kernel<TT, DD, attn_rm_qs<DD>(), false>), grid, dim3(256), 0, st, p); } while (0)
     if (dtype == VIDI_DT_BF16) {
         if (D == 72) LAUNCH(BF16, 72); else if (D == 64) LAUNCH(BF16, 64); else if (D == 16) LAUNCH(BF16, 16);
         else if (D == 32) LAUNCH(BF16, 32); else return VIDI_ERR_SHAPE;

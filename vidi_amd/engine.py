@@ -19,6 +19,9 @@ points, and both arms are held to the goldens):
     skipped here.
   * VIDI_LN_FOLD (default on): the towers' LayerNorm weights are multiplied into the consuming projection, Wf = T(W * gamma) —
     one extra rounding per weight; the reference multiplies the T-rounded LayerNorm output by the unfused weights.
+  * VIDI_ATTN_PRESCALE (default on, SigLIP's d = 72 heads): the softmax scale (and log2 e) is multiplied into the q projection before that
+    fold's single rounding, so q is rounded at a different value than the reference's (same relative precision); the attention kernel then
+    keeps its running maximum rounded to T.  The reference scales the T-rounded scores.
   * VIDI_FOLD_REPKV (default on): the multimodal stream's o_proj(repeat_kv(V)) uses wo_kv = T(sum_g Wo block) — the G column blocks
     summed in fp32 and rounded once; the error (about one ulp per weight) feeds every later layer's K/V cache.
 """
@@ -116,6 +119,10 @@ class VidiEngine:
         # towers: q | k | v as one row-major buffer + the transpose-read attention kernel (VIDI_ATTN_RM=1) or Q|K row-major + V transposed by
         # the projection's epilogue + the Vt attention kernel (0)
         self.attn_rm = os.environ.get("VIDI_ATTN_RM", "1") != "0"
+        # SigLIP tower (d = 72): softmax scale * log2(e) folded into the q projection (weights and bias, before the LayerNorm fold: still ONE
+        # rounding per weight) and vidi_attn_self_rm called with scale = 0 — its d = 72 body then carries the running maximum inside the
+        # QK^T contraction and the exponent needs no FMA (VIDI_ATTN_PRESCALE=0: unscaled q, scale applied to the fp32 scores)
+        self.attn_prescale = os.environ.get("VIDI_ATTN_PRESCALE", "1") != "0" and self.ln_fold and self.attn_rm
         # multimodal stream: each (post-norm + residual, next pre-norm) pair as one launch (VIDI_STREAM_NORM2=0: two launches)
         self.stream_norm2 = os.environ.get("VIDI_STREAM_NORM2", "1") != "0"
         # decode step: rope + cache append + T2T as one launch (VIDI_DECODE_ATTN=0: rope_cache + attn_text), T2V + T2A partial passes as
@@ -227,7 +234,13 @@ class VidiEngine:
             for n, k in (("layer_norm1", "ln1"), ("layer_norm2", "ln2")):
                 L[k + "w"], L[k + "b"] = g(p + n + ".weight"), g(p + n + ".bias")
             if self.ln_fold:    # layer_norm1 -> q/k/v_proj and layer_norm2 -> fc1 with the LayerNorm folded in (the plain weights are dropped)
-                L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(L["wqkv"], L.pop("bqkv"), L["ln1w"], L["ln1b"])
+                Wqkv, bqkv = L["wqkv"], L.pop("bqkv")
+                self.vis_prescaled = self.attn_prescale and cfg.vis_hidden_size // cfg.vis_num_heads == 72
+                if self.vis_prescaled:
+                    qs = torch.ones((3 * Hv, 1), dtype=torch.float32, device=dev)
+                    qs[:Hv] = (cfg.vis_hidden_size // cfg.vis_num_heads) ** -0.5 * math.log2(math.e)
+                    Wqkv, bqkv = Wqkv.float() * qs, bqkv.float() * qs[:, 0]             # fp32: fold_ln rounds the product once
+                L["wqkv"], L["sqkv"], L["cqkv"] = fold_ln(Wqkv, bqkv, L["ln1w"], L["ln1b"])
                 L["fc1"], L["s1"], L["c1"] = fold_ln(L["fc1"], L.pop("b1"), L["ln2w"], L["ln2b"])
             self.vis["layers"].append(L)
 
@@ -400,7 +413,7 @@ class VidiEngine:
                 hip.row_stats(x, ws["st"], cfg.vis_ln_eps)
             for L in V["layers"]:
                 self._tower_layer(x, L, ws, cfg.vis_ln_eps, hip.ACT_GELU_TANH,
-                                  dict(B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=hd ** -0.5),
+                                  dict(B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=0.0 if getattr(self, "vis_prescaled", False) else hd ** -0.5),
                                   dict(vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh))
         return out.view(T, N, Hv)
 

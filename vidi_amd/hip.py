@@ -459,7 +459,8 @@ def attn_self(qk, vt, out, *, B, N, Npad, H, D, koff, scale):
 
 def attn_self_rm(qkv, out, *, B, N, H, D, scale, koff=None, voff=None, head_major=False):
     """encoder self-attention reading Q | K | V (V in natural order, transposed on the fly by the LDS transpose read) from one projection
-    output: row-major [B*N, ld] with column offsets koff / voff, or head-major [3][B][H][N][D] (gemm_ln_heads)"""
+    output: row-major [B*N, ld] with column offsets koff / voff, or head-major [3][B][H][N][D] (gemm_ln_heads).  scale <= 0: Q already
+    carries scale * log2(e) (include/vidi_hip.h)"""
     lib = load_library()
     if head_major:
         if not qkv.is_contiguous() or qkv.numel() < 3 * B * H * N * D:
