@@ -56,6 +56,12 @@ template <int V> struct IntC { static constexpr int value = V; };
 #ifndef VIDI_ATTN_RM_FLATDMA
 #define VIDI_ATTN_RM_FLATDMA 1         // d = 72, two query sets: the tile DMA as five branch-free instructions per wave (see issue_dma_flat)
 #endif
+#ifndef VIDI_ATTN_RM_XTILE
+#define VIDI_ATTN_RM_XTILE 1           // d = 72: the two-set pipeline carried across the tile boundary (0: per tile)
+#endif
+#ifndef VIDI_ATTN_RM_PREX
+#define VIDI_ATTN_RM_PREX 3            // matrix instructions in front of the running-max branch in the cross-tile loop (2 measured +4 % on one box and
+#endif                                 // -1.5 % on another, and leaves the fp16 build 2 registers short: 252 / 253 VGPRs at 3)
 #ifndef VIDI_ATTN_RM_VF0
 #define VIDI_ATTN_RM_VF0 2             // softmax chunk of step 1 after which the V fragments of sub-tile 0 are requested
 #endif
@@ -290,8 +296,172 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         for (int i = tid; i < CBYTES / 4; i += 256) *(unsigned*)(smem + RING + i * 4) = (i % (CROWB / 4) == 0) ? one1 : 0u;
     }
     constexpr int ROWD = D - (DT - 1) * 32;
+    // ---- pieces of the two-set pipelined tile body (d = 72; see the loops below) ----
+    const __attribute__((address_space(3))) char* lds0 = (const __attribute__((address_space(3))) char*)smem;
+    auto QKm = [&](int s, const u32x4 (&kf)[KS], int qs, f32x16& S) __attribute__((always_inline)) { S = T::mfma32(kf[s], qf[qs][s], s == 0 ? zero16 : S); };
+    auto PVm = [&](int j, const u32x4 (&vf)[DT][2], int qs, const u32x4& pf0, const u32x4& pf1) __attribute__((always_inline)) {
+        const int dt = j % DT, m = j / DT;
+        o[qs][dt] = T::mfma32(vf[dt][m], m ? pf1 : pf0, o[qs][dt]);
+    };
+    auto load_kf = [&](int u, u32x4 (&kf)[KS], const char* sK, int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[s] = *(const u32x4*)(sK + (u * 32 + l31) * ROWB + (((2 * s + hi) ^ ksw) << 4));
+        // keys past N, without a branch and without touching the scores: d = 72 leaves contraction chunk 9 (the hi lanes of the last
+        // k-step) empty; Q carries 1.0 in its first slot, K a bias: 0 for a real key, -inf for one past N — the matrix pipe adds it
+        // (x + 0 = x exactly; x - inf = -inf: what masking the score would have given)
+        constexpr unsigned NEG_INF = T::id == VIDI_DT_BF16 ? 0xff80u : 0xfc00u;      // -inf in T
+        constexpr unsigned ONE_HI = PS ? ((unsigned)(T::id == VIDI_DT_BF16 ? 0x3f80u : 0x3c00u) << 16) : 0u;      // PS: K's slot 1 = 1.0 (times Q's -max)
+        const unsigned bias = ((kb + u * 32 + l31 >= p.N) ? NEG_INF : 0u) | ONE_HI;
+        kf[KS - 1][0] = hi ? bias : kf[KS - 1][0];
+    };
+    u32x2 vraw[12];
+    auto load_vf = [&](int u, u32x4 (&vf)[DT][2], const int (&va)[DT]) __attribute__((always_inline)) {
+        static_assert(DT * 4 <= 12, "raw halves");
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int rowb = dt * 32 < MAINC ? MROWB : 16;
+                if constexpr (VIDI_ATTN_RM_TRASM != 0) {
+                    const unsigned a = (unsigned)(uintptr_t)(lds0 + va[dt]);
+                    VIDI_TR_READ(vraw[(dt * 2 + m) * 2], a, (u * 32 + 16 * m) * rowb);
+                    VIDI_TR_READ(vraw[(dt * 2 + m) * 2 + 1], a, (u * 32 + 16 * m + 8) * rowb);
+                } else {
+                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m) * rowb));
+                    const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m + 8) * rowb));
+                    const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
+                    vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                }
+            }
+    };
+    auto vf_ready = [&](u32x4 (&vf)[DT][2]) __attribute__((always_inline)) {        // before the first PV of a sub-tile
+        if constexpr (VIDI_ATTN_RM_TRASM != 0) {
+            tr_wait<DT * 4>(vraw);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const u32x2 a = vraw[(dt * 2 + m) * 2], c = vraw[(dt * 2 + m) * 2 + 1];
+                    vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
+                }
+        }
+    };
+    constexpr float TAU = 8.0f;
+    // running max of an item (+ the rare rescale): ends in a branch.  NPRE matrix instructions go in front of it.
+    auto sm_a = [&](int qs, f32x16& S, auto&& M, auto npre) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < decltype(npre)::value; ++c) M(c);
+        float mx = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+        mx = xhalf_max(mx);
+        if constexpr (PS) {
+            // S already is (score - max~) in base-2 units: Q carries the scale (host contract: scale <= 0) and -max~ in contraction slot 73
+            // (K has 1.0 there), max~ = the running maximum ROUNDED TO T (any reference works as long as every term uses the same one).
+            // nm_run = -max~ (the slot's value, 0 before the first sub-tile), thr_run = -inf before the first sub-tile, then TAU.
+            if (__builtin_expect(__any(mx > thr_run[qs]), 0)) {
+                asm volatile("" : "+v"(mx));
+                const float m_new = T::to_f32(T::from_f32(mx - nm_run[qs]));          // max~ of everything seen so far
+                const float delta = -nm_run[qs] - m_new;                               // exact: both are T values
+                const float alpha = fast_exp2(delta + fminf(thr_run[qs], 0.f));       // 0 on the first sub-tile (o = 0 there; -max~ may be huge)
+                nm_run[qs] = -m_new; thr_run[qs] = TAU;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[r] += delta;                            // this item's scores were formed with the old slot value
+                if (hi) qf[qs][KS - 1][0] = (unsigned)T::from_f32(1.0f) | ((unsigned)T::from_f32(-m_new) << 16);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
+            }
+            return;
+        }
+        float mxs = mx * sc;
+        if (__builtin_expect(__any(mxs > thr_run[qs]), 0)) {
+            asm volatile("" : "+v"(mxs));                    // (keeps the rare path's arithmetic inside the branch: LLVM speculates it above)
+            const float m_cand = fmaxf(-nm_run[qs], mxs);
+            const float alpha = fast_exp2(-nm_run[qs] - m_cand);
+            nm_run[qs] = -m_cand; thr_run[qs] = m_cand + TAU;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
+        }
+    };
+    // exponentials + packing of an item in 8 chunks of 2 probabilities; matrix instruction M(c) leads chunk c
+    auto sm_b = [&](int qs, const f32x16& S, u32x4& pf0, u32x4& pf1, auto&& M) __attribute__((always_inline)) {
+        unsigned w[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            M(c);
+            const float e0 = PS ? fast_exp2(S[2 * c]) : fast_exp2(__builtin_fmaf(S[2 * c], sc, nm_run[qs]));
+            const float e1 = PS ? fast_exp2(S[2 * c + 1]) : fast_exp2(__builtin_fmaf(S[2 * c + 1], sc, nm_run[qs]));
+            w[c] = pack2<T>(e0, e1);
+        }
+#pragma unroll
+        for (int c = 8; c < 12; ++c) M(c);           // (matrix instructions beyond the 8 chunks, if the step has more)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(w[c]));       // keep the exponentials in THIS block (they are pure: LLVM sinks them to their users)
+        pf0 = u32x4{w[0], w[1], w[2], w[3]}; pf1 = u32x4{w[4], w[5], w[6], w[7]};
+    };
     issue_dma(0, 0);
 
+    // ---- d = 72, two query sets, pipeline carried ACROSS the tile boundary --------------------------------------------------------------
+    // In the per-tile form below QK^T of (A,0) and PV of (B,1) have no softmax of their own wave beside them (11 of a tile's 44 matrix
+    // instructions).  Here QK^T of the next tile's (A,0) runs beside the softmax of (B,1) and PV of (B,1) beside the next tile's (A,0):
+    // every step is one softmax item beside 11 matrix instructions.  The rendezvous moves to the middle of the tile: by then every LDS read
+    // of tile t has returned (K(1), V(0), V(1) are in registers after step 3), so slot t & 1 can take tile t + 2 at once, and tile t + 1 —
+    // requested at the previous tile's midpoint, a whole tile ago — is waited for there.  Still a 2-slot ring, still one barrier per tile.
+    // (only the prescaled-Q form: with the scale > 0 form's two extra state registers per set this loop spills)
+    constexpr bool kXTile = (PS && QS == 2 && D == 72 && kFlatDma && VIDI_ATTN_RM_XTILE != 0);
+    if constexpr (kXTile) {
+        constexpr int P = VIDI_ATTN_RM_PREX;
+        u32x4 kf[KS], vf[DT][2], pa0, pa1, pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
+        f32x16 SA, SB;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { vf[dt][0] = u32x4{0, 0, 0, 0}; vf[dt][1] = u32x4{0, 0, 0, 0}; }     // the first "previous PV" adds 0 * 0
+        if (ntiles > 1) {
+            issue_dma(64, 1);
+            asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // tile 0 has landed (five pieces per wave and tile), tile 1 may be on its way
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        load_kf(0, kf, smem, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) QKm(s, kf, 0, SA);
+        for (int t = 0; t < ntiles; ++t) {
+            const int kb = t * 64, slot = t & 1;
+            const char* sK = smem + slot * BUF;
+            int va[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + slot * vstep[dt];
+            // step 1: softmax (A,0)  ||  PV (B,1) of tile t - 1, QK (B,0)
+            { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB); };
+              sm_a(0, SA, M, IntC<P>{});
+              sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P); if (c + P == 2 * DT - 1) load_vf(0, vf, va); if (c + P == 2 * DT + KS - 1) load_kf(1, kf, sK, kb); }); }
+            // step 2: softmax (B,0)  ||  PV (A,0), QK (A,1)
+            vf_ready(vf);
+            { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
+              sm_a(1, SB, M, IntC<P>{});
+              sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P); }); }
+            // step 3: softmax (A,1)  ||  PV (B,0), QK (B,1); V fragments of sub-tile 1 replace sub-tile 0's once its last PV has been issued
+            { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB); };
+              sm_a(0, SA, M, IntC<P>{});
+              sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P); if (c + P == 2 * DT - 1) load_vf(1, vf, va); }); }
+            // midpoint: every LDS read of tile t has returned; tile t + 1 (requested a tile ago) has landed, for everyone
+            vf_ready(vf);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + 2 < ntiles) issue_dma(kb + 128, slot);
+            load_kf(0, kf, smem + (slot ^ 1) * BUF, kb + 64);            // (past the last tile: stale bytes, the scores are never used)
+            // step 4: softmax (B,1)  ||  PV (A,1), QK (A,0) of tile t + 1
+            { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
+              sm_a(1, SB, M, IntC<P>{});
+              sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P); }); }
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) PVm(j, vf, 1, pb0, pb1);           // PV (B,1) of the last tile
+    }
+
+    if constexpr (!kXTile)
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
         wait_vmcnt<0>();                                  // my pieces of tile t have landed ...
@@ -299,7 +469,6 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         const int slot = t & 1;
         if (t + 1 < ntiles) issue_dma(kb + 64, (t + 1) & 1);
         const char* sK = smem + slot * BUF;
-        const __attribute__((address_space(3))) char* lds0 = (const __attribute__((address_space(3))) char*)smem;
         int va[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + slot * vstep[dt];
@@ -312,121 +481,16 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         // Source order = the intended issue order (a matrix instruction leads every chunk of two probabilities); the compiler's own placement inside
         // a basic block measured better than sched_group_barrier patterns (-2 %), so only two things are pinned: the exponentials stay in their
         // step's block (LLVM would sink them to their users in the next one), and the rare rescale is out of line.
-        auto QKm = [&](int s, const u32x4 (&kf)[KS], int qs, f32x16& S) __attribute__((always_inline)) { S = T::mfma32(kf[s], qf[qs][s], s == 0 ? zero16 : S); };
-        auto PVm = [&](int j, const u32x4 (&vf)[DT][2], int qs, const u32x4& pf0, const u32x4& pf1) __attribute__((always_inline)) {
-            const int dt = j % DT, m = j / DT;
-            o[qs][dt] = T::mfma32(vf[dt][m], m ? pf1 : pf0, o[qs][dt]);
-        };
-        auto load_kf = [&](int u, u32x4 (&kf)[KS]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) kf[s] = *(const u32x4*)(sK + (u * 32 + l31) * ROWB + (((2 * s + hi) ^ ksw) << 4));
-            // keys past N, without a branch and without touching the scores: d = 72 leaves contraction chunk 9 (the hi lanes of the last
-            // k-step) empty; Q carries 1.0 in its first slot, K a bias: 0 for a real key, -inf for one past N — the matrix pipe adds it
-            // (x + 0 = x exactly; x - inf = -inf: what masking the score would have given)
-            constexpr unsigned NEG_INF = T::id == VIDI_DT_BF16 ? 0xff80u : 0xfc00u;      // -inf in T
-            constexpr unsigned ONE_HI = PS ? ((unsigned)(T::id == VIDI_DT_BF16 ? 0x3f80u : 0x3c00u) << 16) : 0u;      // PS: K's slot 1 = 1.0 (times Q's -max)
-            const unsigned bias = ((kb + u * 32 + l31 >= p.N) ? NEG_INF : 0u) | ONE_HI;
-            kf[KS - 1][0] = hi ? bias : kf[KS - 1][0];
-        };
-        u32x2 vraw[12];
-        auto load_vf = [&](int u, u32x4 (&vf)[DT][2]) __attribute__((always_inline)) {
-            static_assert(DT * 4 <= 12, "raw halves");
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int rowb = dt * 32 < MAINC ? MROWB : 16;
-                    if constexpr (VIDI_ATTN_RM_TRASM != 0) {
-                        const unsigned a = (unsigned)(uintptr_t)(lds0 + va[dt]);
-                        VIDI_TR_READ(vraw[(dt * 2 + m) * 2], a, (u * 32 + 16 * m) * rowb);
-                        VIDI_TR_READ(vraw[(dt * 2 + m) * 2 + 1], a, (u * 32 + 16 * m + 8) * rowb);
-                    } else {
-                        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m) * rowb));
-                        const v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds0 + va[dt] + (u * 32 + 16 * m + 8) * rowb));
-                        const u32x2 a = __builtin_bit_cast(u32x2, lo), c = __builtin_bit_cast(u32x2, up);
-                        vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
-                    }
-                }
-        };
-        auto vf_ready = [&](u32x4 (&vf)[DT][2]) __attribute__((always_inline)) {        // before the first PV of a sub-tile
-            if constexpr (VIDI_ATTN_RM_TRASM != 0) {
-                tr_wait<DT * 4>(vraw);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const u32x2 a = vraw[(dt * 2 + m) * 2], c = vraw[(dt * 2 + m) * 2 + 1];
-                        vf[dt][m] = u32x4{a[0], a[1], c[0], c[1]};
-                    }
-            }
-        };
-        constexpr float TAU = 8.0f;
-        // running max of an item (+ the rare rescale): ends in a branch.  NPRE matrix instructions go in front of it.
-        auto sm_a = [&](int qs, f32x16& S, auto&& M, auto npre) __attribute__((always_inline)) {
-#pragma unroll
-            for (int c = 0; c < decltype(npre)::value; ++c) M(c);
-            float mx = S[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
-            mx = xhalf_max(mx);
-            if constexpr (PS) {
-                // S already is (score - max~) in base-2 units: Q carries the scale (host contract: scale <= 0) and -max~ in contraction slot 73
-                // (K has 1.0 there), max~ = the running maximum ROUNDED TO T (any reference works as long as every term uses the same one).
-                // nm_run = -max~ (the slot's value, 0 before the first sub-tile), thr_run = -inf before the first sub-tile, then TAU.
-                if (__builtin_expect(__any(mx > thr_run[qs]), 0)) {
-                    asm volatile("" : "+v"(mx));
-                    const float m_new = T::to_f32(T::from_f32(mx - nm_run[qs]));          // max~ of everything seen so far
-                    const float delta = -nm_run[qs] - m_new;                               // exact: both are T values
-                    const float alpha = fast_exp2(delta + fminf(thr_run[qs], 0.f));       // 0 on the first sub-tile (o = 0 there; -max~ may be huge)
-                    nm_run[qs] = -m_new; thr_run[qs] = TAU;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[r] += delta;                            // this item's scores were formed with the old slot value
-                    if (hi) qf[qs][KS - 1][0] = (unsigned)T::from_f32(1.0f) | ((unsigned)T::from_f32(-m_new) << 16);
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
-                }
-                return;
-            }
-            float mxs = mx * sc;
-            if (__builtin_expect(__any(mxs > thr_run[qs]), 0)) {
-                asm volatile("" : "+v"(mxs));                    // (keeps the rare path's arithmetic inside the branch: LLVM speculates it above)
-                const float m_cand = fmaxf(-nm_run[qs], mxs);
-                const float alpha = fast_exp2(-nm_run[qs] - m_cand);
-                nm_run[qs] = -m_cand; thr_run[qs] = m_cand + TAU;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[qs][dt][i] *= alpha;
-            }
-        };
-        // exponentials + packing of an item in 8 chunks of 2 probabilities; matrix instruction M(c) leads chunk c
-        auto sm_b = [&](int qs, const f32x16& S, u32x4& pf0, u32x4& pf1, auto&& M) __attribute__((always_inline)) {
-            unsigned w[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                M(c);
-                const float e0 = PS ? fast_exp2(S[2 * c]) : fast_exp2(__builtin_fmaf(S[2 * c], sc, nm_run[qs]));
-                const float e1 = PS ? fast_exp2(S[2 * c + 1]) : fast_exp2(__builtin_fmaf(S[2 * c + 1], sc, nm_run[qs]));
-                w[c] = pack2<T>(e0, e1);
-            }
-#pragma unroll
-            for (int c = 8; c < 12; ++c) M(c);           // (matrix instructions beyond the 8 chunks, if the step has more)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(w[c]));       // keep the exponentials in THIS block (they are pure: LLVM sinks them to their users)
-            pf0 = u32x4{w[0], w[1], w[2], w[3]}; pf1 = u32x4{w[4], w[5], w[6], w[7]};
-        };
         constexpr int P1 = VIDI_ATTN_RM_PRE1, P2 = VIDI_ATTN_RM_PRE2;
         u32x4 kf[KS], vf[DT][2], pa0, pa1, pb0, pb1;
         f32x16 SA, SB;
-        load_kf(0, kf);
+        load_kf(0, kf, sK, kb);
 #pragma unroll
         for (int s = 0; s < KS; ++s) QKm(s, kf, 0, SA);
         // step 1: softmax (A,0)  ||  QK (B,0)  [KS]
         { auto M = [&](int i) __attribute__((always_inline)) { if (i < KS) QKm(i, kf, 1, SB); };
           sm_a(0, SA, M, IntC<P1>{});
-          sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P1); if (c + P1 == KS - 1) load_kf(1, kf); if (c == VIDI_ATTN_RM_VF0) load_vf(0, vf); }); }
+          sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P1); if (c + P1 == KS - 1) load_kf(1, kf, sK, kb); if (c == VIDI_ATTN_RM_VF0) load_vf(0, vf, va); }); }
         // step 2: softmax (B,0)  ||  PV (A,0) [2 DT], QK (A,1) [KS]
         vf_ready(vf);
         { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
@@ -435,7 +499,7 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         // step 3: softmax (A,1)  ||  PV (B,0), QK (B,1); V fragments of sub-tile 1 replace sub-tile 0's once its last PV has been issued
         { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB); };
           sm_a(0, SA, M, IntC<P2>{});
-          sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P2); if (c + P2 == 2 * DT - 1) load_vf(1, vf); }); }
+          sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P2); if (c + P2 == 2 * DT - 1) load_vf(1, vf, va); }); }
         // step 4: softmax (B,1)  ||  PV (A,1)
         vf_ready(vf);
         { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); };
