@@ -128,3 +128,53 @@ def test_conv_window_gather_addresses():
             out[m] = wg @ row
         ref = F.conv2d(f.reshape(T, side, side, C).permute(0, 3, 1, 2), w).permute(0, 2, 3, 1).reshape(T * n, N)
         assert torch.allclose(out, ref, atol=5e-3, rtol=1e-4)
+
+
+def test_attention_d72_tile_dma_piece_map():
+    """The d = 72 encoder-attention kernel's branch-free tile DMA (attn_self_rm.hip, issue_dma_flat), emulated on the host: every wave
+    issues exactly five 1-KB pieces (64 lanes x 16 bytes, lane-linear in LDS); together they must fill the K image [64 keys][9 chunks],
+    the V main block [64 keys][8 chunks, chunk c of key r at slot c ^ 2 (r & 3)] and the V tail block [64 keys][1 chunk] — every byte
+    written, pieces that overlap (K piece 8 by waves 0 and 1, the tail by waves 2 and 3) writing the same source bytes."""
+    D, NCH, MCH, MAINC = 72, 9, 8, 64
+    KBYTES, VMAIN = 64 * NCH * 16, 64 * MCH * 16
+    BUF = KBYTES + VMAIN + 1024
+    lds = {}                                                         # LDS byte offset of a 16-byte chunk -> ("K" | "V", key row, first d)
+
+    def put(dst, lane, src):
+        off = dst + lane * 16
+        assert lds.setdefault(off, src) == src, (off, lds[off], src)
+
+    vswz = lambda r: 2 * (r & 3)                                     # noqa: E731
+    for wave in range(4):
+        issued = 0
+        for lane in range(64):
+            tid = wave * 64 + lane
+            for j in range(2):                                       # K pieces wave and 4 + wave
+                i = j * 256 + tid
+                put((j * 4 + wave) * 1024, lane, ("K", i // NCH, (i % NCH) * 8))
+            if wave < 2:                                             # slot 2: K piece 8 (chunks 512 .. 575) ...
+                i = 512 + lane
+                put(8 * 1024, lane, ("K", i // NCH, (i % NCH) * 8))
+            else:                                                    # ... or the V tail block: key = lane, d 64 .. 71
+                put(KBYTES + VMAIN, lane, ("V", lane, MAINC))
+            for j in range(2):                                       # V main pieces wave and 4 + wave: 8 keys per piece
+                pc = j * 4 + wave
+                row = pc * (64 // MCH) + lane // MCH
+                put(KBYTES + pc * 1024, lane, ("V", row, ((lane % MCH) ^ vswz(row)) * 8))
+            issued = 5
+        assert issued == 5
+    assert sorted(lds) == list(range(0, BUF, 16))                    # every chunk of the slot, nothing outside it
+    for r in range(64):
+        for c in range(NCH):                                         # K image: rows unpadded, no swizzle at 9 chunks per row
+            assert lds[(r * NCH + c) * 16] == ("K", r, c * 8)
+        for c in range(MCH):                                         # V main block: chunk c of key r sits at slot c ^ 2 (r & 3)
+            assert lds[KBYTES + (r * MCH + (c ^ vswz(r))) * 16] == ("V", r, c * 8)
+        assert lds[KBYTES + VMAIN + r * 16] == ("V", r, MAINC)
+    # the contraction slots the kernel borrows: d = 72 occupies 72 of the 5 x 16 slots of the QK^T k-steps; slot 72 carries (1.0 in Q) x
+    # (0 | -inf in K) for keys past N, slot 73 (-max~ in Q) x (1.0 in K): the matrix pipe returns  q.k + bias - max~
+    q = torch.randn(D, dtype=torch.float64); k = torch.randn(D, dtype=torch.float64)
+    for bias, mt in ((0.0, 3.25), (float("-inf"), -1.5)):
+        qx = torch.cat([q, torch.tensor([1.0, -mt]), torch.zeros(6, dtype=torch.float64)])
+        kx = torch.cat([k, torch.tensor([bias, 1.0]), torch.zeros(6, dtype=torch.float64)])
+        got = float((qx * kx).sum())
+        assert got == float("-inf") if bias else abs(got - (float(q @ k) - mt)) < 1e-12
