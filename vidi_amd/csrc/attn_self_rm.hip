@@ -14,6 +14,12 @@
 // fragment, so memory holds V in natural order.  The softmax denominator's ones row (d = D when D % 32 != 0) is patched into the
 // fragment registers of the lanes that own output row D.
 //
+// Round 3: (1) the transpose reads are inline asm (VIDI_ATTN_RM_TRASM: the builtin drew a wait for the next tile's LDS-DMA in front of them);
+// (2) the d = 72 instantiation runs two 32-query sets per wave in a hand-pipelined tile body (VIDI_ATTN_RM_QS72), its tile DMA is five
+// branch-free instructions per wave, keys past N are masked by a bias in a spare contraction slot; (3) template flag PS: the caller folded
+// scale * log2(e) into Q (scale <= 0 at the C ABI) — the running maximum then rides in the contraction too, the exponent needs no FMA, and
+// the pipeline is carried across the tile boundary with the rendezvous at the tile's midpoint.  profiles/r3_notes.md has the measurements.
+//
 // Algorithmic FLOPs = 4*N*N*D per (batch, head).
 #include "kernels.h"
 #include <stdlib.h>
