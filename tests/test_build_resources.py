@@ -72,8 +72,8 @@ def test_hot_kernels_do_not_spill(report):
 
 
 def test_encoder_attention_occupancy():
-    """the d = 72 instantiation runs two query sets per wave in <= 256 registers (two waves per SIMD); every other head dim one set in
-    <= 168 (three waves per SIMD) — a register more on either side halves / cuts the resident waves with no functional symptom"""
+    """the d = 72 and d = 64 instantiations run two query sets per wave in <= 256 registers (two waves per SIMD); the other head dims one
+    set in <= 168 (three waves per SIMD) — a register more on either side halves / cuts the resident waves with no functional symptom"""
     path = os.path.join(BUILD, "attn_self_rm.resources.txt")
     if not os.path.exists(path):
         pytest.skip("no resource report")
@@ -83,7 +83,7 @@ def test_encoder_attention_occupancy():
         if not m:
             continue
         d, qs = int(m.group(1)), int(m.group(2))
-        assert qs == (2 if d == 72 else 1), name
+        assert qs == (2 if d in (72, 64) else 1), name
         assert res["Occupancy"] >= (2 if qs == 2 else 3), (name, res)
         assert res["LDS Size"] <= 65536, (name, res)
         seen += 1

@@ -41,7 +41,11 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
                                        // waves per SIMD.  Left to the compiler the two chains ran back to back (399 vs 636 useful TFLOP/s in
                                        // round 2); pipelined: 714 -> 747 on the SigLIP shape, bit-identical (profiles/r3_ab_attn_pipe.jsonl).
                                        // Every other head dim keeps one set per wave (three waves per SIMD).
-template <int D> constexpr int attn_rm_qs() { return D == 72 ? VIDI_ATTN_RM_QS72 : 1; }
+#ifndef VIDI_ATTN_RM_QS64
+#define VIDI_ATTN_RM_QS64 2            // the same two-set body for d = 64 (Whisper): no spare contraction chunk and no ones row there, so keys past N
+#endif                                 // are masked through the first QK^T instruction's C input (zeros except in the last tile) and the row sums stay
+                                       // on the VALU; ~190 VGPRs, two waves per SIMD
+template <int D> constexpr int attn_rm_qs() { return D == 72 ? VIDI_ATTN_RM_QS72 : (D == 64 ? VIDI_ATTN_RM_QS64 : 1); }
 
 #ifndef VIDI_ATTN_RM_TRASM
 #define VIDI_ATTN_RM_TRASM 1           // 1: the V transpose reads are inline asm.  Through the builtin the compiler cannot tell that the LDS-DMA
@@ -218,23 +222,24 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
     // wave-dependent choices (which piece, its LDS address, which descriptor) are made once, here.  Slot 2 of waves 0-1 is K piece 8, of
     // waves 2-3 the V tail: both are fetched twice (same bytes to the same LDS address), which costs 2 KB of L2 reads per tile and saves
     // ~25 scalar instructions and 10 branches per tile and wave (the loop is instruction-issue-bound).
-    constexpr bool kFlatDma = (QS == 2 && D == 72 && VIDI_ATTN_RM_SRD != 0 && VIDI_ATTN_RM_FLATDMA != 0);
+    constexpr bool kFlatDma = (QS == 2 && (D == 72 || D == 64) && VIDI_ATTN_RM_SRD != 0 && VIDI_ATTN_RM_FLATDMA != 0);   // (d = 64: 8 K + 8 V pieces, four per wave)
     unsigned fvo2 = 0;
     int fdst2 = 0;
     __amdgpu_buffer_rsrc_t srdM = srdK;
-    if constexpr (kFlatDma) {
-        static_assert(!kFlatDma || (KRND == 3 && VRND == 2 && MCH == 8 && TAILC == 8), "piece map of d = 72");
+    if constexpr (kFlatDma && D == 72) {
+        static_assert(!(kFlatDma && D == 72) || (KRND == 3 && VRND == 2 && MCH == 8 && TAILC == 8), "piece map of d = 72");
         const int i2 = 512 + lane;                                   // K piece 8: chunks 512 .. 575 (no swizzle at 9 chunks per row)
         fvo2 = wave < 2 ? (unsigned)((i2 / NCH) * p.ld + (i2 % NCH) * 8) * 2u : (unsigned)(lane * p.ld + MAINC) * 2u;
         fdst2 = wave < 2 ? 8 * 1024 : KBYTES + VMAIN;
         srdM = wave < 2 ? srdK : srdV;
     }
     auto issue_dma_flat = [&](int kb, auto bufi) {
+        static_assert(!kFlatDma || D == 72 || (KRND == 2 && VRND == 2 && MCH == 8 && TAILC == 0), "piece map of d = 64");
         char* sK = smem + bufi * BUF;
         const unsigned so = (unsigned)kb * (unsigned)p.ld * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdK, (__attribute__((address_space(3))) void*)(sK + wave * 1024), 16, (unsigned)(krow[0] * p.ld + kcol[0]) * 2u, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdK, (__attribute__((address_space(3))) void*)(sK + 4096 + wave * 1024), 16, (unsigned)(krow[1] * p.ld + kcol[1]) * 2u, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdM, (__attribute__((address_space(3))) void*)(sK + fdst2), 16, (int)fvo2, so, 0, 0);
+        if constexpr (D == 72) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdM, (__attribute__((address_space(3))) void*)(sK + fdst2), 16, (int)fvo2, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sK + KBYTES + wave * 1024), 16, (unsigned)(vrow[0] * p.ld + vcol[0]) * 2u, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (__attribute__((address_space(3))) void*)(sK + KBYTES + 4096 + wave * 1024), 16, (unsigned)(vrow[1] * p.ld + vcol[1]) * 2u, so, 0, 0);
     };
@@ -304,7 +309,15 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
     constexpr int ROWD = D - (DT - 1) * 32;
     // ---- pieces of the two-set pipelined tile body (d = 72; see the loops below) ----
     const __attribute__((address_space(3))) char* lds0 = (const __attribute__((address_space(3))) char*)smem;
-    auto QKm = [&](int s, const u32x4 (&kf)[KS], int qs, f32x16& S) __attribute__((always_inline)) { S = T::mfma32(kf[s], qf[qs][s], s == 0 ? zero16 : S); };
+    // d = 64 has no spare contraction chunk for the tail bias: there the first QK^T instruction of a sub-tile starts from cin[u] — zeros,
+    // except in the last tile, where the rows of keys past N hold -inf (set once at the top of that tile)
+    constexpr bool kBiasSlot = (D == 72), kCinMask = (QS == 2 && D == 64);
+    f32x16 cin[kCinMask ? 2 : 1];
+    if constexpr (kCinMask) { cin[0] = zero16; cin[1] = zero16; }
+    auto QKm = [&](int s, const u32x4 (&kf)[KS], int qs, f32x16& S, int u = 0) __attribute__((always_inline)) {
+        if constexpr (kCinMask) S = T::mfma32(kf[s], qf[qs][s], s == 0 ? cin[u] : S);
+        else S = T::mfma32(kf[s], qf[qs][s], s == 0 ? zero16 : S);
+    };
     auto PVm = [&](int j, const u32x4 (&vf)[DT][2], int qs, const u32x4& pf0, const u32x4& pf1) __attribute__((always_inline)) {
         const int dt = j % DT, m = j / DT;
         o[qs][dt] = T::mfma32(vf[dt][m], m ? pf1 : pf0, o[qs][dt]);
@@ -315,6 +328,7 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         // keys past N, without a branch and without touching the scores: d = 72 leaves contraction chunk 9 (the hi lanes of the last
         // k-step) empty; Q carries 1.0 in its first slot, K a bias: 0 for a real key, -inf for one past N — the matrix pipe adds it
         // (x + 0 = x exactly; x - inf = -inf: what masking the score would have given)
+        if constexpr (!kBiasSlot) return;
         constexpr unsigned NEG_INF = T::id == VIDI_DT_BF16 ? 0xff80u : 0xfc00u;      // -inf in T
         constexpr unsigned ONE_HI = PS ? ((unsigned)(T::id == VIDI_DT_BF16 ? 0x3f80u : 0x3c00u) << 16) : 0u;      // PS: K's slot 1 = 1.0 (times Q's -max)
         const unsigned bias = ((kb + u * 32 + l31 >= p.N) ? NEG_INF : 0u) | ONE_HI;
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
             const float m_cand = fmaxf(-nm_run[qs], mxs);
             const float alpha = fast_exp2(-nm_run[qs] - m_cand);
             nm_run[qs] = -m_cand; thr_run[qs] = m_cand + TAU;
+            if constexpr (!kOnesRow) l_run[qs] *= alpha;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -396,13 +411,16 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
     // exponentials + packing of an item in 8 chunks of 2 probabilities; matrix instruction M(c) leads chunk c
     auto sm_b = [&](int qs, const f32x16& S, u32x4& pf0, u32x4& pf1, auto&& M) __attribute__((always_inline)) {
         unsigned w[8];
+        float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             M(c);
             const float e0 = PS ? fast_exp2(S[2 * c]) : fast_exp2(__builtin_fmaf(S[2 * c], sc, nm_run[qs]));
             const float e1 = PS ? fast_exp2(S[2 * c + 1]) : fast_exp2(__builtin_fmaf(S[2 * c + 1], sc, nm_run[qs]));
             w[c] = pack2<T>(e0, e1);
+            if constexpr (!kOnesRow) { ps0 += e0; ps1 += e1; }       // (no ones row at d = 64: the row sums stay on the VALU, as in the one-set body)
         }
+        if constexpr (!kOnesRow) l_run[qs] += ps0 + ps1;
 #pragma unroll
         for (int c = 8; c < 12; ++c) M(c);           // (matrix instructions beyond the 8 chunks, if the step has more)
 #pragma unroll
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + slot * vstep[dt];
         const bool tail = (kb + 64 > p.N);
 
-      if constexpr (QS == 2 && D == 72) {
+      if constexpr (QS == 2 && (D == 72 || D == 64)) {
         // ---- two query sets, software-pipelined by hand: the matrix work of one set is issued between the softmax VALU of the other ----
         // items (set, 32-key sub-tile) in the order (A,0) (B,0) (A,1) (B,1); step i runs the softmax of item i on the VALU while the
         // matrix pipe takes QK^T of item i+1 and PV of item i-1.  K fragments of a sub-tile are read ONCE for both sets, so are V's.
@@ -490,20 +508,28 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         constexpr int P1 = VIDI_ATTN_RM_PRE1, P2 = VIDI_ATTN_RM_PRE2;
         u32x4 kf[KS], vf[DT][2], pa0, pa1, pb0, pb1;
         f32x16 SA, SB;
+        if constexpr (kCinMask) {
+            if (tail) {                                  // the last tile: -inf under the keys past N (the matrix pipe adds the scores to it)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cin[u][r] = (kb + u * 32 + krow32(r, hi) >= p.N) ? -INFINITY : 0.f;
+            }
+        }
         load_kf(0, kf, sK, kb);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) QKm(s, kf, 0, SA);
+        for (int s = 0; s < KS; ++s) QKm(s, kf, 0, SA, 0);
         // step 1: softmax (A,0)  ||  QK (B,0)  [KS]
-        { auto M = [&](int i) __attribute__((always_inline)) { if (i < KS) QKm(i, kf, 1, SB); };
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < KS) QKm(i, kf, 1, SB, 0); };
           sm_a(0, SA, M, IntC<P1>{});
           sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P1); if (c + P1 == KS - 1) load_kf(1, kf, sK, kb); if (c == VIDI_ATTN_RM_VF0) load_vf(0, vf, va); }); }
         // step 2: softmax (B,0)  ||  PV (A,0) [2 DT], QK (A,1) [KS]
         vf_ready(vf);
-        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA, 1); };
           sm_a(1, SB, M, IntC<P2>{});
           sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P2); }); }
         // step 3: softmax (A,1)  ||  PV (B,0), QK (B,1); V fragments of sub-tile 1 replace sub-tile 0's once its last PV has been issued
-        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB); };
+        { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB, 1); };
           sm_a(0, SA, M, IntC<P2>{});
           sm_b(0, SA, pa0, pa1, [&](int c) __attribute__((always_inline)) { M(c + P2); if (c + P2 == 2 * DT - 1) load_vf(1, vf, va); }); }
         // step 4: softmax (B,1)  ||  PV (A,1)
