@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
     const float sc = p.scale > 0.f ? p.scale * 1.4426950408889634f : 1.0f;      // fold log2(e): softmax in base 2 (scale <= 0: Q carries it)
 
     const int ntiles = (p.N + 63) / 64;
+    const bool half_last = (((p.N - 1) & 63) < 32);      // the last tile's second 32 keys are all past N
     const int ksw = kswz(l31);
     if constexpr (kOnesRow) {                            // constant rows: {1, 0, 0, 0 | 0 ...}
         const unsigned one1 = (unsigned)T::from_f32(1.0f);
@@ -452,7 +453,9 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
         load_kf(0, kf, smem, 0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) QKm(s, kf, 0, SA);
-        for (int t = 0; t < ntiles; ++t) {
+        // (the two halves of a tile as lambdas: the LAST tile is peeled off the loop so that its second half can be skipped when its 32 keys are
+        // all past N — N = 729: keys 736 .. 767 — without a second exit from the loop, which cost hundreds of spilled registers)
+        auto first_half = [&](int t) __attribute__((always_inline)) {
             const int kb = t * 64, slot = t & 1;
             const char* sK = smem + slot * BUF;
             int va[DT];
@@ -467,6 +470,12 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
             { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
               sm_a(1, SB, M, IntC<P>{});
               sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P); }); }
+        };
+        auto second_half = [&](int t) __attribute__((always_inline)) {
+            const int kb = t * 64, slot = t & 1;
+            int va[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) va[dt] = vaddr[dt] + slot * vstep[dt];
             // step 3: softmax (A,1)  ||  PV (B,0), QK (B,1); V fragments of sub-tile 1 replace sub-tile 0's once its last PV has been issued
             { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 1, pb0, pb1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 1, SB); };
               sm_a(0, SA, M, IntC<P>{});
@@ -480,7 +489,10 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
             { auto M = [&](int i) __attribute__((always_inline)) { if (i < 2 * DT) PVm(i, vf, 0, pa0, pa1); else if (i < 2 * DT + KS) QKm(i - 2 * DT, kf, 0, SA); };
               sm_a(1, SB, M, IntC<P>{});
               sm_b(1, SB, pb0, pb1, [&](int c) __attribute__((always_inline)) { M(c + P); }); }
-        }
+        };
+        for (int t = 0; t + 1 < ntiles; ++t) { first_half(t); second_half(t); }
+        first_half(ntiles - 1);
+        if (!half_last) second_half(ntiles - 1);         // else: vf / pb still hold V(0) / P(B,0): the PV below consumes exactly those
 #pragma unroll
         for (int j = 0; j < 2 * DT; ++j) PVm(j, vf, 1, pb0, pb1);           // PV (B,1) of the last tile
     }
