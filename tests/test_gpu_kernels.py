@@ -403,13 +403,15 @@ def test_attn_self_rm(hip, dt, D, N, H, B):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("D,N,H,B", [(72, 729, 3, 2), (72, 729, 16, 9), (72, 64, 2, 8), (72, 50, 2, 3), (72, 300, 4, 2), (64, 1500, 2, 1), (16, 49, 4, 3)])
+@pytest.mark.parametrize("D,N,H,B", [(72, 729, 3, 2), (72, 729, 16, 9), (72, 64, 2, 8), (72, 50, 2, 3), (72, 300, 4, 2), (72, 96, 2, 3), (72, 20, 2, 3),
+                                     (64, 1500, 2, 1), (16, 49, 4, 3)])
 def test_attn_self_rm_prescaled_q(hip, dt, D, N, H, B):
     """scale <= 0: Q already carries scale * log2(e) (the towers fold it into the q projection's weights).  d = 72 then takes the running
     maximum inside the QK^T contraction (the kernel's spare contraction chunk) and the exponent needs no FMA; every other head dim runs
     the ordinary body with a unit scale.  Checked against the oracle on the SAME rounded Q (softmax of q'.k * ln 2), with planted score
     outliers late in the key range so that the running maximum moves by more than the lazy-rescale threshold after the first tile, and
-    with large negative scores everywhere (the first sub-tile must establish the maximum, not assume 0)."""
+    with large negative scores everywhere (the first sub-tile must establish the maximum, not assume 0).  N = 729, 96 and 20 end in a
+    tile whose second 32 keys are all past N (skipped by the d = 72 loop: twelve, two and one tile); 300, 64 and 50 do not."""
     import math
     Hd = H * D
     q = seeded((B, N, H, D), 40, dtype=dt); k = seeded((B, N, H, D), 41, dtype=dt); v = seeded((B, N, H, D), 42, 1.0, dtype=dt) + 0.25
