@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VIDI_ABI_VERSION 1
+#define VIDI_ABI_VERSION 2 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state) */
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
 #define VIDI_DT_F32 2 /* output type of the preprocessing kernels only */
@@ -283,8 +283,11 @@ int vidi_add3(const void* a, const void* b, const void* c, void* y, long long n,
 int vidi_embed(const long long* ids, const void* E, void* out, int n, int H, long long vocab, float normalizer, int dtype, void* stream);
 /* GeGLU on the interleaved gate/up layout for the vidi_gemv path */
 int vidi_geglu_unpack(const void* Yp, void* out, int M, int I, int dtype, void* stream);
-/* final-logit softcap in place + greedy argmax (gemma.py:565-569, do_sample=False) */
-int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream);
+/* final-logit softcap in place + greedy argmax (gemma.py:565-569, do_sample=False).  workspace: vidi_softcap_argmax_workspace_bytes(B)
+ * bytes (8-byte aligned), zeroed ONCE by the caller; every call leaves it zeroed.  Calls on different streams need different workspaces
+ * (the library keeps no device state: SURVEY 8b "stateless, re-entrant ... workspace passed in explicitly"). */
+size_t vidi_softcap_argmax_workspace_bytes(int B);
+int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* workspace, void* stream);
 /* mel:[C,nmel,L] -> [C,L+2,nmel] zero-padded rows for the conv1-as-GEMM view (TP whisper:566,618) */
 int vidi_mel_transpose_pad(const void* mel, void* out, int C, int nmel, int L, int dtype, void* stream);
 /* y = T(x*s): `embeds * normalizer` for externally supplied embeddings (gemma.py:353-356); n % 8 == 0 */

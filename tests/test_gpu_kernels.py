@@ -436,6 +436,31 @@ def test_attn_self_rm_prescaled_q(hip, dt, D, N, H, B):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,early_key,late_key", [(729, 3, 722), (729, 40, 300), (300, 3, 250)])
+def test_attn_self_rm_prescaled_q_early_outlier_then_drop(hip, dt, N, early_key, late_key):
+    """The d = 72 prescaled-Q body enters its rescale branch WAVE-WIDE when any query of a 32-query set sees a score above its lazy
+    threshold.  Query 9 gets one early key ≈ +150 base-2 units above everything after it; query 5 of the SAME set gets a late key that
+    triggers the branch while query 9's own sub-tile maximum sits ≈150 below its running maximum: the lane that did not trigger must keep
+    its maximum (alpha <= 1) — with the maximum allowed to move down, alpha = 2^150 turns query 9's accumulator into inf / NaN."""
+    import math
+    D, H, B = 72, 2, 2
+    q = seeded((B, N, H, D), 50, dtype=dt); k = seeded((B, N, H, D), 51, dtype=dt); v = seeded((B, N, H, D), 52, 1.0, dtype=dt) + 0.25
+    sc2 = D ** -0.5 * math.log2(math.e)
+    q9 = q[:, 9].float()
+    k[:, early_key] = (q9 * (150.0 / (sc2 * q9.pow(2).sum(-1, keepdim=True)))).to(dt)        # score(query 9, early key) ≈ +150 in base-2 units
+    k[:, late_key] = (q[:, 5].float() * 6.0).to(dt)                                            # query 5: a late maximum far above its threshold
+    qs = (q.float() * sc2).to(dt)
+    ref = O.sdpa_reference(qs.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2), math.log(2.0))
+    ref = ref.transpose(1, 2).reshape(B * N, H * D)
+    s9 = (qs[:, 9].float() * k[:, early_key].float()).sum(-1)
+    assert float(s9.min()) > 120.0, "the planted outlier is not large enough to exercise the case"
+    hm = torch.stack([qs.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)]).contiguous()
+    out = torch.zeros((B * N, H * D), dtype=dt).cuda()
+    hip.attn_self_rm(dev(hm), out, B=B, N=N, H=H, D=D, scale=0.0, head_major=True)
+    report(f"attn_self_rm prescaled early outlier N{N} keys {early_key}/{late_key}", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("seq,frames,heads,hd,K,cfg", [(729, 18, 16, 72, 1152, -1), (49, 3, 4, 16, 192, -1), (49, 3, 4, 16, 192, 0), (1500, 9, 20, 64, 1280, 5)])
 def test_gemm_ln_heads_is_gemm_ln_rearranged(hip, dt, seq, frames, heads, hd, K, cfg):
     """the head-major q/k/v projection equals the row-major one with its columns / rows regrouped: Y[which][frame][head][token][d]"""
@@ -909,6 +934,38 @@ def test_softcap_argmax_multi_block(hip, dt, B, V, pad):
         want = torch.tensor([min((7 * b + 3) % V, V // 2, (V - 1 - b) % V) for b in range(B)])
         assert torch.equal(idx.cpu(), want), (idx.cpu(), want)
         assert torch.equal(idx.cpu(), torch.argmax(ld.float().cpu(), dim=-1))
+
+
+def test_softcap_argmax_two_streams_are_independent(hip):
+    """stateless, re-entrant, workspace passed in explicitly.  Two streams run vidi_softcap_argmax concurrently on different
+    logits with their own caller-owned workspaces (many rows x many blocks per row, 20 rounds without any host synchronisation between
+    the streams); every index must be the row's first maximum, both workspaces must be left zeroed, and a call without a zeroed
+    workspace must be rejected by the binding rather than guessed at."""
+    dt = torch.bfloat16
+    B, V = 48, 256000
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    wss = [hip.softcap_argmax_workspace(B, "cuda") for _ in streams]
+    lgs, idxs, wants = [], [], []
+    for s in range(2):
+        lg = seeded((B, V), 300 + s, 20.0, dtype=dt)
+        big = lg.float().abs().max().item() * 2 + 1.0
+        want = torch.tensor([(9973 * (b + 1) * (s + 1)) % V for b in range(B)])
+        for b in range(B):
+            lg[b, want[b]] = big
+            lg[b, min(V - 1, int(want[b]) + 4097)] = big              # the same value later in another block's slice: the first one wins
+        lgs.append(lg.cuda()); wants.append(want)
+        idxs.append(torch.full((20, B), -1, dtype=torch.int64, device="cuda"))
+    torch.cuda.synchronize()
+    for rep in range(20):
+        for s, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                hip.softcap_argmax(lgs[s], idxs[s][rep], 0.0, wss[s])        # cap = 0: logits untouched, so every round sees the same data
+    torch.cuda.synchronize()
+    for s in range(2):
+        assert torch.equal(idxs[s].cpu(), wants[s][None].expand(20, B)), f"stream {s}"
+        assert int(wss[s].abs().sum()) == 0, "the workspace must be left zeroed"
+    with pytest.raises(Exception):
+        hip.softcap_argmax(lgs[0], idxs[0][0], 0.0, torch.zeros(1, dtype=torch.int64, device="cuda"))    # too small for 48 rows
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -382,9 +382,14 @@ __global__ __launch_bounds__(256, QS) void attn_self_rm_kernel(AttnSelfRmParams 
             // nm_run = -max~ (the slot's value, 0 before the first sub-tile), thr_run = -inf before the first sub-tile, then TAU.
             if (__builtin_expect(__any(mx > thr_run[qs]), 0)) {
                 asm volatile("" : "+v"(mx));
-                const float m_new = T::to_f32(T::from_f32(mx - nm_run[qs]));          // max~ of everything seen so far
+                // The branch is taken wave-wide when ANY query triggers; a lane that did not (mx far below 0) must keep its maximum:
+                // mx is clamped at 0 (= the old max~ in these units) except on the first sub-tile (floor -inf: nothing seen yet), so
+                // max~ never moves down, delta <= 0 and alpha <= 1 for every lane (an early outlier followed by a much lower sub-tile
+                // would otherwise give alpha = 2^(+large) -> inf)
+                const float floor0 = fminf(thr_run[qs], 0.f);                          // -inf on the first sub-tile, else 0
+                const float m_new = T::to_f32(T::from_f32(fmaxf(mx, floor0) - nm_run[qs]));   // max~ of everything seen so far
                 const float delta = -nm_run[qs] - m_new;                               // exact: both are T values
-                const float alpha = fast_exp2(delta + fminf(thr_run[qs], 0.f));       // 0 on the first sub-tile (o = 0 there; -max~ may be huge)
+                const float alpha = fast_exp2(delta + floor0);                         // 0 on the first sub-tile (o = 0 there; -max~ may be huge)
                 nm_run[qs] = -m_new; thr_run[qs] = TAU;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[r] += delta;                            // this item's scores were formed with the old slot value

@@ -493,10 +493,13 @@ int vidi_resize_bilinear_ac(const void* x, void* out, int T, int s_in, int s_out
     return vidi_ew_dispatch(EW_RESIZE_AC, a, i, nullptr, dtype, (hipStream_t)stream);
 }
 
-int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* stream) {
+size_t vidi_softcap_argmax_workspace_bytes(int B) { return B > 0 ? (size_t)16 * (size_t)B : 0; }
+
+int vidi_softcap_argmax(void* logits, long long* idx, int B, int V, long long ld, float cap, int dtype, void* workspace, void* stream) {
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
-    if (!logits || !idx || B <= 0 || V <= 0) return VIDI_ERR_ARG;
-    void* a[2] = {logits, (void*)idx};
+    if (!logits || !idx || !workspace || B <= 0 || V <= 0) return VIDI_ERR_ARG;
+    if ((uintptr_t)workspace & 7) return VIDI_ERR_ALIGN;
+    void* a[3] = {logits, (void*)idx, workspace};
     const long long i[3] = {B, V, ld};
     const float f[1] = {cap};
     return vidi_ew_dispatch(EW_SOFTCAP_ARGMAX, a, i, f, dtype, (hipStream_t)stream);

@@ -212,18 +212,17 @@ __global__ void geglu_unpack_kernel(const u16* __restrict__ Yp, u16* __restrict_
 //   One block per row walked the 256 000 logits in 123 us per decode step (round 2 trace); now a row is spread over up to 128 blocks:
 //   each reduces its slice to (value, first index), folds it into a per-row 64-bit key with atomicMax (value in the high word as an
 //   order-preserving integer, ~index in the low word: max = largest value, then smallest index) and the last block to arrive writes
-//   idx[b] and clears the row's scratch for the next call.  The scratch lives in the library (VIDI_AM_ROWS rows): calls on different
-//   streams must not overlap in time (the engine issues its decode step on one stream).
-#define VIDI_AM_ROWS 256
-__device__ unsigned long long g_am_best[VIDI_AM_ROWS];
-__device__ unsigned int g_am_count[VIDI_AM_ROWS];
+//   idx[b] and clears the row's scratch for the next call.  The scratch is CALLER-OWNED (vidi_softcap_argmax_workspace_bytes: 16 bytes per
+//   row = a 64-bit key + a 32-bit arrival counter; zeroed once by the caller, left zeroed by every call): the library holds no state, so
+//   calls on different streams are independent as long as they use different workspaces (stateless, re-entrant).
+struct AmSlot { unsigned long long best; unsigned int count; unsigned int pad; };
 
 template <typename T>
 __device__ __forceinline__ float softcap_value(float x, float cap) { return rnd<T>(rnd<T>(tanhf(rnd<T>(x / cap))) * cap); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void softcap_argmax_kernel(u16* __restrict__ logits, long long* __restrict__ idx, int V,
-                                                             long long ld, float cap, int vec) {
+                                                             long long ld, float cap, int vec, AmSlot* __restrict__ ws) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -267,12 +266,12 @@ __global__ __launch_bounds__(256) void softcap_argmax_kernel(u16* __restrict__ l
         if (bi != 0x7fffffff) {                          // a slice of NaNs only contributes nothing (as `x > best` never held for them)
             unsigned u = __float_as_uint(best);
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-            atomicMax(&g_am_best[b], ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi));
+            atomicMax(&ws[b].best, ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi));
         }
         __threadfence();
-        if (atomicAdd(&g_am_count[b], 1u) == gridDim.x - 1) {
-            const unsigned long long key = atomicExch(&g_am_best[b], 0ull);
-            g_am_count[b] = 0;
+        if (atomicAdd(&ws[b].count, 1u) == gridDim.x - 1) {
+            const unsigned long long key = atomicExch(&ws[b].best, 0ull);
+            ws[b].count = 0;
             idx[b] = key ? (long long)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0x7fffffffll;
         }
     }
@@ -383,9 +382,9 @@ static int ew_dispatch_T(int op, void** a, const long long* i, const float* f, h
             const int vec = (V % 8 == 0) && (i[2] % 8 == 0) && (((uintptr_t)a[0] & 15) == 0);
             const int items = vec ? V / 8 : V;
             const int nblk = max(1, min(128, (items + 255) / 256));
-            for (int b0 = 0; b0 < B; b0 += VIDI_AM_ROWS)      // more rows than scratch slots: stream-ordered batches reuse the slots
-                hipLaunchKernelGGL(softcap_argmax_kernel<T>, dim3(nblk, min(VIDI_AM_ROWS, B - b0)), dim3(256), 0, st,
-                                   (u16*)a[0] + (size_t)b0 * i[2], (long long*)a[1] + b0, V, i[2], f[0], vec);
+            for (int b0 = 0; b0 < B; b0 += 32768)             // gridDim.y limit
+                hipLaunchKernelGGL(softcap_argmax_kernel<T>, dim3(nblk, min(32768, B - b0)), dim3(256), 0, st,
+                                   (u16*)a[0] + (size_t)b0 * i[2], (long long*)a[1] + b0, V, i[2], f[0], vec, (AmSlot*)a[2] + b0);
             break;
         }
         case EW_MEL_T: {

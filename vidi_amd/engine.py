@@ -1030,8 +1030,17 @@ class VidiEngine:
         B = hn_last.shape[0]
         logits = self.proj(hn_last.contiguous(), self.lm_head)
         idx = torch.empty((B,), dtype=torch.int64, device=self.dev)
-        hip.softcap_argmax(logits, idx, self.cfg.final_logit_softcapping)
+        hip.softcap_argmax(logits, idx, self.cfg.final_logit_softcapping, self.argmax_workspace(B))
         return logits, idx
+
+    def argmax_workspace(self, B: int) -> torch.Tensor:
+        """the engine's scratch for vidi_softcap_argmax (the C ABI keeps no state; the engine issues its work on one stream at a time)"""
+        ws = getattr(self, "_am_ws", None)
+        if ws is None or ws.numel() * 8 < 16 * B:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("argmax workspace must exist before graph capture (run one eager step first)")
+            ws = self._am_ws = hip.softcap_argmax_workspace(max(256, B), self.dev)
+        return ws
 
     def embed_tokens(self, ids: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         """embed_tokens(ids) * normalizer (normalize=False: the raw table rows); ids < 0 give zero rows (padding)."""

@@ -69,7 +69,7 @@ SIGNATURES = {
     "vidi_add3": [_c_vp] * 4 + [_c_ll, _c_int, _c_vp],
     "vidi_embed": [_c_vp] * 3 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp],
     "vidi_geglu_unpack": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp],
-    "vidi_softcap_argmax": [_c_vp] * 2 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp],
+    "vidi_softcap_argmax": [_c_vp] * 2 + [_c_int, _c_int, _c_ll, _c_f, _c_int, _c_vp, _c_vp],
     "vidi_mel_transpose_pad": [_c_vp] * 2 + [_c_int] * 4 + [_c_vp],
     "vidi_sinusoid": [_c_vp] * 2 + [_c_int] * 5 + [_c_vp],
     "vidi_resize_h_u8": [_c_vp] * 4 + [_c_ll, _c_int, _c_int, _c_int, _c_int, _c_vp],
@@ -97,6 +97,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.vidi_build_info.restype = ctypes.c_char_p
     lib.vidi_attn_cross_workspace_bytes.restype = ctypes.c_size_t
     lib.vidi_attn_cross_workspace_bytes.argtypes = [_c_int] * 4
+    lib.vidi_softcap_argmax_workspace_bytes.restype = ctypes.c_size_t
+    lib.vidi_softcap_argmax_workspace_bytes.argtypes = [_c_int]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -715,10 +717,30 @@ def resize_bilinear_ac(x, out, *, T, s_in, s_out, C):
     return out
 
 
-def softcap_argmax(logits, idx, cap):
+def softcap_argmax_workspace(B: int, device) -> torch.Tensor:
+    """zeroed caller-owned scratch of vidi_softcap_argmax for up to B rows (every call leaves it zeroed)"""
+    n = load_library().vidi_softcap_argmax_workspace_bytes(int(B))
+    return torch.zeros((n // 8,), dtype=torch.int64, device=device)
+
+
+_am_ws = {}
+
+
+def softcap_argmax(logits, idx, cap, workspace: Optional[torch.Tensor] = None):
+    """workspace: from softcap_argmax_workspace (one per stream that may run concurrently).  Without one, a zeroed scratch cached per
+    (device, stream) is used — allocated eagerly on first use, so pass an explicit workspace to calls that are graph-captured."""
     B, V = logits.shape
-    _check(load_library().vidi_softcap_argmax(_p(logits), _p(idx), B, V, logits.stride(0), float(cap or 0.0), _dt(logits), _stream()),
-           "vidi_softcap_argmax")
+    if workspace is None:
+        key = (logits.device.index, _stream())
+        workspace = _am_ws.get(key)
+        if workspace is None or workspace.numel() * 8 < 16 * B:
+            if torch.cuda.is_current_stream_capturing():
+                raise VidiHipError("vidi_softcap_argmax: pass a pre-allocated workspace when capturing a graph")
+            workspace = _am_ws[key] = softcap_argmax_workspace(max(B, 64), logits.device)
+    elif workspace.numel() * workspace.element_size() < 16 * B:
+        raise VidiHipError("vidi_softcap_argmax: workspace too small")
+    _check(load_library().vidi_softcap_argmax(_p(logits), _p(idx), B, V, logits.stride(0), float(cap or 0.0), _dt(logits), _p(workspace),
+                                              _stream()), "vidi_softcap_argmax")
     return idx
 
 

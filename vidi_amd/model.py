@@ -384,7 +384,7 @@ class VidiForCausalLM:
         flat = keep.reshape(Bk * Lk, H).contiguous()
         logits = hip.gemm(flat, eng.lm_head, None) if flat.shape[0] > 8 else hip.gemv(flat, eng.lm_head)
         idx = torch.empty((Bk * Lk,), dtype=torch.int64, device=eng.dev)
-        hip.softcap_argmax(logits, idx, self.config.final_logit_softcapping)
+        hip.softcap_argmax(logits, idx, self.config.final_logit_softcapping, eng.argmax_workspace(Bk * Lk))
         return DattnCausalLMOutputWithPast(logits=logits.view(Bk, Lk, -1), past_key_values=ts,
                                            past_image_key_values=mm_state, past_audio_key_values=mm_state)
 
