@@ -28,6 +28,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/fp16, MI355X_MICROARCH.md
+# With randn * 0.02 weights the text->video attention logits have a spread of ~1.4: over 90 000 keys the softmax is nearly flat, the T2V
+# output is an average of ~10^4 random V rows (1 % of the T2T output) and the first token never depended on the video (it was 67480 for
+# every input in rounds 1-3).  q_proj x 2 doubles the logits' spread (Neff ~ 20 keys): the video now moves the logits, so the in-run
+# checks below see the multimodal path.  FLOPs, bytes and shapes are unchanged.
+ATTN_GAIN = 2.0
+# bounds of the in-run verification (fractions of the reference's spread), about 2x what the kernels use against the same-rounding
+# (bf16) oracle at these depths (tests/test_gpu_full_depth.py, profiles/r4_tolerance_audit.jsonl)
+VERIFY_BOUND_EMBEDS = 0.06
+VERIFY_BOUND_KV = 0.04
 
 
 def parse():
@@ -53,6 +62,10 @@ def parse():
     ap.add_argument("--aud-chunk", type=int, default=0, help="override cfg.aud_chunks_per_batch")
     ap.add_argument("--no-preproc", action="store_true", help="skip the extra (untimed-in-`value`) GPU preprocessing leg")
     ap.add_argument("--src-hw", type=int, nargs=2, default=[480, 854], help="decoded frame size fed to the preprocessing leg")
+    ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of sampled frames / K/V-cache rows after the timed region")
+    ap.add_argument("--attn-gain", type=float, default=ATTN_GAIN, help="factor on the decoder's random q_proj weights (a power of two: exact in "
+                                                                        "bf16/fp16) so that the cross-attention over ~10^5 keys is peaked enough "
+                                                                        "for the first token to depend on the video; 1 = SURVEY 8d's plain randn * 0.02")
     return ap.parse_args()
 
 
@@ -93,6 +106,24 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def _physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False, windows=None):
@@ -187,8 +218,10 @@ def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False, windows=None):
                       "effective_tflops": (T * cfg.vis_select_layers * f_vis + (Nv + Na) * cfg.num_hidden_layers * f_llm +
                                            C * cfg.aud_num_layers * f_aud + (Nv + Na) * cfg.num_hidden_layers * f_x) / t_total / 1e12}
     best = max(legs, key=lambda n: legs[n]["value"])
-    # `cores` = the threads the winning leg actually ran on (the thread sweep picks them per leg); `host_threads` = what the box offers
-    return {"value": legs[best]["value"], "unit": "video-tokens/s", "cores": legs[best]["threads"], "host_threads": cores, "threads": legs[best]["threads"], "kind": "port",
+    # `cores` (the contract's key) = `threads_used` = the threads the winning leg actually ran on (the sweep picks them per leg);
+    # `host_threads` / `host_cores_physical` = what the box offers
+    return {"value": legs[best]["value"], "unit": "video-tokens/s", "cores": legs[best]["threads"], "threads_used": legs[best]["threads"],
+            "host_threads": cores, "host_cores_physical": _physical_cores(), "kind": "port",
             "dtype": best, "cpu_model": _cpu_model(),
             "sample": f"oracle (eager PyTorch, fp32 and bf16; the faster one is `value`) on {nf} frames x {vis_l} SigLIP layers, {ntok} tokens x "
                       f"{llm_l} LLM stream layers, {nwin} Whisper windows x {aud_l} layers, x-attn Lq={prompt_len} over {nk} keys x {x_calls} calls; "
@@ -196,6 +229,184 @@ def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False, windows=None):
                       f"{cfg.vis_select_layers}+{cfg.num_hidden_layers}+{cfg.aud_num_layers} layers",
             "t_prefill_extrapolated_s": legs[best]["t_prefill_extrapolated_s"], "by_dtype": legs,
             "thread_sweep_gemm_tflops": {f"{d}@{n}": v for (d, n), v in probe.items()}}
+
+
+def _oracle_frame_embeds(O, px, t_global, T, w, ocfg, normalizer_dtype):
+    """Token embeddings (inputs of the decoder's multimodal stream) of the frames `px` = frames `t_global` of a T-frame video:
+    oracle/vidi_oracle.py:encode_video_images restricted to a few frames, with the GLOBAL frame count deciding the token budget and
+    the GLOBAL index addressing pos_t (multimodal.py:156-208), then `* normalizer` (gemma.py:353-355)."""
+    import torch
+    m = "model."
+    feats = O.siglip_forward(px, w, ocfg)
+    side, pool, d = ocfg.vis_side, ocfg.mm_image_pool_size, ocfg.hidden_size
+    feats = feats.reshape(len(feats), side, side, -1).permute(0, 3, 1, 2)
+    if ocfg.arch == "mistral":
+        feats = O.learned_conv2d_pool(feats, w[m + "mm_rand_img_pool.conv.weight"], pool)
+    else:
+        feats = O.conv2d_pool(feats, O.token_budget_hw(T, side, pool, ocfg.mm_max_tokens_base), pool)
+    feats = feats.permute(0, 2, 3, 1)
+    feats = O.projector_mlp(feats, w, m + "mm_rand_img_projector.")
+    feats = O.mm_RMSNorm(feats, w[m + "mm_rand_img_norm.weight"])
+    ph = O.learnable_pos_embd(feats.shape[1], pool, d, w, m + "mm_rand_pos_h.", feats.dtype)
+    feats = feats + O.mm_rms_norm(ph.reshape(1, -1, 1, d))
+    pw = O.learnable_pos_embd(feats.shape[2], pool, d, w, m + "mm_rand_pos_w.", feats.dtype)
+    feats = feats + O.mm_rms_norm(pw.reshape(1, 1, -1, d))
+    pt = O.learnable_pos_embd(T, ocfg.mm_time_interval, d, w, m + "mm_rand_pos_t.", feats.dtype)
+    feats = feats + O.mm_rms_norm(pt[torch.as_tensor(t_global)].reshape(-1, 1, 1, d))
+    feats = feats.flatten(1, 2)
+    mask = torch.sum(torch.abs(feats), dim=-1) != 0
+    feats = O.mm_RMSNorm(feats, w[m + "mm_rand_llm_norm.weight"]) * mask.unsqueeze(-1)
+    if ocfg.arch != "mistral":
+        feats = feats * torch.tensor(d ** 0.5, dtype=normalizer_dtype)
+    return feats
+
+
+def _oracle_window_embeds(O, mel, c_global, audio_size, w, ocfg, normalizer_dtype):
+    """The same for whole 30-s audio windows `c_global` (windows that the global floors of multimodal.py:226-235 do not clip)."""
+    import torch
+    import torch.nn.functional as F
+    m = "model."
+    feats = O.whisper_encoder_forward(mel, w, ocfg)                                  # [n, 1500, Da]
+    pool, d = ocfg.mm_audio_pool_size, ocfg.hidden_size
+    s2_total = O.audio_token_counts([audio_size], ocfg)[1][0]
+    per = feats.shape[1] // pool
+    x = F.conv1d(feats.permute(0, 2, 1), w[m + "mm_rand_aud_pool.weight"], None, stride=pool).permute(0, 2, 1)      # [n, per, .]
+    x = O.projector_mlp(x, w, m + "mm_rand_aud_projector.")
+    x = O.mm_RMSNorm(x, w[m + "mm_rand_aud_norm.weight"])
+    pt = O.learnable_pos_embd(s2_total, ocfg.mm_time_interval, d, w, m + "mm_rand_pos_t.", x.dtype)
+    rows = torch.stack([torch.arange(c * per, (c + 1) * per) for c in c_global])
+    x = x + O.mm_rms_norm(pt[rows])
+    mask = torch.sum(torch.abs(x), dim=-1) != 0
+    x = O.mm_RMSNorm(x, w[m + "mm_rand_llm_norm.weight"]) * mask.unsqueeze(-1)
+    if ocfg.arch != "mistral":
+        x = x * torch.tensor(d ** 0.5, dtype=normalizer_dtype)
+    return x
+
+
+def _cache_rows(mm, li, rows, nkv, hd):
+    """K and V rows `rows` (local key indices) of layer li out of the tiled caches -> two [n, nkv*hd] fp32 host tensors"""
+    r = torch.as_tensor(rows, dtype=torch.int64, device=mm.kc.device)
+    k = mm.kc[li].reshape(nkv, -1, hd)[:, r].permute(1, 0, 2).reshape(len(rows), nkv * hd)
+    tk = r & 31
+    x = tk & 15
+    pos = (tk & ~15) | (8 * ((x >> 2) & 1) + (x & 3) + 4 * (x >> 3))                # perm16 key order inside a 32-key sub-tile
+    v = mm.vtc[li][:, r >> 5, :, pos]                                               # [n, nkv, hd]
+    return k.float().cpu(), v.reshape(len(rows), nkv * hd).float().cpu()
+
+
+def verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, rank, pixel, mel, f0, f1, T, c0, c1, audio_size, Nv, Na,
+                          fi, fa, mm, idt, mask, pos, lg0):
+    """Untimed check of what the timed kernels produced, against the CPU oracle (oracle/vidi_oracle.py — the checker, never the thing
+    measured) evaluated in the model dtype with the reference's eager rounding points:
+      * the token embeddings of three frames (first / middle / last: SigLIP x26 -> pool -> projector -> norms -> positions) and of one
+        30-s audio window (Whisper x32 -> Conv1d pool -> projector -> norm -> positions);
+      * 64 sampled K/V-cache rows (image + audio keys; first / last rows, frame edges, random rows) of layers 0, mid, last: the diagonal
+        stream is row-wise, so the oracle runs `mm_stream_layer` through all layers on just those rows, starting from the embeddings the
+        GPU produced;
+      * how much the first-token logits move when every video key is masked (the multimodal path must matter to the answer).
+    Every rank checks the sampled rows / frames it owns (global indices, so the sample is the same for every N); the errors are MAX-reduced.
+    Errors are max |got - ref| as a fraction of the reference tensor's spread (std)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dataclasses
+    import numpy as np
+    import vidi_oracle as O
+    t_begin = time.perf_counter()
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    d = {k: v for k, v in cfg.to_dict().items() if k in names}
+    d["vis_select_layer"] = cfg.mm_vision_select_layer
+    d["arch"] = cfg.arch
+    ocfg = O.OracleConfig(**d)
+    nkv, hd, Lr = cfg.num_key_value_heads, cfg.head_dim, cfg.num_hidden_layers
+    tpf = Nv // T
+    per = cfg.aud_max_source_positions // cfg.mm_audio_pool_size
+    spread = lambda got, ref: float((got.float() - ref.float()).abs().max() / ref.float().std())
+    errs = {"embeds_frames": 0.0, "embeds_audio": 0.0, "kv": 0.0}
+    counts = {"frames": 0, "windows": 0, "kv_rows": 0}
+    check_layers = sorted({0, (Lr - 1) // 2, Lr - 1})
+    per_layer = {}
+
+    def local_checks():
+        """parts (1) and (2): rank-local (no collective inside)"""
+        wdev = make_weights()                   # the original (not repacked) parameters again: same seed, same tensors
+
+        class HostView:                         # tensors cross to the host when the oracle asks for them (one layer at a time)
+            def __getitem__(self, k): return wdev[k].cpu()
+            def __contains__(self, k): return k in wdev
+            def get(self, k, default=None): return wdev[k].cpu() if k in wdev else default
+
+        w = HostView()
+        # ---- (1) token embeddings of sampled frames / one audio window ----
+        mine = [t for t in sorted({0, T // 2, T - 1}) if f0 <= t < f1]
+        if mine and fi is not None and fi.shape[0]:
+            ref = _oracle_frame_embeds(O, pixel[[t - f0 for t in mine]].cpu(), mine, T, w, ocfg, dtype)
+            got = torch.stack([fi[(t - f0) * tpf: (t - f0 + 1) * tpf] for t in mine]).cpu()
+            errs["embeds_frames"] = spread(got, ref)
+            counts["frames"] = len(mine)
+        if c0 == 0 and c1 > 0 and fa is not None and fa.shape[0] >= per and Na >= per:
+            ref = _oracle_window_embeds(O, mel[:1].cpu(), [0], audio_size, w, ocfg, dtype)
+            errs["embeds_audio"] = spread(fa[:per].cpu()[None], ref)
+            counts["windows"] = 1
+        # ---- (2) sampled K/V-cache rows through all layers ----
+        rs = np.random.RandomState(7)
+        g_img = sorted(set([0, 1, tpf - 1, tpf, Nv // 2, Nv - 1] + rs.randint(0, Nv, 42).tolist()))
+        g_aud = sorted(set([0, Na // 2, Na - 1] + rs.randint(0, Na, 13).tolist())) if Na > 0 else []
+        img0, aud0 = f0 * tpf, c0 * per
+        n_il, n_al = (0 if fi is None else fi.shape[0]), (0 if fa is None else fa.shape[0])
+        li_rows = [r - img0 for r in g_img if img0 <= r < img0 + n_il]
+        la_rows = [r - aud0 for r in g_aud if aud0 <= r < aud0 + n_al]
+        if li_rows or la_rows:
+            parts = ([fi[torch.as_tensor(li_rows, device=dev)]] if li_rows else []) + ([fa[torch.as_tensor(la_rows, device=dev)]] if la_rows else [])
+            x = torch.cat(parts).cpu()[None]
+            keys = li_rows + [mm.aud_start + r for r in la_rows]
+            for li in range(Lr):
+                x, kref, vref = O.mm_stream_layer(x, w, f"model.layers.{li}.", ocfg)
+                if li in check_layers:
+                    kg, vg = _cache_rows(mm, li, keys, nkv, hd)
+                    per_layer[li] = max(spread(kg, kref[0]), spread(vg, vref[0]))
+            errs["kv"] = max(per_layer.values())
+            counts["kv_rows"] = len(keys)
+        del wdev
+        torch.cuda.empty_cache()
+
+    shared_gpu = world > 1 and os.environ.get("VIDI_FORCE_DEVICE") is not None       # test mode: the ranks share one GPU's memory
+    torch.set_num_threads(max(8, min(64, (os.cpu_count() or 8) // (1 if shared_gpu else world))))
+    with torch.no_grad():
+        if shared_gpu:
+            import torch.distributed as dist
+            for r in range(world):              # one rank at a time holds the second copy of the parameters
+                if r == rank:
+                    local_checks()
+                dist.barrier()
+        else:
+            local_checks()
+        # ---- (3) the answer must depend on the video: first-token logits with every image key masked ----
+        mm_blind = dataclasses.replace(mm, img_mask=torch.zeros(max(64, (mm.n_img + 63) // 64 * 64), dtype=torch.uint8, device=dev), img_any_valid=False)
+        _, last2 = model._prefill(idt, mask, pos, mm_blind, 1)
+        lg2, tk2 = eng.logits_argmax(last2)
+        shift = float((lg2.float() - lg0.float()).abs().max() / lg0.float().std())
+        tk_seen = torch.argmax(lg0.float(), dim=-1)
+        token_moves = bool((tk2.cpu() != tk_seen.cpu()).any())
+    if world > 1:
+        import torch.distributed as dist
+        red_dev = "cpu" if dist.get_backend() == "gloo" else dev
+        e = torch.tensor([errs["embeds_frames"], errs["embeds_audio"], errs["kv"]] + [per_layer.get(li, 0.0) for li in check_layers], dtype=torch.float64, device=red_dev)
+        c = torch.tensor([counts["frames"], counts["windows"], counts["kv_rows"]], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        e, c = e.tolist(), c.tolist()
+        errs = {"embeds_frames": e[0], "embeds_audio": e[1], "kv": e[2]}
+        per_layer = dict(zip(check_layers, e[3:]))
+        counts = {"frames": int(c[0]), "windows": int(c[1]), "kv_rows": int(c[2])}
+    ok = (errs["embeds_frames"] <= VERIFY_BOUND_EMBEDS and errs["embeds_audio"] <= VERIFY_BOUND_EMBEDS and errs["kv"] <= VERIFY_BOUND_KV
+          and counts["frames"] > 0 and counts["kv_rows"] > 0 and math.isfinite(shift))
+    return {"ok": bool(ok), "oracle": f"oracle/vidi_oracle.py in {str(dtype).split('.')[-1]} with the reference's eager rounding points (CPU)",
+            "unit": "max |got - ref| / std(ref)",
+            "embeds_frames_max_err": errs["embeds_frames"], "embeds_audio_max_err": errs["embeds_audio"], "embeds_bound": VERIFY_BOUND_EMBEDS,
+            "frames_checked": counts["frames"], "audio_windows_checked": counts["windows"],
+            "kv_rows_max_err": errs["kv"], "kv_rows_max_err_by_layer": {str(k): v for k, v in per_layer.items()}, "bound": VERIFY_BOUND_KV,
+            "kv_rows": counts["kv_rows"], "kv_layers": check_layers,
+            "first_token_logit_shift_when_video_masked": shift, "first_token_changes_when_video_masked": token_moves,
+            "seconds": time.perf_counter() - t_begin}
 
 
 def main():
@@ -227,7 +438,14 @@ def main():
         cfg.vis_frames_per_chunk = a.vis_chunk
     if a.aud_chunk > 0:
         cfg.aud_chunks_per_batch = a.aud_chunk
-    weights = init_random_weights(cfg, seed=3, dtype=dtype, device=dev)          # replicated on every rank (same seed)
+    def make_weights():
+        w = init_random_weights(cfg, seed=3, dtype=dtype, device=dev)            # replicated on every rank (same seed)
+        if a.attn_gain != 1.0:
+            for li in range(cfg.num_hidden_layers):
+                w[f"model.layers.{li}.self_attn.q_proj.weight"] *= a.attn_gain
+        return w
+
+    weights = make_weights()
     model = VidiForCausalLM(cfg, weights, dtype=dtype, device=dev)
     del weights
     eng = model.engine
@@ -241,10 +459,18 @@ def main():
     audio_size = int(round(secs * 100))                       # mel frames (100 per second)
     f0, f1 = shard(T, world, rank)
     c0, c1 = shard(Cw, world, rank)
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    # the synthetic video is a function of the GLOBAL frame / window index (one generator seed per frame and per window), so an N-rank
+    # run encodes exactly the video the 1-rank run does and `first_token` / `verify` are comparable across N
+    g = torch.Generator(device=dev)
     S = cfg.vis_image_size
-    pixel = (torch.randn((f1 - f0, 3, S, S), generator=g, device=dev) * 0.5).clamp_(-1, 1).to(dtype)
-    mel = (torch.randn((c1 - c0, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g, device=dev) * 0.3).to(dtype)
+    pixel = torch.empty((f1 - f0, 3, S, S), dtype=dtype, device=dev)
+    for f in range(f0, f1):
+        g.manual_seed(1_000_000 + f)
+        pixel[f - f0] = (torch.randn((3, S, S), generator=g, device=dev) * 0.5).clamp_(-1, 1).to(dtype)
+    mel = torch.empty((c1 - c0, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), dtype=dtype, device=dev)
+    for c in range(c0, c1):
+        g.manual_seed(2_000_000 + c)
+        mel[c - c0] = (torch.randn((cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g, device=dev) * 0.3).to(dtype)
     gi = torch.Generator().manual_seed(2)
     plens = [a.prompt_len] * a.queries
     if a.ragged_prompts is not None:
@@ -270,6 +496,7 @@ def main():
     idt, mask, pos = strip_image_token(ids, amask)
     stage_ms = {}
     checks = []            # (first-token logits, argmax) of every timed step: verified after the timed region (finite, identical)
+    last_feats = [None, None]   # the last step's video / audio token embeddings (inputs of the stream): the verify leg reads sampled rows
 
     def ev():
         e = torch.cuda.Event(enable_timing=True)
@@ -288,6 +515,7 @@ def main():
         logits, nxt = eng.logits_argmax(last)
         e4 = ev()
         checks.append((logits, nxt))
+        last_feats[:] = [fi, fa]
         if record:
             torch.cuda.synchronize()
             for k, (x, y) in {"vision_encode": (e0, e1), "audio_encode": (e1, e2), "mm_stream": (e2, e3), "text_prefill": (e3, e4)}.items():
@@ -375,6 +603,16 @@ def main():
     t_decode = t_total_decode / max(1, a.decode_steps)
     t_replay = (t_total_decode - t_capture) / max(1, a.decode_steps - 1) if use_graph else t_decode
 
+    # ---- verification leg (untimed): sampled frames' token embeddings and sampled K/V-cache rows against the CPU oracle ----
+    verify = None
+    if not a.no_verify:
+        verify = verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, rank, pixel, mel, f0, f1, T, c0, c1, audio_size, Nv, Na,
+                                       last_feats[0], last_feats[1], mm, idt, mask, pos, lg0)
+        if not verify["ok"]:
+            if rank == 0:
+                print(json.dumps({"verify": verify}), file=sys.stderr)
+            raise RuntimeError("bench: the HIP path disagrees with the oracle on the sampled rows (see `verify` on stderr)")
+
     fam = timer.summary() if timer is not None else {}
     roof = None
     if "gemm" in fam:
@@ -421,7 +659,7 @@ def main():
         "queries": a.queries, "decode_tokens": a.decode_steps, "decode_graph": bool(use_graph), "decode_graph_capture_ms": t_capture * 1e3,
         "decode_replay_ms_per_token": t_replay * 1e3, "frames_per_s": T * a.steps / dt,
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
-        "first_token": first_token, "first_token_logit_abs_sum": logit_checksum,
+        "first_token": first_token, "first_token_logit_abs_sum": logit_checksum, "attn_gain": a.attn_gain, "verify": verify,
         "kernel_families": fams, "kernel_family_steps": timer_steps,
         "roofline": roof,
     }

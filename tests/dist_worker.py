@@ -41,6 +41,18 @@ def main(out_path):
     n0 = eng.n_collectives
     hn = eng.text_forward(eng.embed_tokens(idt.cuda()), pos.reshape(-1).cuda(), ts, mm, Lq=idt.shape[1], new_mask=mask.cuda())
     per_forward = eng.n_collectives - n0
+    # what the per-layer exchange itself costs, BEFORE any amplification by the layers above: layer 0's merged T2V / T2A outputs for a
+    # fixed query block (5 tokens), straight from the cross-attention entry points the text stream uses
+    nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    Lq, G = 5, nq // nkv
+    qx = seeded((Lq, nq * hd), 77).to(dt).cuda()
+    xo = torch.zeros((2 * Lq, nq * hd), dtype=dt, device="cuda")
+    if eng.sharded:
+        eng._cross_sharded(qx, 0, mm, {"img": xo[:Lq], "aud": xo[Lq:]}, R=Lq * G)
+    elif not eng._cross_dual(qx, 0, mm, xo[:Lq], xo[Lq:], R=Lq * G):
+        eng._cross(qx, 0, mm, "img", xo[:Lq], R=Lq * G)
+        eng._cross(qx, 0, mm, "aud", xo[Lq:], R=Lq * G)
+    eng.n_collectives = n0 + per_forward
     nxt = torch.tensor([30], dtype=torch.int64).cuda()
     hn2 = eng.text_forward(eng.embed_tokens(nxt), torch.tensor([idt.shape[1]]).cuda(), ts, mm, Lq=1)
     toks = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=6, do_sample=False)
@@ -69,7 +81,7 @@ def main(out_path):
         toks_graph = model.generate(ids, mm_state=mm, max_new_tokens=6, do_sample=False).cpu()
         os.environ["VIDI_DECODE_GRAPH"] = "0"
     if rank == 0:
-        torch.save({"tokens8": toks8.cpu(), "collectives8": coll8, "tokens_graph": toks_graph, "sharded": bool(eng.sharded),
+        torch.save({"xattn_layer0": xo.float().cpu(), "tokens8": toks8.cpu(), "collectives8": coll8, "tokens_graph": toks_graph, "sharded": bool(eng.sharded),
                     "prefill": hn.float().cpu(), "decode": hn2.float().cpu(), "g_img": int(mm.g_img), "g_aud": int(mm.g_aud),
                     "n_img_local": int(mm.n_img), "n_aud_local": int(mm.n_aud), "tokens": toks.cpu(), "tokens_cached": toks_cached.cpu(),
                     "collectives_per_forward": per_forward, "layers": cfg.num_hidden_layers}, out_path)

@@ -9,7 +9,14 @@
 Frames / windows / stream rows never interact inside their towers / the diagonal stream, so the GPU runs enough of them to reach the
 production kernels (the persistent GEMM serves >= 192 tiles) and the fp32 CPU oracle is evaluated on a SAMPLE of them; for the decoder
 the key masks make the restriction exact: every key outside the sample is masked on the GPU, so the text stream attends to exactly the
-keys the oracle holds.  bf16 (the bench dtype); the bound of every check is written where it is made."""
+keys the oracle holds.  bf16 (the bench dtype); the bound of every check is written where it is made.
+
+TWO oracle arms per check.  (1) fp32 oracle: the distance to exact arithmetic — dominated by bf16 rounding NOISE that the reference
+itself has (drift report; 5-sigma bounds from the measured noise growth).  (2) SAME-ROUNDING oracle: `oracle/vidi_oracle.py` is
+dtype-generic, so fed bf16 weights and inputs it rounds where the reference's eager modules round (every nn.Module output to bf16,
+norms in fp32 inside).  Against that arm the noise cancels and what is left is the kernels' own deviation (different summation
+order -> occasional one-ulp flips of an output, the documented folds: LayerNorm / softmax scale folded into weights, o_proj over
+the summed repeat_kv column blocks), so its bounds are several times tighter and a real kernel error of a few % at depth fails."""
 import os
 
 import numpy as np
@@ -39,6 +46,16 @@ class LazyF32:
         return self.w[k].float() if k in self.w else default
 
 
+# Bounds of the same-rounding arm (fraction of the reference's spread, relative part); set from the measured use of each
+# (profiles/r4_tolerance_audit.jsonl), about 2x the observed maximum.
+SAME_ROUNDING = {
+    "siglip": (4e-2, 2e-2), "siglip_rms": 1.5e-2,
+    "whisper": (4e-2, 2e-2), "whisper_rms": 1.5e-2,
+    "kv": (2e-2, 1e-2), "kv_rms": 5e-3,
+    "hidden": (6e-2, 2e-2), "hidden_rms": 1.5e-2,
+}
+
+
 def _tower_cfg(**over):
     from vidi_amd.config import tiny
     return tiny(**over)
@@ -66,6 +83,16 @@ def test_siglip_tower_real_dims_full_depth(fold, monkeypatch):
     ref = O.siglip_forward(px[sample].float(), w32, oracle_cfg(cfg))
     # 26 layers of bf16 residual-stream roundings against the fp32 oracle: 7 % of the spread + 4 % relative (1.06 M values; 0.7 used)
     report(f"siglip real dims x26 layers (fold={fold})", got[sample], ref, 7e-2 * ref.std().item(), 4e-2)
+    # same-rounding arm: the oracle in bf16 with the eager rounding points (HF modeling_siglip.py:310-357 executed in bf16)
+    w16 = {k: v.to(dt) for k, v in w32.items()}
+    ref16 = O.siglip_forward(px[sample], w16, oracle_cfg(cfg)).float()
+    report(f"siglip real dims x26 layers (fold={fold}) vs the bf16-rounding oracle", got[sample], ref16, SAME_ROUNDING["siglip"][0] * ref16.std().item(),
+           SAME_ROUNDING["siglip"][1])
+    rms = float((got[sample].float().cpu() - ref16).pow(2).mean().sqrt() / ref16.pow(2).mean().sqrt())
+    rms32 = float((got[sample].float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    rms_ref = float((ref16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    report(f"siglip x26 (fold={fold}) rms error / rms vs bf16 oracle [vs fp32: {rms32:.4f}; bf16 oracle vs fp32 oracle: {rms_ref:.4f}]",
+           torch.tensor([rms]), torch.tensor([0.0]), SAME_ROUNDING["siglip_rms"], 0.0)
 
 
 def test_whisper_encoder_real_dims_full_depth():
@@ -83,6 +110,15 @@ def test_whisper_encoder_real_dims_full_depth():
     ref = O.whisper_encoder_forward(mel[sample].float(), w32, oracle_cfg(cfg))
     # 32 layers: 8 % of the spread + 4 % relative (1.9 M values; 0.7 used)
     report("whisper real dims x32 layers", got[sample], ref, 8e-2 * ref.std().item(), 4e-2)
+    w16 = {k: v.to(dt) for k, v in w32.items()}
+    ref16 = O.whisper_encoder_forward(mel[sample], w16, oracle_cfg(cfg)).float()
+    report("whisper real dims x32 layers vs the bf16-rounding oracle", got[sample], ref16, SAME_ROUNDING["whisper"][0] * ref16.std().item(),
+           SAME_ROUNDING["whisper"][1])
+    rms = float((got[sample].float().cpu() - ref16).pow(2).mean().sqrt() / ref16.pow(2).mean().sqrt())
+    rms32 = float((got[sample].float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    rms_ref = float((ref16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    report(f"whisper x32 rms error / rms vs bf16 oracle [vs fp32: {rms32:.4f}; bf16 oracle vs fp32 oracle: {rms_ref:.4f}]",
+           torch.tensor([rms]), torch.tensor([0.0]), SAME_ROUNDING["whisper_rms"], 0.0)
 
 
 def _unpack_rows(mm, li, rows, nkv, hd):
@@ -186,4 +222,36 @@ def test_decoder_42_layers_real_dims_at_the_60_min_sizes():
         r = O.model_forward(e, torch.tensor([[L + i]]), tm, xi, mi, xa, ma, wl, ocfg, caches, L + i)
         check(f"42-layer teacher-forced decode step {i}", dec[i], r[0], 21e-2 * r.std().item(), 5e-2)
         check_rms(f"42-layer teacher-forced decode step {i}", dec[i], r[0], 5e-2)
+    # ---- same-rounding arm: the oracle again, in bf16 with the eager rounding points, on the same sampled keys ----
+    class Lazy16:
+        def __init__(self, w): self.w = w
+        def __getitem__(self, k): return self.w[k]
+        def __contains__(self, k): return k in self.w
+        def get(self, k, default=None): return self.w.get(k, default)
+
+    w16 = Lazy16(w_host)
+    caches16 = O.OracleCaches()
+    emb16 = O.embed_text(idl, am, w16)
+    href16 = O.model_forward(emb16, opos, am, xi.to(dt), mi, xa.to(dt), ma, w16, ocfg, caches16, 0).float()
+    kvb, kvr = SAME_ROUNDING["kv"]
+    for li in (0, 1, 20, 41):
+        for name, rows, start, cache, c32 in (("image", img_rows, 0, caches16.image, caches.image), ("audio", aud_rows, aud_start, caches16.audio, caches.audio)):
+            kg, vg = _unpack_rows(mm, li, [start + r for r in rows], nkv, hd)
+            kref, vref = cache[li][0].float(), cache[li][1].float()
+            check(f"42-layer stream vs bf16-rounding oracle: layer {li} {name} K rows", kg, kref[0], kvb * kref.std().item(), kvr)
+            check(f"42-layer stream vs bf16-rounding oracle: layer {li} {name} V rows", vg, vref[0], kvb * vref.std().item(), kvr)
+            check_rms(f"42-layer stream vs bf16-rounding oracle: layer {li} {name} K rows", kg, kref[0], SAME_ROUNDING["kv_rms"])
+            # how far the two oracle arms are from each other (the noise the fp32 comparison above has to allow for)
+            d = float((kref[0] - c32[li][0][0].float()).abs().max() / c32[li][0].float().std())
+            print(f"[drift] layer {li} {name}: bf16-rounding oracle vs fp32 oracle, worst K element = {100 * d:.2f} % of the spread")
+    hb, hr = SAME_ROUNDING["hidden"]
+    check("42-layer text prefill hidden (39 tokens) vs bf16-rounding oracle", hn, href16[0], hb * href16.std().item(), hr)
+    check_rms("42-layer text prefill hidden (39 tokens) vs bf16-rounding oracle", hn, href16[0], SAME_ROUNDING["hidden_rms"])
+    tm = am
+    for i, t in enumerate(forced):
+        e = torch.nn.functional.embedding(torch.tensor([[t]]), w16["model.embed_tokens.weight"])
+        tm = torch.cat([tm, torch.ones(1, 1, dtype=torch.bool)], dim=1)
+        r = O.model_forward(e, torch.tensor([[L + i]]), tm, xi.to(dt), mi, xa.to(dt), ma, w16, ocfg, caches16, L + i).float()
+        check(f"42-layer teacher-forced decode step {i} vs bf16-rounding oracle", dec[i], r[0], hb * r.std().item(), hr)
+        check_rms(f"42-layer teacher-forced decode step {i} vs bf16-rounding oracle", dec[i], r[0], SAME_ROUNDING["hidden_rms"])
     assert not failures, "\n".join(failures)

@@ -220,4 +220,24 @@ def test_generate_hooks_logits_processor_stopping_criteria_streamer():
 
     st = Collect()
     out = model.generate(ids, streamer=st, **kw)
-    assert st.ended and [t[0] for t in st.toks] == out[0].tolist() == base[0].tolist()
+    # HF order: the (empty, inputs_embeds-driven) prompt first, then one call per new token
+    assert st.ended and st.toks[0] == [[]] and [t[0] for t in st.toks[1:]] == out[0].tolist() == base[0].tolist()
+
+    # transformers' own TextStreamer(skip_prompt=True) drops the FIRST put (the prompt): every generated token must still be printed
+    from transformers import TextStreamer
+
+    class CharTok:
+        def decode(self, toks, **kw):
+            return "".join(chr(97 + int(t) % 26) + " " for t in toks)
+
+    class Capture(TextStreamer):
+        def __init__(self):
+            super().__init__(CharTok(), skip_prompt=True)
+            self.text = ""
+
+        def on_finalized_text(self, text, stream_end=False):
+            self.text += text
+
+    cap = Capture()
+    out = model.generate(ids, streamer=cap, **kw)
+    assert cap.text.split() == [chr(97 + int(t) % 26) for t in out[0].tolist()]

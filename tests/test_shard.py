@@ -65,7 +65,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, frames, windows, audio_size, ret):
+def _worker(rank, world, port, frames, windows, audio_size, ret, over=None):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
@@ -78,7 +78,7 @@ def _worker(rank, world, port, frames, windows, audio_size, ret):
     from vidi_amd.model import VidiForCausalLM
     from vidi_amd.weights import init_random_weights
     torch.set_num_threads(2)
-    cfg = tiny()
+    cfg = tiny(**(over or {}))
     w = init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu")
     eng = OracleEngine(cfg, w)
     if world > 1:
@@ -110,15 +110,15 @@ def _worker(rank, world, port, frames, windows, audio_size, ret):
         dist.destroy_process_group()
 
 
-def _run(world, frames, windows, audio_size):
+def _run(world, frames, windows, audio_size, over=None, timeout=240):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, frames, windows, audio_size, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frames, windows, audio_size, ret, over)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(ret.get(timeout=240) for _ in range(world))
+    got = sorted(ret.get(timeout=timeout) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -135,6 +135,29 @@ def test_generate_under_set_dist_shards_the_video_and_reproduces_single_rank(wor
         assert toks == ref, (rank, toks, ref)
         f0, f1 = S.shard(frames, world, rank)
         assert sh == dict(kind="img", local=f1 - f0, off=f0, total=frames)          # what the product handed this rank's engine
+
+
+@pytest.mark.parametrize("windows,clip", [(120, 37), (60, 0)], ids=["configs3_60min_1fps", "configs4_30min_2fps"])
+def test_world8_with_the_baseline_partition_shapes(windows, clip):
+    """BASELINE configs[3] / [4] on the host logic, WORLD 8: 3 600 frames -> 450 per rank; 120 windows -> 15 per rank with the last
+    window clipped by the global floors (multimodal.py:226-235: rank 7 owns fewer audio tokens than its windows hold), 60 windows ->
+    8, 8, 8, 8, 7, 7, 7, 7.  Small towers (42-px frames, 4 tokens each) keep it a host-logic test: the token-budget rule sees the GLOBAL
+    3 600 frames (base 1 000 -> the resize branch, as the 60-min config takes it), pos_t the global indices, and `generate()` on every one
+    of the 8 ranks must return the single-rank tokens."""
+    over = dict(vis_image_size=42, mm_max_tokens_base=1000)
+    frames, audio_size = 3600, windows * 100 - clip
+    ref = _run(1, frames, windows, audio_size, over, timeout=600)[0][1]
+    got = _run(8, frames, windows, audio_size, over, timeout=600)
+    assert len(got) == 8
+    for rank, toks, sh in got:
+        assert toks == ref, (rank, toks, ref)
+        assert sh == dict(kind="img", local=450, off=450 * rank, total=3600)
+    # the audio-token ranges of the 8 window shards, as the product computes them (50 encoder rows per window, pool 5)
+    s2_total = (audio_size * 50 // 100) // 5
+    owned = [S.audio_shard_tokens(S.shard(windows, 8, r)[0], S.shard(windows, 8, r)[1] - S.shard(windows, 8, r)[0], 50, 5, s2_total) for r in range(8)]
+    assert sum(n for _, n in owned) == s2_total and all(owned[i][0] + owned[i][1] == owned[i + 1][0] for i in range(7))
+    if clip:
+        assert owned[7][1] < 15 * 10                                 # the last rank's windows are clipped
 
 
 def test_batch_of_eight_ragged_queries_under_set_dist():

@@ -49,6 +49,9 @@ int vidi_patch_embed(const void* px, const void* W, const void* bias, const void
     (void)hipGetLastError();
     if (!px || !W || !bias || !pos || !Y) return VIDI_ERR_ARG;
     if (T <= 0 || S <= 0 || P <= 0 || P > 16 || S < P) return VIDI_ERR_SHAPE;
+    // every 16-byte LDS-DMA piece of the gather starts at pixel (.. * S + px * P + dy * S): 4-byte aligned only when P and S are even
+    // (tools/micro/lds_dma_align_probe.hip validated 4-byte, not 2-byte, alignment): odd sizes take the caller's im2col + vidi_gemm arm
+    if ((P | S) & 1) return VIDI_ERR_ALIGN;
     if ((ldw % 8) || (ldy % 8) || (ldpos % 8)) return VIDI_ERR_ALIGN;
     if (((uintptr_t)px & 3) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)pos & 15)) return VIDI_ERR_ALIGN;
     const int side = S / P, n = side * side;

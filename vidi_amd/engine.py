@@ -212,7 +212,7 @@ class VidiEngine:
         conv_w = g(v + "embeddings.patch_embedding.weight")
         # patch embedding straight from the NCHW pixels (vidi_patch_embed: the persistent GEMM's loader gathers the patches; default) or
         # through an im2col buffer + the generic GEMM (VIDI_PATCH_LOADER=0, the A/B arm; also patches wider than the loader's 16-pixel run)
-        self.patch_loader = os.environ.get("VIDI_PATCH_LOADER", "1") != "0" and P <= 16 and 3 * P * 16 >= 192
+        self.patch_loader = os.environ.get("VIDI_PATCH_LOADER", "1") != "0" and P <= 16 and 3 * P * 16 >= 192 and (P | cfg.vis_image_size) % 2 == 0
         if self.patch_loader:
             pw = hip.patch_embed_weight(conv_w, P)
         else:

@@ -314,6 +314,10 @@ class VidiForCausalLM:
         use_graph = (not do_sample and not processors and not criteria and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
                      and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1" and (eng.world == 1 or self._backend() == "nccl"))
         replay = None
+        if streamer is not None:
+            # HF generate() hands the streamer the prompt ids first — [B, 0] when driven by inputs_embeds, as the reference is
+            # (gemma.py:646-655) — then every new token: TextStreamer(skip_prompt=True) drops exactly that first call
+            streamer.put(out[:, :0].cpu())
         for step in range(max_new):
             nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
             out[:, step] = nxt
@@ -324,6 +328,10 @@ class VidiForCausalLM:
             for crit in criteria:
                 stop = crit(out[:, :n_done], scores)
                 finished = finished | (stop.to(finished.device).bool() if torch.is_tensor(stop) else torch.full_like(finished, bool(stop)))
+            if criteria and eng.world > 1:
+                # user criteria may be non-deterministic (MaxTime): every rank follows rank 0's decision, or a rank that stops alone
+                # strands the others in the next layer's all-gather
+                finished = self._bcast0(finished.to(torch.uint8)).bool()
             if bool(finished.all()) or step == max_new - 1:          # one D2H sync per token, like HF's stopping criteria
                 break
             if use_graph:
