@@ -354,9 +354,11 @@ def projector_mlp(x: Tensor, w: W, prefix: str) -> Tensor:
 # encode_video_images / encode_video_audios — lmm/dattn/multimodal.py:156-252
 # --------------------------------------------------------------------------------------------
 def encode_video_images(images: Sequence[Tensor], w: W, cfg: OracleConfig,
-                        vis_features: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                        vis_features: Optional[Tensor] = None, budget_frames: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     """images: list (batch) of [T_i,3,S,S].  Returns (features[B,Nv,H], mask[B,Nv] bool).
-    `vis_features` lets a caller inject precomputed tower outputs (for slice tests)."""
+    `vis_features` lets a caller inject precomputed tower outputs (for slice tests); `budget_frames` overrides the frame count the
+    token-budget rule sees (:175-180 counts the concatenated frames of the WHOLE batch) so that one video of a batch can be evaluated
+    on its own with the batch's budget."""
     m = "model."
     split_sizes = [im.shape[0] for im in images]
     concat = torch.cat(list(images), dim=0)
@@ -366,7 +368,8 @@ def encode_video_images(images: Sequence[Tensor], w: W, cfg: OracleConfig,
     if cfg.arch == "mistral":                                                           # Vidi_7B/.../multimodal.py:165-170
         feats = learned_conv2d_pool(feats, w[m + "mm_rand_img_pool.conv.weight"], cfg.mm_image_pool_size)
     else:
-        hw = token_budget_hw(feats.size(0), side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)  # :175-180
+        hw = token_budget_hw(feats.size(0) if budget_frames is None else budget_frames, side, cfg.mm_image_pool_size,
+                             cfg.mm_max_tokens_base)                                   # :175-180
         feats = conv2d_pool(feats, hw, cfg.mm_image_pool_size)                          # :182-189
     feats = feats.permute(0, 2, 3, 1)                                                   # :190
     feats = projector_mlp(feats, w, m + "mm_rand_img_projector.")                       # :192

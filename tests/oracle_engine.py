@@ -62,7 +62,7 @@ class OracleEngine:
             f, m = O.encode_video_images([full], self.w, self.ocfg)
             self.last_shard = dict(kind="img", local=int(pixel.shape[0]), off=int(frame_offset), total=int(full.shape[0]))
             return f[0], m[0].to(torch.uint8)
-        f, m = O.encode_video_images([pixel.float().cpu()], self.w, self.ocfg)
+        f, m = O.encode_video_images([pixel.float().cpu()], self.w, self.ocfg, budget_frames=kw.get("budget_frames"))
         return f[0], m[0].to(torch.uint8)
 
     def encode_video_audios(self, mel, audio_size, normalizer=None, chunk_offset=0, sample_flag=None, **kw):

@@ -174,6 +174,66 @@ def test_generate_matches_oracle(tiny_setup):
     assert got.shape[1] <= n_new and got.dtype == torch.int64
 
 
+def test_batch_of_videos_one_tower_pass_and_the_batch_token_budget():
+    """multimodal.py:157-180 on the HIP engine: a batch of two videos goes through SigLIP / Whisper in ONE pass (the concatenated frames /
+    windows) and the token-budget rule counts the frames of the WHOLE batch — 3 + 4 frames cross the (lowered) budget that neither
+    video crosses alone.  `encode_videos` against the oracle's batched evaluation (masks bit-exact), first greedy tokens of `generate`
+    against the oracle's batched greedy loop, and the number of tower launches (one pass = as many as for one 7-frame video)."""
+    from vidi_amd.config import tiny
+    from vidi_amd.model import VidiForCausalLM
+    from vidi_amd import hip
+    dt = torch.bfloat16
+    cfg = tiny(mm_max_tokens_base=75)
+    eng, w32 = make(cfg, dt, seed=4)
+    ocfg = oracle_cfg(cfg)
+    model = VidiForCausalLM.__new__(VidiForCausalLM)
+    model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), eng
+    from types import SimpleNamespace
+    model.generation_config = SimpleNamespace(eos_token_id=cfg.eos_token_id, pad_token_id=0)
+    model.model = None
+    S = cfg.vis_image_size
+    vids = [seeded((n, 3, S, S), 300 + n, 0.5).clamp(-1, 1).to(dt) for n in (3, 4)]
+    mels = [seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 310 + i, 0.3).to(dt) for i in range(2)]
+    sizes = [100, 83]
+    fb, mb = O.encode_video_images([v.float() for v in vids], w32, ocfg)
+    ab, amb = O.encode_video_audios([m.float() for m in mels], sizes, w32, ocfg)
+    alone, _ = O.encode_video_images([vids[0].float()], w32, ocfg)
+    assert fb.shape[1] // 4 != alone.shape[1] // 3                               # the batch is pooled differently from a video alone
+    timer = hip.KernelTimer()
+    hip.TIMER = timer
+    try:
+        fi, mi, fa, ma = model.encode_videos([v.cuda() for v in vids], [m.cuda() for m in mels], sizes)
+        torch.cuda.synchronize()
+    finally:
+        hip.TIMER = None
+    n_batch = sum(v["launches"] for v in timer.summary().values())
+    timer1 = hip.KernelTimer()
+    hip.TIMER = timer1
+    try:
+        model.encode_videos([torch.cat(vids).cuda()], [torch.cat(mels).cuda()], [183])
+        torch.cuda.synchronize()
+    finally:
+        hip.TIMER = None
+    n_one = sum(v["launches"] for v in timer1.summary().values())
+    assert torch.equal(mi.cpu(), mb) and torch.equal(ma.cpu(), amb)
+    report("batched encode_videos: image features", fi, fb, *tol(dt, fb.std().item(), tight=True))
+    report("batched encode_videos: audio features", fa, ab, *tol(dt, ab.std().item(), tight=True))
+    # one tower pass for the batch: the per-video tail (pool, projector, norms, positions) adds a few launches per video, the towers none
+    assert n_batch < n_one + 40, (n_batch, n_one)
+    ids = torch.tensor([[2, 21, 22, -200, 23, 24], [2, 31, -200, 32, 33, 34]])
+    ref_ids, dbg = O.generate_greedy(ids, [v.float() for v in vids], [m.float() for m in mels], sizes, w32, ocfg, 4, return_debug=True)
+    out = model.forward(ids, images=[v.cuda() for v in vids], audios=[m.cuda() for m in mels], audio_sizes=sizes, logits_to_keep=1)
+    ref_logits = dbg["prefill_logits"]
+    ltol = logit_tol(dt, ref_logits)
+    report("batched forward: last-token logits of both rows", out.logits[:, -1], ref_logits, ltol, 0.0)
+    got = model.generate(ids, images=[v.cuda() for v in vids], audios=[m.cuda() for m in mels], audio_sizes=sizes, max_new_tokens=4,
+                         eos_token_id=999999).cpu()
+    for b in range(2):
+        top2 = torch.topk(ref_logits[b].float(), 2).values
+        if float(top2[0] - top2[1]) > 2 * ltol:
+            assert int(got[b, 0]) == int(ref_ids[b, 0])
+
+
 def test_graph_decode_equals_eager(tiny_setup, monkeypatch):
     """The hipGraph-replayed decode (device-side cache position, vidi_attn_text_dyn) must emit exactly the
     tokens of the eager per-launch loop, for a batch of two prompts of different lengths sharing one video."""

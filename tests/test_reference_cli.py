@@ -241,3 +241,38 @@ def test_generate_hooks_logits_processor_stopping_criteria_streamer():
     cap = Capture()
     out = model.generate(ids, streamer=cap, **kw)
     assert cap.text.split() == [chr(97 + int(t) % 26) for t in out[0].tolist()]
+
+
+def test_batch_of_videos_shares_the_token_budget_like_the_reference():
+    """multimodal.py:157-180: the reference concatenates the frames of ALL samples of a batch before the token-budget rule, so two videos
+    that are each under the budget are pooled down when their SUM is over it.  The product answers a batch row by row (rows never
+    interact) but must hand every row the batch's frame count: `generate()` / `encode_videos()` on a 3 + 4-frame batch whose 7 frames
+    cross the (lowered) budget against the oracle's own batched evaluation — and against the per-video evaluation, which differs."""
+    import dataclasses
+    from vidi_amd.model import VidiForCausalLM
+    from vidi_amd.config import tiny
+    from vidi_amd.weights import init_random_weights
+    cfg = tiny(mm_max_tokens_base=75)                      # budget 300 tokens: 4 frames x 64 = 256 stay, 7 x 64 = 448 take the resize branch
+    w = init_random_weights(cfg, seed=4, dtype=torch.float32, device="cpu")
+    eng = OracleEngine(cfg, w)
+    model = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=eng)
+    g = torch.Generator().manual_seed(9)
+    S = cfg.vis_image_size
+    vids = [(torch.randn((n, 3, S, S), generator=g) * 0.5).clamp(-1, 1) for n in (3, 4)]
+    mels = [torch.randn((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g) * 0.3 for _ in range(2)]
+    sizes = [100, 83]
+    w32 = {k: v.float() for k, v in w.items()}
+    ocfg = oracle_config(cfg)
+    fb, mb = O.encode_video_images(vids, w32, ocfg)                                    # the reference's batch semantics
+    f_alone, _ = O.encode_video_images(vids[:1], w32, ocfg)
+    # (tiny dims: the rule's floor of 10 x 10 gives 25 tokens per frame inside the batch against 4 x 4 = 16 for the video alone)
+    assert fb.shape[1] // 4 != f_alone.shape[1] // 3, "the batch must be pooled differently from a video on its own for this test to bite"
+    fi, mi, fa, ma = model.encode_videos(vids, mels, sizes)
+    assert fi.shape == fb.shape and torch.equal(mi, mb)
+    assert torch.allclose(fi.float(), fb, rtol=1e-5, atol=1e-6)
+    ids = torch.tensor([[2, 21, 22, -200, 23, 24], [2, 31, -200, 32, 33, 34]])
+    ref = O.generate_greedy(ids, vids, mels, sizes, w32, ocfg, 5)
+    out = model.generate(ids, images=vids, audios=mels, audio_sizes=sizes, max_new_tokens=5, eos_token_id=999999)
+    assert out.tolist() == ref.tolist()
+    logits = model.forward(ids, images=vids, audios=mels, audio_sizes=sizes, logits_to_keep=1).logits if hasattr(eng, "lm_head") else None
+    assert logits is None or logits.shape[0] == 2

@@ -10,5 +10,8 @@ for f in sys.argv[1:]:
                 print('   ', k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items()})
             if d.get('roofline'):
                 print(' roofline', {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d['roofline'].items() if k != 'kernel'})
+            print(' first_token', d.get('first_token'), 'attn_gain', d.get('attn_gain'))
+            if d.get('verify'):
+                print(' verify', json.dumps(d['verify']))
             if 'cpu_baseline' in d:
                 print(' cpu', d['cpu_baseline'].get('value'), d['cpu_baseline'].get('cores'), d.get('speedup_vs_cpu'))

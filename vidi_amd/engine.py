@@ -422,7 +422,11 @@ class VidiEngine:
     # -----------------------------------------------------------------------------------------
     def encode_video_images(self, pixel: torch.Tensor, frame_offset: int = 0, total_frames: Optional[int] = None,
                             normalizer: Optional[float] = None, sample_flag: Optional[torch.Tensor] = None,
-                            vis_features: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                            vis_features: Optional[torch.Tensor] = None, budget_frames: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`pixel`: this call's frames [T,3,S,S] of ONE video — all of it, or (sharded) frames frame_offset .. of its total_frames.
+        `budget_frames`: the frame count the token-budget rule sees.  The reference applies the rule to the CONCATENATED frames of
+        the whole batch (multimodal.py:157-158, 175-180: `n_tokens = image_features.size(0) * ...`), so two 200-frame videos answered
+        in one batch are pooled like a 400-frame video; default = this video's total frames (batch of one)."""
         cfg = self.cfg
         T = pixel.shape[0]
         Ttot = total_frames if total_frames is not None else T
@@ -453,7 +457,7 @@ class VidiEngine:
                     conv = hip.gemm(col, self.mm["img_pool_w"], None)
                 hip.resize_bilinear_ac(conv, pooled[t0 * oh * ow: t1 * oh * ow], T=t1 - t0, s_in=oc, s_out=pool, C=Hv)
         else:
-            hw = token_budget_hw(Ttot, side, pool, cfg.mm_max_tokens_base)                  # global T decides
+            hw = token_budget_hw(Ttot if budget_frames is None else budget_frames, side, pool, cfg.mm_max_tokens_base)   # global T (of the batch) decides
             resize = hw[0] != 28
             h, w = hw if resize else (side + 1, side + 1)
             oh, ow = h // pool, w // pool

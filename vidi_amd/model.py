@@ -133,51 +133,88 @@ class VidiForCausalLM:
     def _row(xs, i):
         return None if xs is None else [xs[i]]
 
-    def encode_videos(self, images, audios, audio_sizes):
-        """-> (image_features[1,Nv,H], image_mask[1,Nv] bool, audio_features[1,Na,H], audio_mask[1,Na] bool),
-        un-normalised like the reference (the normaliser is applied inside the decoder, gemma.py:353-356)."""
+    def _tower_batch(self, images, audios):
+        """ONE pass of each tower over the concatenated frames / 30-s windows of all the batch's videos (multimodal.py:157-169, 216-222:
+        `torch.cat` of the samples, then the tower) -> (per-video SigLIP features or None, per-video Whisper features or None).
+        Engines without the tower entry points (the CPU test engine) and sharded engines (every rank encodes its own frame range of
+        each video) return (None, None): the per-video calls run their towers themselves."""
         eng = self.engine
         B = self._n_videos(images, audios)
-        if B > 1:                                   # per-sample encode, then pad_sequence like multimodal.py:199, 243
-            per = [self.encode_videos(self._row(images, i), self._row(audios, i),
-                                      None if audio_sizes is None else [audio_sizes[i]]) for i in range(B)]
-            pad = torch.nn.utils.rnn.pad_sequence
-            cat = lambda k: None if per[0][k] is None else pad([p[k][0] for p in per], batch_first=True)     # noqa: E731
-            return cat(0), cat(1), cat(2), cat(3)
-        img = self._single(images, "images")
-        aud = self._single(audios, "audios")
-        fi = mi = fa = ma = None
-        if img is not None:
-            fi, mi = eng.encode_video_images(img.to(eng.dev))
-            fi, mi = fi[None], mi[None].bool()
-        if aud is not None:
-            fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]))
-            fa, ma = fa[None], ma[None].bool()
-        return fi, mi, fa, ma
+        vis = aud = None
+        if not hasattr(eng, "siglip_forward") or getattr(eng, "sharded", eng.world > 1):
+            return vis, aud
+        if images is not None and all(int(images[i].shape[0]) > 0 for i in range(B)):
+            f = eng.siglip_forward(torch.cat([images[i].to(eng.dev) for i in range(B)], dim=0))
+            vis = list(torch.split(f, [int(images[i].shape[0]) for i in range(B)], dim=0))
+        if audios is not None and all(int(audios[i].shape[0]) > 0 for i in range(B)):
+            f = eng.whisper_forward(torch.cat([audios[i].to(eng.dev) for i in range(B)], dim=0))
+            aud = list(torch.split(f, [int(audios[i].shape[0]) for i in range(B)], dim=0))
+        return vis, aud
 
-    def encode_mm_state(self, images, audios, audio_sizes) -> MMState:
-        """encode + run the query-independent multimodal stream through all layers (caches).
+    def _batch_frames(self, images) -> Optional[int]:
+        """frames of the WHOLE batch: what the reference's token-budget rule counts (multimodal.py:157-158, 175-180)"""
+        if images is None:
+            return None
+        return int(sum(int(images[i].shape[0]) for i in range(self._n_videos(images, None))))
+
+    def encode_videos(self, images, audios, audio_sizes):
+        """-> (image_features[B,Nv,H], image_mask[B,Nv] bool, audio_features[B,Na,H], audio_mask[B,Na] bool),
+        un-normalised like the reference (the normaliser is applied inside the decoder, gemma.py:353-356).  A batch of videos goes
+        through each tower in ONE pass and shares the token budget (the reference pools by the batch's total frame count), then
+        every video is finished on its own (positions, norms, masks) and the rows are padded like multimodal.py:199, 243."""
+        eng = self.engine
+        B = self._n_videos(images, audios)
+        vis, aud = self._tower_batch(images, audios) if B > 1 else (None, None)
+        budget = self._batch_frames(images) if B > 1 else None
+        per = []
+        for i in range(B):
+            img = self._single(self._row(images, i) if B > 1 else images, "images")
+            au = self._single(self._row(audios, i) if B > 1 else audios, "audios")
+            fi = mi = fa = ma = None
+            if img is not None:
+                kw = {} if budget is None else dict(budget_frames=budget)
+                if vis is not None:
+                    kw["vis_features"] = vis[i]
+                fi, mi = eng.encode_video_images(img.to(eng.dev), **kw)
+            if au is not None:
+                kw = {} if aud is None else dict(aud_features=aud[i])
+                fa, ma = eng.encode_video_audios(au.to(eng.dev), int(audio_sizes[i]), **kw)
+            per.append((fi, None if mi is None else mi.bool(), fa, None if ma is None else ma.bool()))
+        pad = torch.nn.utils.rnn.pad_sequence
+        cat = lambda k: None if per[0][k] is None else pad([p[k] for p in per], batch_first=True)     # noqa: E731
+        return cat(0), cat(1), cat(2), cat(3)
+
+    def encode_mm_state(self, images, audios, audio_sizes, vis_features=None, aud_features=None, budget_frames=None) -> MMState:
+        """encode + run the query-independent multimodal stream through all layers (caches) for ONE video.
 
         Under `engine.set_dist(...)` (one process per GPU) every rank is handed the SAME video and keeps only its share: a
         contiguous range of frames and of 30-s audio windows (vidi_amd/shard.py), encoded with the global positions, streamed
         through the 42 layers locally (the diagonal stream never mixes tokens) and left resident as this rank's K/V shard.
         The flags the reference derives from the whole sample (`images.sum() != 0`, multimodal.py:203-206, 247-250) are taken
-        from the whole sample here too."""
+        from the whole sample here too.  `vis_features` / `aud_features`: this video's tower outputs when a batch of videos went
+        through the towers together; `budget_frames`: the batch's total frames for the token-budget rule (see encode_videos)."""
         eng = self.engine
         img = self._single(images, "images")
         aud = self._single(audios, "audios")
         fi = mi = fa = ma = None
         nz = eng.normalizer
         kw_i, kw_a = {}, {}
+        if budget_frames is not None:
+            kw_i["budget_frames"] = int(budget_frames)
         if getattr(eng, "sharded", eng.world > 1):
             from .shard import video_shard
             sh = video_shard(0 if img is None else int(img.shape[0]), 0 if aud is None else int(aud.shape[0]), eng.world, eng.rank)
             if img is not None:
-                kw_i = dict(frame_offset=sh.f0, total_frames=sh.total_frames, sample_flag=eng.sample_flag(img))
+                kw_i.update(frame_offset=sh.f0, total_frames=sh.total_frames, sample_flag=eng.sample_flag(img))
                 img = img[sh.f0: sh.f1]
             if aud is not None:
                 kw_a = dict(chunk_offset=sh.c0, sample_flag=eng.sample_flag(aud))
                 aud = aud[sh.c0: sh.c1]
+        else:
+            if vis_features is not None:
+                kw_i["vis_features"] = vis_features
+            if aud_features is not None:
+                kw_a["aud_features"] = aud_features
         if img is not None:
             fi, mi = eng.encode_video_images(img.to(eng.dev), normalizer=nz, **kw_i)
         if aud is not None:
@@ -245,14 +282,21 @@ class VidiForCausalLM:
             # row is answered against its own video, unpadded, and the answers are re-padded — the same tokens
             B = self._n_videos(images, audios)
             assert inputs.shape[0] == B, "one prompt per video"
+            # both towers ONCE over the concatenated frames / windows of the batch, and the batch's total frame count for the token
+            # budget (multimodal.py:157-180); from there on the videos are independent
+            vis, aud = self._tower_batch(images, audios)
+            budget = self._batch_frames(images)
             rows = []
             for i in range(B):
                 kw = dict(kwargs)
                 kw["attention_mask"] = None
                 am_i = None if attention_mask is None else attention_mask[i].bool().cpu()
                 ids_i = inputs[i].cpu() if am_i is None else inputs[i].cpu()[am_i]
-                rows.append(self.generate(ids_i[None], images=self._row(images, i), audios=self._row(audios, i),
-                                          audio_sizes=None if audio_sizes is None else [audio_sizes[i]], **kw)[0])
+                mm_i = self.encode_mm_state(self._row(images, i), self._row(audios, i), None if audio_sizes is None else [audio_sizes[i]],
+                                            vis_features=None if vis is None else vis[i], aud_features=None if aud is None else aud[i],
+                                            budget_frames=budget)
+                rows.append(self.generate(ids_i[None], mm_state=mm_i, **kw)[0])
+                del mm_i
             n = max(int(r.shape[0]) for r in rows)
             out = torch.full((B, n), int(pad), dtype=torch.int64, device=eng.dev)
             for i, r in enumerate(rows):
@@ -364,11 +408,15 @@ class VidiForCausalLM:
             ids_all, mask_all, _ = strip_image_token(input_ids, attention_mask)
             L = ids_all.shape[1]
             outs, states = [], []
+            vis, aud = self._tower_batch(images, audios)                       # the towers once over the batch; batch-wide token budget
+            budget = self._batch_frames(images)
             for i in range(B):
                 am_i = None if attention_mask is None else attention_mask[i].bool().cpu()
                 ids_i = input_ids[i].cpu() if am_i is None else input_ids[i].cpu()[am_i]
-                r = self.forward(ids_i[None], images=self._row(images, i), audios=self._row(audios, i),
-                                 audio_sizes=None if audio_sizes is None else [audio_sizes[i]], logits_to_keep=0)
+                mm_i = self.encode_mm_state(self._row(images, i), self._row(audios, i), None if audio_sizes is None else [audio_sizes[i]],
+                                            vis_features=None if vis is None else vis[i], aud_features=None if aud is None else aud[i],
+                                            budget_frames=budget)
+                r = self.forward(ids_i[None], mm_state=mm_i, logits_to_keep=0)
                 outs.append(r.logits[0])
                 states.append((r.past_key_values, r.past_image_key_values))
             full = torch.zeros((B, L, outs[0].shape[-1]), dtype=outs[0].dtype, device=eng.dev)
