@@ -215,26 +215,30 @@ def siglip_forward(pixel: Tensor, w: W, cfg: OracleConfig, prefix: str = "model.
     x = x + w[p + "embeddings.position_embedding.weight"][None]
     n_states = cfg.vis_num_layers + 1
     target = cfg.vis_select_layer % n_states                          # -2 -> L-1 layers applied
+    for i in range(target):
+        x = siglip_layer(x, w, cfg, f"{p}encoder.layers.{i}.")
+    return x
+
+
+def siglip_layer(x: Tensor, w: W, cfg: OracleConfig, lp: str) -> Tensor:
+    """one SiglipEncoderLayer on x:[T,N,Hv] — TP/models/siglip/modeling_siglip.py:250-357 (pre-LN attention + pre-LN MLP)."""
     nh = cfg.vis_num_heads
     hd = cfg.vis_hidden_size // nh
-    for i in range(target):
-        lp = f"{p}encoder.layers.{i}."
-        r = x
-        h = layer_norm(x, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], cfg.vis_ln_eps)
-        T, N, _ = h.shape
-        q = linear(h, w[lp + "self_attn.q_proj.weight"], w[lp + "self_attn.q_proj.bias"]).view(T, N, nh, hd).transpose(1, 2)
-        k = linear(h, w[lp + "self_attn.k_proj.weight"], w[lp + "self_attn.k_proj.bias"]).view(T, N, nh, hd).transpose(1, 2)
-        v = linear(h, w[lp + "self_attn.v_proj.weight"], w[lp + "self_attn.v_proj.bias"]).view(T, N, nh, hd).transpose(1, 2)
-        a = sdpa_reference(q, k, v, hd ** -0.5).transpose(1, 2).reshape(T, N, nh * hd)
-        a = linear(a, w[lp + "self_attn.out_proj.weight"], w[lp + "self_attn.out_proj.bias"])
-        x = r + a
-        r = x
-        h = layer_norm(x, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], cfg.vis_ln_eps)
-        h = linear(h, w[lp + "mlp.fc1.weight"], w[lp + "mlp.fc1.bias"])
-        h = gelu_tanh(h)                                              # hidden_act = gelu_pytorch_tanh
-        h = linear(h, w[lp + "mlp.fc2.weight"], w[lp + "mlp.fc2.bias"])
-        x = r + h
-    return x
+    r = x
+    h = layer_norm(x, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], cfg.vis_ln_eps)
+    T, N, _ = h.shape
+    q = linear(h, w[lp + "self_attn.q_proj.weight"], w[lp + "self_attn.q_proj.bias"]).view(T, N, nh, hd).transpose(1, 2)
+    k = linear(h, w[lp + "self_attn.k_proj.weight"], w[lp + "self_attn.k_proj.bias"]).view(T, N, nh, hd).transpose(1, 2)
+    v = linear(h, w[lp + "self_attn.v_proj.weight"], w[lp + "self_attn.v_proj.bias"]).view(T, N, nh, hd).transpose(1, 2)
+    a = sdpa_reference(q, k, v, hd ** -0.5).transpose(1, 2).reshape(T, N, nh * hd)
+    a = linear(a, w[lp + "self_attn.out_proj.weight"], w[lp + "self_attn.out_proj.bias"])
+    x = r + a
+    r = x
+    h = layer_norm(x, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], cfg.vis_ln_eps)
+    h = linear(h, w[lp + "mlp.fc1.weight"], w[lp + "mlp.fc1.bias"])
+    h = gelu_tanh(h)                                                  # hidden_act = gelu_pytorch_tanh
+    h = linear(h, w[lp + "mlp.fc2.weight"], w[lp + "mlp.fc2.bias"])
+    return r + h
 
 
 # --------------------------------------------------------------------------------------------
@@ -247,30 +251,35 @@ def whisper_encoder_forward(mel: Tensor, w: W, cfg: OracleConfig, prefix: str = 
     x = gelu_erf(F.conv1d(x, w[p + "conv2.weight"], w[p + "conv2.bias"], stride=2, padding=1))
     x = x.permute(0, 2, 1)
     x = x + w[p + "embed_positions.weight"][None]
+    for i in range(cfg.aud_num_layers):
+        x = whisper_layer(x, w, cfg, f"{p}layers.{i}.")
+    return layer_norm(x, w[p + "layer_norm.weight"], w[p + "layer_norm.bias"], cfg.aud_ln_eps)
+
+
+def whisper_layer(x: Tensor, w: W, cfg: OracleConfig, lp: str) -> Tensor:
+    """one WhisperEncoderLayer on x:[C,N,d] — TP/models/whisper/modeling_whisper.py:279-333, 380-411."""
     nh = cfg.aud_num_heads
     hd = cfg.aud_d_model // nh
-    for i in range(cfg.aud_num_layers):
-        lp = f"{p}layers.{i}."
-        r = x
-        h = layer_norm(x, w[lp + "self_attn_layer_norm.weight"], w[lp + "self_attn_layer_norm.bias"], cfg.aud_ln_eps)
-        C, N, _ = h.shape
-        # q is scaled BEFORE the attention call (modeling_whisper.py:309), scaling=1.0 inside
-        q = (linear(h, w[lp + "self_attn.q_proj.weight"], w[lp + "self_attn.q_proj.bias"]) * (hd ** -0.5))
-        q = q.view(C, N, nh, hd).transpose(1, 2)
-        k = linear(h, w[lp + "self_attn.k_proj.weight"], None).view(C, N, nh, hd).transpose(1, 2)
-        v = linear(h, w[lp + "self_attn.v_proj.weight"], w[lp + "self_attn.v_proj.bias"]).view(C, N, nh, hd).transpose(1, 2)
-        a = sdpa_reference(q, k, v, 1.0).transpose(1, 2).reshape(C, N, nh * hd)
-        a = linear(a, w[lp + "self_attn.out_proj.weight"], w[lp + "self_attn.out_proj.bias"])
-        x = r + a
-        r = x
-        h = layer_norm(x, w[lp + "final_layer_norm.weight"], w[lp + "final_layer_norm.bias"], cfg.aud_ln_eps)
-        h = gelu_erf(linear(h, w[lp + "fc1.weight"], w[lp + "fc1.bias"]))
-        h = linear(h, w[lp + "fc2.weight"], w[lp + "fc2.bias"])
-        x = r + h
-        if x.dtype == torch.float16:                                  # modeling_whisper.py:409-411
-            cv = torch.finfo(x.dtype).max - 1000
-            x = torch.clamp(x, min=-cv, max=cv)
-    return layer_norm(x, w[p + "layer_norm.weight"], w[p + "layer_norm.bias"], cfg.aud_ln_eps)
+    r = x
+    h = layer_norm(x, w[lp + "self_attn_layer_norm.weight"], w[lp + "self_attn_layer_norm.bias"], cfg.aud_ln_eps)
+    C, N, _ = h.shape
+    # q is scaled BEFORE the attention call (modeling_whisper.py:309), scaling=1.0 inside
+    q = (linear(h, w[lp + "self_attn.q_proj.weight"], w[lp + "self_attn.q_proj.bias"]) * (hd ** -0.5))
+    q = q.view(C, N, nh, hd).transpose(1, 2)
+    k = linear(h, w[lp + "self_attn.k_proj.weight"], None).view(C, N, nh, hd).transpose(1, 2)
+    v = linear(h, w[lp + "self_attn.v_proj.weight"], w[lp + "self_attn.v_proj.bias"]).view(C, N, nh, hd).transpose(1, 2)
+    a = sdpa_reference(q, k, v, 1.0).transpose(1, 2).reshape(C, N, nh * hd)
+    a = linear(a, w[lp + "self_attn.out_proj.weight"], w[lp + "self_attn.out_proj.bias"])
+    x = r + a
+    r = x
+    h = layer_norm(x, w[lp + "final_layer_norm.weight"], w[lp + "final_layer_norm.bias"], cfg.aud_ln_eps)
+    h = gelu_erf(linear(h, w[lp + "fc1.weight"], w[lp + "fc1.bias"]))
+    h = linear(h, w[lp + "fc2.weight"], w[lp + "fc2.bias"])
+    x = r + h
+    if x.dtype == torch.float16:                                      # modeling_whisper.py:409-411
+        cv = torch.finfo(x.dtype).max - 1000
+        x = torch.clamp(x, min=-cv, max=cv)
+    return x
 
 
 # --------------------------------------------------------------------------------------------

@@ -11,12 +11,18 @@ production kernels (the persistent GEMM serves >= 192 tiles) and the fp32 CPU or
 the key masks make the restriction exact: every key outside the sample is masked on the GPU, so the text stream attends to exactly the
 keys the oracle holds.  bf16 (the bench dtype); the bound of every check is written where it is made.
 
-TWO oracle arms per check.  (1) fp32 oracle: the distance to exact arithmetic — dominated by bf16 rounding NOISE that the reference
-itself has (drift report; 5-sigma bounds from the measured noise growth).  (2) SAME-ROUNDING oracle: `oracle/vidi_oracle.py` is
-dtype-generic, so fed bf16 weights and inputs it rounds where the reference's eager modules round (every nn.Module output to bf16,
-norms in fp32 inside).  Against that arm the noise cancels and what is left is the kernels' own deviation (different summation
-order -> occasional one-ulp flips of an output, the documented folds: LayerNorm / softmax scale folded into weights, o_proj over
-the summed repeat_kv column blocks), so its bounds are several times tighter and a real kernel error of a few % at depth fails."""
+THREE views per block.
+(1) FREE-RUNNING vs the fp32 oracle: the distance to exact arithmetic after all the layers.  It is dominated by bf16 rounding NOISE that
+    the reference itself has; the bounds are 5-sigma bounds from the measured noise growth (a drift report, loose by nature).
+(2) FREE-RUNNING vs the SAME-ROUNDING oracle (`oracle/vidi_oracle.py` fed bf16 weights and inputs rounds where the reference's eager
+    modules round).  Measured in round 4: the noise does NOT cancel — the K/V caches agree to rms 7e-5 at layer 0 (occasional one-ulp
+    flips), 0.44 % after ONE stream update and 3.1 % at layer 41, the same as against fp32 (3.1 %): two bf16 evaluations that differ in
+    summation order / fold points decorrelate within a layer, as two chaotic trajectories do.  A tight free-running bound at depth is
+    therefore not a property any correct bf16 implementation has; this arm is reported with the fp32 arm's bounds.
+(3) TEACHER-FORCED, EVERY LAYER: the engine's diagnostic probe (`VidiEngine.probe`) keeps each layer's INPUT rows as the kernels saw them;
+    the same-rounding oracle evaluates that ONE layer on exactly that input and must reproduce the layer's output (next layer's probed
+    input, K/V cache rows) within a few bf16 ulps — at layer 41 as at layer 0.  This is the arm that catches a kernel error of a few %
+    at depth: nothing accumulates, so the bound is one layer's roundings."""
 import os
 
 import numpy as np
@@ -46,14 +52,29 @@ class LazyF32:
         return self.w[k].float() if k in self.w else default
 
 
-# Bounds of the same-rounding arm (fraction of the reference's spread, relative part); set from the measured use of each
-# (profiles/r4_tolerance_audit.jsonl), about 2x the observed maximum.
-SAME_ROUNDING = {
-    "siglip": (4e-2, 2e-2), "siglip_rms": 1.5e-2,
-    "whisper": (4e-2, 2e-2), "whisper_rms": 1.5e-2,
-    "kv": (2e-2, 1e-2), "kv_rms": 5e-3,
-    "hidden": (6e-2, 2e-2), "hidden_rms": 1.5e-2,
+# Teacher-forced per-layer bounds (fraction of the layer output's spread, relative part = bf16 ulps of the value), about 2x the
+# measured use (profiles/r4_tolerance_audit.jsonl); the worst layer of each block is what the audit records.
+TEACHER = {
+    "siglip": (3e-2, 2e-2), "whisper": (3e-2, 2e-2),          # one encoder layer: LN-fold / prescaled-q arms included
+    "kv": (1e-2, 1.2e-2),                                      # K/V rows of a layer = one GEMM of its probed input
+    "stream": (3e-2, 2e-2),                                    # one diagonal-stream update (o_proj fold, two norm pairs, GeGLU, down_proj)
+    "text": (4e-2, 2e-2),                                      # one decoder layer on the text rows (T2T + T2V + T2A + MLP)
 }
+
+
+def _per_layer(name, pairs, bound, failures):
+    """pairs: [(layer, got, ref)] -> audits the WORST layer through report() (one audit line per block), lists every layer's use"""
+    use = []
+    for li, got, ref in pairs:
+        g, r = got.float().cpu(), ref.float().cpu()
+        tol = bound[0] * float(r.std()) + bound[1] * r.abs()
+        use.append((float(((g - r).abs() / tol).max()), li, g, r))
+    print(f"[teacher-forced] {name}: tolerance use per layer " + " ".join(f"{li}:{u:.2f}" for u, li, _, _ in use))
+    u, li, g, r = max(use, key=lambda t: t[0])
+    try:
+        report(f"{name} (worst of {len(use)} layers: layer {li})", g, r, bound[0] * float(r.std()), bound[1])
+    except AssertionError as e:
+        failures.append(str(e))
 
 
 def _tower_cfg(**over):
@@ -77,22 +98,27 @@ def test_siglip_tower_real_dims_full_depth(fold, monkeypatch):
     T = 16                                                  # 11 664 rows: every projection of the tower takes the persistent GEMM
     g = torch.Generator().manual_seed(300)
     px = (torch.randn((T, 3, 384, 384), generator=g) * 0.5).clamp(-1, 1).to(dt)
+    sample = [0, 15]                                        # first / last frame of the chunk (first and last row tiles)
+    eng.probe = {"vis_frames": sample, "vis_x": []}
     got = eng.siglip_forward(px.cuda())
     assert got.shape == (T, 729, 1152)
-    sample = [0, 15]                                        # first / last frame of the chunk (first and last row tiles)
     ref = O.siglip_forward(px[sample].float(), w32, oracle_cfg(cfg))
     # 26 layers of bf16 residual-stream roundings against the fp32 oracle: 7 % of the spread + 4 % relative (1.06 M values; 0.7 used)
     report(f"siglip real dims x26 layers (fold={fold})", got[sample], ref, 7e-2 * ref.std().item(), 4e-2)
-    # same-rounding arm: the oracle in bf16 with the eager rounding points (HF modeling_siglip.py:310-357 executed in bf16)
+    # (2) free-running vs the same-rounding oracle: reported with the fp32 arm's bound (see the module docstring)
     w16 = {k: v.to(dt) for k, v in w32.items()}
-    ref16 = O.siglip_forward(px[sample], w16, oracle_cfg(cfg)).float()
-    report(f"siglip real dims x26 layers (fold={fold}) vs the bf16-rounding oracle", got[sample], ref16, SAME_ROUNDING["siglip"][0] * ref16.std().item(),
-           SAME_ROUNDING["siglip"][1])
-    rms = float((got[sample].float().cpu() - ref16).pow(2).mean().sqrt() / ref16.pow(2).mean().sqrt())
-    rms32 = float((got[sample].float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-    rms_ref = float((ref16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-    report(f"siglip x26 (fold={fold}) rms error / rms vs bf16 oracle [vs fp32: {rms32:.4f}; bf16 oracle vs fp32 oracle: {rms_ref:.4f}]",
-           torch.tensor([rms]), torch.tensor([0.0]), SAME_ROUNDING["siglip_rms"], 0.0)
+    ocfg = oracle_cfg(cfg)
+    ref16 = O.siglip_forward(px[sample], w16, ocfg).float()
+    report(f"siglip real dims x26 layers (fold={fold}) free-running vs the bf16-rounding oracle", got[sample], ref16, 7e-2 * ref16.std().item(), 4e-2)
+    # (3) teacher-forced: every layer on the input the kernels saw
+    xs = [t.cpu() for t in eng.probe["vis_x"]]
+    assert len(xs) == 27 and xs[0].shape == (2, 729, 1152)
+    failures = []
+    _per_layer(f"siglip layer, teacher-forced (fold={fold})",
+               [(i, xs[i + 1], O.siglip_layer(xs[i], w16, ocfg, f"model.mm_vis.vision_model.encoder.layers.{i}.")) for i in range(26)],
+               TEACHER["siglip"], failures)
+    assert torch.equal(xs[26].to(got.device), got[sample])
+    assert not failures, "\n".join(failures)
 
 
 def test_whisper_encoder_real_dims_full_depth():
@@ -104,21 +130,24 @@ def test_whisper_encoder_real_dims_full_depth():
     C = 8                                                   # 12 000 rows: the persistent GEMM on every projection
     g = torch.Generator().manual_seed(301)
     mel = (torch.randn((C, 128, 3000), generator=g) * 0.3).to(dt)
+    sample = [7]
+    eng.probe = {"aud_windows": sample, "aud_x": []}
     got = eng.whisper_forward(mel.cuda())
     assert got.shape == (C, 1500, 1280)
-    sample = [7]
     ref = O.whisper_encoder_forward(mel[sample].float(), w32, oracle_cfg(cfg))
     # 32 layers: 8 % of the spread + 4 % relative (1.9 M values; 0.7 used)
     report("whisper real dims x32 layers", got[sample], ref, 8e-2 * ref.std().item(), 4e-2)
     w16 = {k: v.to(dt) for k, v in w32.items()}
-    ref16 = O.whisper_encoder_forward(mel[sample], w16, oracle_cfg(cfg)).float()
-    report("whisper real dims x32 layers vs the bf16-rounding oracle", got[sample], ref16, SAME_ROUNDING["whisper"][0] * ref16.std().item(),
-           SAME_ROUNDING["whisper"][1])
-    rms = float((got[sample].float().cpu() - ref16).pow(2).mean().sqrt() / ref16.pow(2).mean().sqrt())
-    rms32 = float((got[sample].float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-    rms_ref = float((ref16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-    report(f"whisper x32 rms error / rms vs bf16 oracle [vs fp32: {rms32:.4f}; bf16 oracle vs fp32 oracle: {rms_ref:.4f}]",
-           torch.tensor([rms]), torch.tensor([0.0]), SAME_ROUNDING["whisper_rms"], 0.0)
+    ocfg = oracle_cfg(cfg)
+    ref16 = O.whisper_encoder_forward(mel[sample], w16, ocfg).float()
+    report("whisper real dims x32 layers free-running vs the bf16-rounding oracle", got[sample], ref16, 8e-2 * ref16.std().item(), 4e-2)
+    xs = [t.cpu() for t in eng.probe["aud_x"]]
+    assert len(xs) == 33 and xs[0].shape == (1, 1500, 1280)
+    failures = []
+    _per_layer("whisper layer, teacher-forced",
+               [(i, xs[i + 1], O.whisper_layer(xs[i], w16, ocfg, f"model.mm_aud.encoder.layers.{i}.")) for i in range(32)],
+               TEACHER["whisper"], failures)
+    assert not failures, "\n".join(failures)
 
 
 def _unpack_rows(mm, li, rows, nkv, hd):
@@ -156,8 +185,10 @@ def test_decoder_42_layers_real_dims_at_the_60_min_sizes():
     aud_rows = sorted(set([0, 1, 63, 64, 35967, 35968, 35998, 35999] + rs.randint(0, Na, 248).tolist()))
     imask = torch.zeros(Nv, dtype=torch.uint8, device="cuda"); imask[torch.as_tensor(img_rows, device="cuda")] = 1
     amask = torch.zeros(Na, dtype=torch.uint8, device="cuda"); amask[torch.as_tensor(aud_rows, device="cuda")] = 1
-    mm = eng.mm_stream_prefill(img, imask, aud, amask, pre_normalized=False)
     aud_start = _round_up(Nv, 64)
+    keys_all = img_rows + [aud_start + r for r in aud_rows]
+    eng.probe = {"stream_rows": torch.as_tensor(keys_all, dtype=torch.int64, device="cuda"), "stream_x": [], "text_h": []}
+    mm = eng.mm_stream_prefill(img, imask, aud, amask, pre_normalized=False)
     assert mm.ntile64 * 64 == 126080 and mm.img_mask is not None and mm.aud_mask is not None
 
     # ---- GPU: 39-token prompt + 4 teacher-forced decode steps over the 42-layer caches ----
@@ -222,7 +253,7 @@ def test_decoder_42_layers_real_dims_at_the_60_min_sizes():
         r = O.model_forward(e, torch.tensor([[L + i]]), tm, xi, mi, xa, ma, wl, ocfg, caches, L + i)
         check(f"42-layer teacher-forced decode step {i}", dec[i], r[0], 21e-2 * r.std().item(), 5e-2)
         check_rms(f"42-layer teacher-forced decode step {i}", dec[i], r[0], 5e-2)
-    # ---- same-rounding arm: the oracle again, in bf16 with the eager rounding points, on the same sampled keys ----
+    # ---- (3) teacher-forced, every one of the 42 layers, same-rounding (bf16) oracle --------------------------------------------
     class Lazy16:
         def __init__(self, w): self.w = w
         def __getitem__(self, k): return self.w[k]
@@ -230,28 +261,35 @@ def test_decoder_42_layers_real_dims_at_the_60_min_sizes():
         def get(self, k, default=None): return self.w.get(k, default)
 
     w16 = Lazy16(w_host)
-    caches16 = O.OracleCaches()
+    Lr = cfg.num_hidden_layers
+    sx = [t.cpu() for t in eng.probe["stream_x"]]                         # residual-stream rows at every layer's input (sampled keys)
+    th = [t.cpu() for t in eng.probe["text_h"][: Lr + 1]]                 # text residual stream: 42 layer inputs + after the last layer
+    assert len(sx) == Lr and sx[0].shape == (len(keys_all), H) and len(th) == Lr + 1 and th[0].shape == (L, H)
+    kv_pairs, st_pairs, gpu_kv = [], [], []
+    for li in range(Lr):
+        x_next, kref, vref = O.mm_stream_layer(sx[li][None], w16, f"model.layers.{li}.", ocfg)
+        kg, vg = _unpack_rows(mm, li, keys_all, nkv, hd)
+        gpu_kv.append((kg.to(dt)[None], vg.to(dt)[None]))
+        kv_pairs += [(li, kg, kref[0]), (li, vg, vref[0])]
+        if li + 1 < Lr:
+            st_pairs.append((li, sx[li + 1], x_next[0]))
+    _per_layer("stream K / V cache rows of a layer from its probed input, teacher-forced", kv_pairs, TEACHER["kv"], failures)
+    _per_layer("diagonal-stream update of a layer, teacher-forced", st_pairs, TEACHER["stream"], failures)
+    # text rows: every layer evaluated on the text residual the kernels saw, attending to the K/V rows the kernels cached (all sampled keys
+    # are the only unmasked ones), with the oracle's own text K/V cache growing layer by layer
+    tc = O.OracleCaches()
+    tc.image = [(k[:, : len(img_rows)], v[:, : len(img_rows)]) for k, v in gpu_kv]
+    tc.audio = [(k[:, len(img_rows):], v[:, len(img_rows):]) for k, v in gpu_kv]
+    cos, sin = O.rope_cos_sin(opos, cfg.head_dim, cfg.rope_theta, dt)
+    dummy_i, dummy_a = torch.zeros((1, len(img_rows), H), dtype=dt), torch.zeros((1, len(aud_rows), H), dtype=dt)
+    tx_pairs = []
+    for li in range(Lr):
+        h_next, _, _ = O.decoder_layer(th[li][None], cos, sin, am, dummy_i, mi, dummy_a, ma, w16, ocfg, tc, li, 0)
+        tx_pairs.append((li, th[li + 1], h_next[0]))
+    _per_layer("decoder layer on the 39 text rows (T2T + T2V + T2A + MLP), teacher-forced", tx_pairs, TEACHER["text"], failures)
     emb16 = O.embed_text(idl, am, w16)
-    href16 = O.model_forward(emb16, opos, am, xi.to(dt), mi, xa.to(dt), ma, w16, ocfg, caches16, 0).float()
-    kvb, kvr = SAME_ROUNDING["kv"]
-    for li in (0, 1, 20, 41):
-        for name, rows, start, cache, c32 in (("image", img_rows, 0, caches16.image, caches.image), ("audio", aud_rows, aud_start, caches16.audio, caches.audio)):
-            kg, vg = _unpack_rows(mm, li, [start + r for r in rows], nkv, hd)
-            kref, vref = cache[li][0].float(), cache[li][1].float()
-            check(f"42-layer stream vs bf16-rounding oracle: layer {li} {name} K rows", kg, kref[0], kvb * kref.std().item(), kvr)
-            check(f"42-layer stream vs bf16-rounding oracle: layer {li} {name} V rows", vg, vref[0], kvb * vref.std().item(), kvr)
-            check_rms(f"42-layer stream vs bf16-rounding oracle: layer {li} {name} K rows", kg, kref[0], SAME_ROUNDING["kv_rms"])
-            # how far the two oracle arms are from each other (the noise the fp32 comparison above has to allow for)
-            d = float((kref[0] - c32[li][0][0].float()).abs().max() / c32[li][0].float().std())
-            print(f"[drift] layer {li} {name}: bf16-rounding oracle vs fp32 oracle, worst K element = {100 * d:.2f} % of the spread")
-    hb, hr = SAME_ROUNDING["hidden"]
-    check("42-layer text prefill hidden (39 tokens) vs bf16-rounding oracle", hn, href16[0], hb * href16.std().item(), hr)
-    check_rms("42-layer text prefill hidden (39 tokens) vs bf16-rounding oracle", hn, href16[0], SAME_ROUNDING["hidden_rms"])
-    tm = am
-    for i, t in enumerate(forced):
-        e = torch.nn.functional.embedding(torch.tensor([[t]]), w16["model.embed_tokens.weight"])
-        tm = torch.cat([tm, torch.ones(1, 1, dtype=torch.bool)], dim=1)
-        r = O.model_forward(e, torch.tensor([[L + i]]), tm, xi.to(dt), mi, xa.to(dt), ma, w16, ocfg, caches16, L + i).float()
-        check(f"42-layer teacher-forced decode step {i} vs bf16-rounding oracle", dec[i], r[0], hb * r.std().item(), hr)
-        check_rms(f"42-layer teacher-forced decode step {i} vs bf16-rounding oracle", dec[i], r[0], SAME_ROUNDING["hidden_rms"])
+    nrm = torch.tensor(cfg.hidden_size ** 0.5, dtype=dt)
+    check("text embeddings x normalizer (layer-0 input)", th[0], (emb16 * nrm)[0], 1e-3 * float(emb16.float().std()) * float(nrm), 8e-3)
+    hfin = O.llm_rmsnorm(th[Lr][None], w16["model.norm.weight"], ocfg)
+    check("final norm of the probed residual, teacher-forced", hn, hfin[0], 1e-2 * hfin.float().std().item(), 1.2e-2)
     assert not failures, "\n".join(failures)

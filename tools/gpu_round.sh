@@ -32,19 +32,14 @@ mfma)
   (cd /tmp && timeout 1200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- $CMD > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err); echo "mfma rc=$?"
   python tools/mfma_busy_from_pmc.py "$(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1)" $OUT/mfma_busy.json
   rm -rf $OUT/pmc_mfma ;;
-gain)
-  # q_proj gain sweep at the 5-min config: how much the first-token logits depend on the video (bench.py verify leg), and the verify errors
-  for gn in 1 2 4; do
-    timeout 600 python bench.py --frames 300 --steps 1 --warmup 1 --no-cpu-baseline --no-preproc --no-kernel-timer --decode-steps 4 --attn-gain $gn > $OUT/bench_gain$gn.json 2> $OUT/bench_gain$gn.err; echo "gain $gn rc=$?"
-    python - <<PY
-import json
-try:
-    d = json.loads([l for l in open("$OUT/bench_gain$gn.json") if l.startswith("{")][-1])
-    print("gain", $gn, "first_token", d["first_token"], "value", round(d["value"]), json.dumps(d["verify"]))
-except Exception as e:
-    print("gain $gn: no result", e); print(open("$OUT/bench_gain$gn.err").read()[-1500:])
-PY
-  done ;;
+verify300)
+  # the bench's in-run verification leg on the 5-min config (quick)
+  timeout 600 python bench.py --frames 300 --steps 1 --warmup 1 --no-cpu-baseline --no-preproc --no-kernel-timer --decode-steps 4 > $OUT/bench_verify300.json 2> $OUT/bench_verify300.err; echo "verify300 rc=$?"
+  python tools/show_bench.py $OUT/bench_verify300.json 2>/dev/null | grep -E "value|first_token|verify" || tail -5 $OUT/bench_verify300.err ;;
+epi2)
+  bash tools/lab/run_epi2_ab.sh 2>&1 | tail -60 ;;
+clock)
+  bash tools/lab/run_clock.sh 2>&1 | tail -70 ;;
 dist8)
   # eight ranks sharing the one GPU (gloo transport): the BASELINE 8-way partition of bench.py end to end on a 10-minute video, and the same video on one rank
   VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --frames 600 --steps 1 --warmup 1 --no-preproc --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8.json 2> $OUT/bench_dist8.err; echo "dist8 rc=$?"

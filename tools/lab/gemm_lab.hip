@@ -93,6 +93,17 @@ static std::vector<Variant> variants() {
         {"w4p_nostore", W4(MODE_PLAIN, true, 0, LabNoStore), MODE_PLAIN, false, 0, 4},
         {"late_stamps", LATE(MODE_PLAIN, LabStamps), MODE_PLAIN, true, 0, 4},
         {"w4p_stamps", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 0, 4},
+        // round 4: tile order x effective clock (cycle stamps / wall time) — does fabric traffic cost clock?  group_m = 1: the 32 CUs of an
+        // XCD share ONE X m-panel and walk n (33 operand slabs per 32 tiles instead of 12); group_m = 8 / 16: fewer, taller groups
+        {"w4p_stamps_g1", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 1, 1},
+        {"w4p_stamps_g2", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 1, 2},
+        {"w4p_stamps_g4", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 1, 4},
+        {"w4p_stamps_g8", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 1, 8},
+        {"w4p_stamps_g16", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 1, 16},
+        {"w4p_stamps_o0g4", W4(MODE_PLAIN, true, 0, LabStamps), MODE_PLAIN, true, 0, 4},
+        {"w4p_g1", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 1},
+        {"w4p_g2", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 2},
+        {"w4p_g16", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 16},
         {"late_br", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 1},
         {"w4p_br", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 0, 4, 1},
         {"late_bt", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 2},
@@ -133,6 +144,8 @@ int main(int argc, char** argv) {
     else if (set == "geglu") want = {"late_geglu", "w4p_geglu"};
     else if (set == "epi") want = {"late", "w4p", "w4pc", "late_br", "w4p_br", "late_bt", "w4p_bt", "late_geglu", "w4p_geglu"};
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
+    else if (set == "clock") want = {"w4p_stamps_g1", "w4p_stamps_g2", "w4p_stamps_g4", "w4p_stamps_g8", "w4p_stamps_g16", "w4p_stamps_o0g4"};
+    else if (set == "orders") want = {"w4p_g1", "w4p_g2", "w4p_o1", "w4p_o1_g8", "w4p_g16", "w4p"};
     else if (set == "stamps_epi") want = {"w4p_stamps", "w4p_br_stamps", "w4p_brs_stamps", "w4p_bt_stamps"};
     else if (set == "split") want = {"w4p", "w4p_br", "t128x128", "t128x256", "late128x256", "t128x128_br", "late128x256_br"};
     else if (set == "store") want = {};
@@ -224,8 +237,10 @@ int main(int argc, char** argv) {
                     ++n;
                 }
                 // late: per block (= per tile) setup / K loop / staging / copy-out; w4p: per block totals over its tiles of wait+frag reads / K loop / next-head issue / epilogue
-                if (n) printf("{\"shape\": \"%s\", \"variant\": \"%s\", \"blocks\": %d, \"cycles_0\": %.0f, \"cycles_1\": %.0f, \"cycles_2\": %.0f, \"cycles_3\": %.0f, \"k_iters\": %d, \"tiles\": %d}\n",
-                              sh.name, v->name, n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, sh.K / 64, ((sh.M + 255) / 256) * ((sh.N + 255) / 256));
+                // effective shader clock of the launch = a block's stamped cycles (its whole life in the persistent kernel) / wall time
+                if (n) printf("{\"shape\": \"%s\", \"variant\": \"%s\", \"blocks\": %d, \"cycles_0\": %.0f, \"cycles_1\": %.0f, \"cycles_2\": %.0f, \"cycles_3\": %.0f, \"k_iters\": %d, \"tiles\": %d, \"group_m\": %d, \"order\": %d, \"eff_clock_GHz\": %.3f}\n",
+                              sh.name, v->name, n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, sh.K / 64, ((sh.M + 255) / 256) * ((sh.N + 255) / 256), v->group_m, v->order,
+                              wn.find("w4") != std::string::npos ? (a[0] + a[1] + a[2] + a[3]) / n / (ms * 1e6) : 0.0);
             }
             fflush(stdout);
         }

@@ -30,6 +30,16 @@
 #ifndef VIDI_W4_RES_DEPTH
 #define VIDI_W4_RES_DEPTH 3
 #endif
+// Epilogue form 2 (row-major outputs: MODE_PLAIN without the head-major layout, MODE_GEGLU): the tile's stores, residual loads and
+// partial-sum stores go through per-tile buffer descriptors.  A lane's byte offset inside the tile is tile-invariant up to the row
+// step, rows past M fall outside the descriptor's extent and columns past N get an out-of-range lane offset, so the hardware's range
+// check replaces the per-store 64-bit address arithmetic (v_mad_i64 / v_lshl_add_u64), the row / column predicates and their exec-mask
+// branches (about 650 of the 3 265 instructions of a bias + residual + statistics tile, 350 of a plain one); the statistics' eight row
+// reductions of a strip run as one interleaved block (row16_sum8: no hazard s_nops).  The row offset is added on the VALU into the
+// VGPR offset: the SGPR offset of a buffer instruction is NOT part of the range check.  Bit-identical results.
+#ifndef VIDI_W4_EPI2
+#define VIDI_W4_EPI2 0
+#endif
 
 struct W4Geom {
     static constexpr int BN = 256, BM = 256, BK = 64, NT = 256, TN = 8, TM = 8, ROWB = 128;
@@ -331,6 +341,28 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             const int which = nc / hdim, nh = nc - which * hdim, hh = nh / p.hm_hd;
             hm_col = ((size_t)which * (p.M / p.hm_seq) * p.hm_heads + hh) * p.hm_seq * p.hm_hd + (nh - hh * p.hm_hd);
         }
+        // epilogue form 2: per-tile descriptors + tile-invariant lane offsets (see VIDI_W4_EPI2 above)
+        constexpr bool bufio = (VIDI_W4_EPI2 != 0) && (GLU || (MODE == MODE_PLAIN && !EPI::heads));
+        constexpr bool stats_on = (MODE == MODE_PLAIN) && EPI::stats && (EPI::res != 0);
+        __amdgpu_buffer_rsrc_t srdY, srdR, srdS;
+        unsigned vY = 0, vR = 0, vS = 0;
+        (void)srdY; (void)srdR; (void)srdS; (void)vY; (void)vR; (void)vS;
+        if constexpr (bufio) {
+            const unsigned rows_here = (unsigned)min(p.M - em0, 256);
+            const bool col_ok = n < Nout;
+            srdY = rsrc_of(Yb + (size_t)em0 * p.ldy, (unsigned long long)rows_here * (unsigned)p.ldy * 2ull);
+            vY = (col_ok && !LAB::no_store) ? (unsigned)((wm * 128 + rr) * p.ldy + n) * 2u : 0x80000000u;
+            if constexpr (has_res && !wrap) {
+                // (a lane past the last column reads zeros: with a zero bias and zero accumulators there it adds nothing to the row sums)
+                srdR = rsrc_of(Rb + (size_t)em0 * p.ldr, (unsigned long long)rows_here * (unsigned)p.ldr * 2ull);
+                vR = col_ok ? (unsigned)((wm * 128 + rr) * p.ldr + n) * 2u : 0x80000000u;
+            }
+            if constexpr (stats_on) {
+                const unsigned strips = (unsigned)((Nout + 127) >> 7);
+                srdS = rsrc_of(p.stat_part + (size_t)em0 * strips * 2, (unsigned long long)rows_here * strips * 8ull);
+                vS = (cc == 0 && no0 < Nout) ? ((unsigned)(wm * 128 + rr) * strips + (unsigned)(no0 >> 7)) * 8u : 0x80000000u;
+            }
+        }
         // ---- registers -> scratch (lane: row l15, 4 consecutive columns per 16-column tile) ----
         auto stage = [&](auto bt) {
             constexpr int b = decltype(bt)::value;
@@ -423,10 +455,16 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         auto load_res = [&](auto bt) {
             constexpr int b = decltype(bt)::value;
             if constexpr (has_res && b < TM) {
+                if constexpr (bufio && !wrap) {
 #pragma unroll
-                for (int j = 0; j < NRD; ++j) {
-                    const int mc = min(em0 + wm * 128 + b * 16 + j * RPI + rr, p.M - 1), mr = wrap ? mc % p.rmod : mc;
-                    res[b % RD][j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
+                    for (int j = 0; j < NRD; ++j)
+                        res[b % RD][j] = __builtin_amdgcn_raw_buffer_load_b128(srdR, vR + (unsigned)((b * 16 + j * RPI) * p.ldr) * 2u, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NRD; ++j) {
+                        const int mc = min(em0 + wm * 128 + b * 16 + j * RPI + rr, p.M - 1), mr = wrap ? mc % p.rmod : mc;
+                        res[b % RD][j] = *(const u32x4*)(Rb + (size_t)mr * p.ldr + min(n, Nout - 8));
+                    }
                 }
             }
         };
@@ -464,6 +502,54 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
                         val[j0 + jj] = pack8<T>(x);
                     }
                 }
+            }
+            if constexpr (bufio) {
+                // form 2: no per-store predicate (rows past M / columns past N are out of the descriptors' range)
+                if constexpr (emit_stats) {
+                    float sv[2 * NRD];
+                    u32x4 outv[NRD];
+#pragma unroll
+                    for (int j = 0; j < NRD; ++j) {
+                        float x[8], r[8];
+                        unpack8<T>(val[j], x);
+                        unpack8<T>(res[b % RD][j], r);
+                        f32x2_t sa = {0.f, 0.f}, sq = {0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2_t y = f32x2_t{x[e], x[e + 1]} + f32x2_t{r[e], r[e + 1]};
+                            x[e] = y[0]; x[e + 1] = y[1];
+                            sa += y;
+                            sq = __builtin_elementwise_fma(y, y, sq);
+                        }
+                        sv[2 * j] = sa[0] + sa[1]; sv[2 * j + 1] = sq[0] + sq[1];
+                        outv[j] = pack8<T>(x);
+                    }
+                    static_assert(NRD == 4, "row16_sum8 takes the strip's four rows");
+                    row16_sum8(sv);
+#pragma unroll
+                    for (int j = 0; j < NRD; ++j) {
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        const unsigned rowoff = (unsigned)(b * 16 + j * RPI);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(sv[2 * j]), __float_as_uint(sv[2 * j + 1])}, srdS,
+                                                              vS + rowoff * (unsigned)((Nout + 127) >> 7) * 8u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(outv[j], srdY, vY + rowoff * (unsigned)p.ldy * 2u, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NRD; ++j) {
+                        u32x4 v = val[j];
+                        if constexpr (has_res) {
+                            float x[8], r[8];
+                            unpack8<T>(v, x);
+                            unpack8<T>(res[b % RD][j], r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] += r[e];          // x is already T-rounded; the sum rounds on pack
+                            v = pack8<T>(x);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(v, srdY, vY + (unsigned)((b * 16 + j * RPI) * p.ldy) * 2u, 0, 0);
+                    }
+                }
+                return;
             }
 #pragma unroll
             for (int j = 0; j < NRD; ++j) {

@@ -115,6 +115,14 @@ class VidiEngine:
         self.normalizer = 1.0 if self.mistral else float(torch.tensor(cfg.hidden_size ** 0.5, dtype=dtype).float())
         self.glu_act = hip.ACT_SILU if self.mistral else hip.ACT_GELU_TANH
         # towers: LayerNorm folded into the q/k/v and fc1 projections (default) or run as its own row pass (VIDI_LN_FOLD=0: the A/B arm)
+        # Diagnostic probe (None in production: one attribute test per layer).  A dict asks the layer loops to keep copies of their
+        # per-layer INPUT rows, so a checker can evaluate every layer on exactly the input the kernels saw ("teacher-forced" parity:
+        # one layer's rounding per comparison instead of the drift of all the layers before it):
+        #   {"vis_frames": [frame idx], "vis_x": []}   siglip_forward: rows of those frames before each layer + after the last
+        #   {"aud_windows": [window idx], "aud_x": []} whisper_forward: likewise (before the final LayerNorm)
+        #   {"stream_rows": LongTensor, "stream_x": []}  mm_stream_prefill: residual-stream rows at every layer's input
+        #   {"text_h": []}                              text_forward: the text residual stream at every layer's input + after the last
+        self.probe = None
         self.ln_fold = os.environ.get("VIDI_LN_FOLD", "1") != "0"
         # towers: q | k | v as one row-major buffer + the transpose-read attention kernel (VIDI_ATTN_RM=1) or Q|K row-major + V transposed by
         # the projection's epilogue + the Vt attention kernel (0)
@@ -411,10 +419,17 @@ class VidiEngine:
                 hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
             if fold:
                 hip.row_stats(x, ws["st"], cfg.vis_ln_eps)
+            pr = self.probe if (self.probe is not None and "vis_frames" in self.probe) else None
+            grab = (lambda: pr["vis_x"].append(torch.stack([x[(f - c0) * N: (f - c0 + 1) * N].clone() for f in pr["vis_frames"] if c0 <= f < c1]))) \
+                if pr is not None and any(c0 <= f < c1 for f in pr["vis_frames"]) else None
             for L in V["layers"]:
+                if grab is not None:
+                    grab()
                 self._tower_layer(x, L, ws, cfg.vis_ln_eps, hip.ACT_GELU_TANH,
                                   dict(B=Tc, N=N, Npad=Npad, H=nh, D=hd, koff=Hv, scale=0.0 if getattr(self, "vis_prescaled", False) else hd ** -0.5),
                                   dict(vstart=2 * Hv, hd=hd, seq=N, seqpad=Npad, nheads=nh))
+            if grab is not None:
+                grab()
         return out.view(T, N, Hv)
 
     # -----------------------------------------------------------------------------------------
@@ -519,7 +534,12 @@ class VidiEngine:
                      M=N, K=3 * Da, ldx=2 * Da, batch=Cc, bsX=(Lm + 1) * Da, bsY=N * Da, bsR=0)
             if fold:
                 hip.row_stats(x, ws["st"], cfg.aud_ln_eps)
+            pr = self.probe if (self.probe is not None and "aud_windows" in self.probe) else None
+            grab = (lambda: pr["aud_x"].append(torch.stack([x[(c - c0) * N: (c - c0 + 1) * N].clone() for c in pr["aud_windows"] if c0 <= c < c1]))) \
+                if pr is not None and any(c0 <= c < c1 for c in pr["aud_windows"]) else None
             for L in A["layers"]:
+                if grab is not None:
+                    grab()
                 self._tower_layer(x, L, ws, cfg.aud_ln_eps, hip.ACT_GELU_ERF,
                                   dict(B=Cc, N=N, Npad=Npad, H=nh, D=hd, koff=Da, scale=hd ** -0.5),
                                   dict(vstart=2 * Da, hd=hd, seq=N, seqpad=Npad, nheads=nh))
@@ -528,6 +548,8 @@ class VidiEngine:
                     x.clamp_(min=-cv, max=cv)
                     if fold:                                        # the clamp may have changed rows: their statistics again
                         hip.row_stats(x, ws["st"], cfg.aud_ln_eps)
+            if grab is not None:
+                grab()
             hip.norm(hip.NORM_LAYER, x, A["lnw"], eps=cfg.aud_ln_eps, bias=A["lnb"], out=x)
         return out.view(C, N, Da)
 
@@ -610,7 +632,10 @@ class VidiEngine:
         gt = self._buf("mm_g", (ntot, cfg.intermediate_size))
         eps = cfg.rms_norm_eps
         fused = self.stream_norm2 and not self.mistral
+        pr = self.probe if (self.probe is not None and "stream_rows" in self.probe) else None
         for li, L in enumerate(self.layers if ntot > 0 else []):
+            if pr is not None:
+                pr["stream_x"].append(X.index_select(0, pr["stream_rows"]))
             if not fused or li == 0:                                                                 # fused: produced by the previous layer's second pass
                 hip.norm(self.norm_mode, X, L["ln_in"], eps=eps, out=hbuf)                           # gemma.py:183-184 / mistral.py:204-205
             hip.gemm_kv_cache(hbuf, L["wkv"], st.kc[li], st.vtc[li], vrow, kvd=kvd, hd=hd, ntile64=ntile, tok0=0)   # :61-63
@@ -861,7 +886,10 @@ class VidiEngine:
         qkv_ready = False
         nL = len(self.layers)
         final_out = None
+        prt = self.probe if (self.probe is not None and "text_h" in self.probe) else None
         for li, L in enumerate(self.layers):
+            if prt is not None:
+                prt["text_h"].append(hidden.clone())
             if not qkv_ready:
                 if not (fused and li > 0):                                                           # fused: produced by the previous layer's FFN side
                     hip.norm(self.norm_mode, hidden, L["ln_in"], eps=eps, out=hn)                   # gemma.py:162 / mistral.py:187
@@ -976,6 +1004,8 @@ class VidiEngine:
                 hip.resid_norm2(dn, None, None, hidden, L["ln_post_ffn"], self.final_norm, hidden, final_out, eps=eps)
         if not dyn:
             ts.past_len = p0 + Lq
+        if prt is not None:
+            prt["text_h"].append(hidden.clone())                    # the residual stream after the last layer (before the final norm)
         if final_out is not None:
             return final_out
         return hip.norm(self.norm_mode, hidden, self.final_norm, eps=eps)                               # gemma.py:411 / mistral.py:423
