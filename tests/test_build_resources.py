@@ -88,3 +88,59 @@ def test_encoder_attention_occupancy():
         assert res["LDS Size"] <= 65536, (name, res)
         seen += 1
     assert seen == 10                                    # 4 head dims x 2 dtypes + the prescaled-Q form of d = 72 x 2 dtypes
+
+
+def test_transpose_read_destinations_untouched_until_the_wait():
+    """vidi_amd/csrc/attn_self_rm.hip issues its V transpose reads (`ds_read_b64_tr_b16`) as inline asm and waits for them with an explicit
+    `s_waitcnt lgkmcnt(0)` (tr_wait): the compiler believes the destinations are written at the asm statement.  The built object is
+    disassembled and every instruction between a transpose read and the next lgkmcnt(0) wait is checked: none may name a pending
+    destination register (a copy or spill there would move stale data without any functional symptom in most runs)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from vidi_amd.build import OBJ, build
+    build(verbose=False)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    with tempfile.TemporaryDirectory() as d:
+        o = os.path.join(d, "attn_self_rm.o")
+        shutil.copy(os.path.join(OBJ, "attn_self_rm.o"), o)
+        subprocess.run([objdump, "--offloading", o], check=True, capture_output=True, cwd=d)
+        co = [f for f in os.listdir(d) if "gfx950" in f]
+        assert co, os.listdir(d)
+        dis = subprocess.run([objdump, "-d", os.path.join(d, co[0])], check=True, capture_output=True, text=True).stdout
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+    def regs(tok):
+        out = set()
+        for m in reg.finditer(tok):
+            out.update([int(m.group(1))] if m.group(1) is not None else range(int(m.group(2)), int(m.group(3)) + 1))
+        return out
+
+    pending, kern, reads, windows, viol = set(), None, 0, 0, []
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            assert not pending, f"{kern}: ends with transpose reads in flight"
+            kern = m.group(1)
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//", line)
+        if not m:
+            continue
+        op, args = m.group(1), m.group(2)
+        if op == "ds_read_b64_tr_b16":
+            parts = args.split(",")
+            if regs(",".join(parts[1:])) & pending:
+                viol.append((kern, line.strip()))
+            windows += not pending
+            pending |= regs(parts[0])
+            reads += 1
+        elif pending:
+            if op == "s_waitcnt" and "lgkmcnt(0)" in args:
+                pending = set()
+            elif regs(args) & pending:
+                viol.append((kern, line.strip()))
+    assert reads >= 100 and windows >= 10, (reads, windows)            # the asm form is the one that was built
+    assert not viol, viol[:5]

@@ -363,6 +363,12 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
              "decode_attn": "VIDI_DECODE_ATTN", "cross_dual": "VIDI_CROSS_DUAL", "decode_norm_gemv": "VIDI_DECODE_NORM_GEMV",
              "decode_tail": "VIDI_DECODE_TAIL", "patch_loader": "VIDI_PATCH_LOADER", "attn_prescale": "VIDI_ATTN_PRESCALE"}
     assert all(getattr(eng, n) for n in names), "the fixture engine runs the default arms"
+    # third arm: everything default EXCEPT the prescaled-q attention (softmax scale folded into the q projection, running maximum rounded
+    # to the model dtype): its distance to the all-off arm is reported beside the default arm's, so the share of the margin that the
+    # prescale form consumes is visible in the audit (the bounds that predate it are kept for this arm)
+    monkeypatch.setenv("VIDI_ATTN_PRESCALE", "0")
+    eng_np, _ = make(cfg, dt)
+    assert not eng_np.attn_prescale and eng_np.ln_fold
     for env in names.values():
         monkeypatch.setenv(env, "0")
     eng0, _ = make(cfg, dt)
@@ -373,7 +379,7 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
     ids = torch.tensor([[2, 21, 22, 23, 24, 25, 26]], dtype=torch.int64).cuda()
     forced = [31, 7, 19, 44, 5]
     runs = []
-    for e in (eng, eng0):
+    for e in (eng, eng0, eng_np):
         fi, mi = e.encode_video_images(px.cuda())
         fa, ma = e.encode_video_audios(mel.cuda(), 100)
         mm = e.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=False)
@@ -387,7 +393,7 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
             h = e.text_forward(e.embed_tokens(torch.tensor([t], device="cuda")), posn, ts, mm, Lq=1)
             hs.append(h.float().cpu())
         runs.append((mm.kc.float().cpu(), mm.vtc.float().cpu(), torch.cat(hs)))
-    a, b = runs
+    a, b, c = runs
     # each arm is held to `tol` against the oracle elsewhere in this file; against each other their errors add: twice those bounds
     def tol2(x, tight):
         at, rt = tol(dt, x.std().item(), tight=tight)
@@ -398,3 +404,8 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
     report("switch arms: stream K caches", a[0], b[0], *kv_tol(b[0]))
     report("switch arms: stream V caches", a[1], b[1], *kv_tol(b[1]))
     report("switch arms: prefill + decode hidden states", a[2], b[2], *tol2(b[2], False))
+    # the arm without the prescaled-q form, at the bounds that predate it (6 % of the spread for the caches)
+    kv_old = lambda x: (6e-2 * x.std().item(), 4e-2) if dt == torch.bfloat16 else (1.2e-2 * x.std().item(), 8e-3)     # noqa: E731
+    report("switch arms [prescale off vs all off]: stream K caches", c[0], b[0], *kv_old(b[0]))
+    report("switch arms [prescale off vs all off]: stream V caches", c[1], b[1], *kv_old(b[1]))
+    report("switch arms [prescale off vs all off]: prefill + decode hidden states", c[2], b[2], *tol2(b[2], False))

@@ -53,6 +53,12 @@ template <int D> constexpr int attn_rm_qs() { return D == 72 ? VIDI_ATTN_RM_QS72
                                        // front of the first transpose read of every tile: the prefetch was waited for one instruction after its
                                        // issue.  As asm the reads carry no memory operand; their completion is waited for explicitly (tr_wait).
 // one 64-bit LDS transpose read; OFF is an instruction immediate
+// INVARIANT (not visible to the compiler): the read completes ASYNCHRONOUSLY, but to the compiler `dst` is written at the asm statement.
+// Between a VIDI_TR_READ and the tr_wait that follows it nothing may read, copy or spill `dst` — a v_mov / scratch store of it there
+// would move stale data, silently.  At 252-253 VGPRs the register allocator has no reason to, but nothing in the source forbids it:
+// tests/test_build_resources.py::test_transpose_read_destinations_untouched_until_the_wait disassembles the built object and fails if
+// any instruction between a transpose read and the next `s_waitcnt lgkmcnt(0)` names one of the pending destination registers (knob
+// variants and compiler upgrades included); VIDI_ATTN_RM_TRASM=0 (the builtin, compiler-tracked) stays available as the reference arm.
 #define VIDI_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
 // every LDS read issued so far has returned; the 12 raw halves pass through so that their consumers are ordered behind the wait
 template <int N>
