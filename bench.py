@@ -39,7 +39,7 @@ ATTN_GAIN = 1.0
 # |err| <= atol x spread + rtol x |ref| — the bounds of tests/test_gpu_full_depth.py.
 VERIFY_BOUND_EMBEDS = 0.12
 VERIFY_KV_TOL = (1e-2, 1.2e-2)
-VERIFY_STREAM_TOL = (3e-2, 2e-2)
+VERIFY_STREAM_TOL = (4e-2, 2.5e-2)
 
 
 def parse():

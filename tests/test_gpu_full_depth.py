@@ -54,25 +54,33 @@ class LazyF32:
 
 # Teacher-forced per-layer bounds (fraction of the layer output's spread, relative part = bf16 ulps of the value), about 2x the
 # measured use (profiles/r4_tolerance_audit.jsonl); the worst layer of each block is what the audit records.
+# Measured use with these bounds: siglip 0.52 (all arms), whisper 0.57, kv 0.52, stream 0.52, text 0.54.  Worst single element of a layer's
+# output: 3 % of its spread (towers), 1-2.6 % (K / V rows: one-ulp flips), 4-5 % (a full stream / text layer: ~6 rounding points) — against
+# 12-17 % for the free-running comparison at layer 41.  RMS error of a layer's output (third entry): the statistic that a systematic
+# error of a fraction of a per cent would move.
 TEACHER = {
-    "siglip": (3e-2, 2e-2), "whisper": (3e-2, 2e-2),          # one encoder layer: LN-fold / prescaled-q arms included
-    "kv": (1e-2, 1.2e-2),                                      # K/V rows of a layer = one GEMM of its probed input
-    "stream": (3e-2, 2e-2),                                    # one diagonal-stream update (o_proj fold, two norm pairs, GeGLU, down_proj)
-    "text": (4e-2, 2e-2),                                      # one decoder layer on the text rows (T2T + T2V + T2A + MLP)
+    "siglip": (5e-2, 3e-2, 2e-2), "whisper": (5e-2, 3e-2, 2e-2),     # one encoder layer: LN-fold / prescaled-q arms included
+    "kv": (1e-2, 1.2e-2, 5e-3),                                       # K/V rows of a layer = one GEMM of its probed input
+    "stream": (4e-2, 2.5e-2, 2e-2),                                   # one diagonal-stream update (o_proj fold, two norm pairs, GeGLU, down_proj)
+    "text": (6e-2, 3e-2, 3e-2),                                       # one decoder layer on the text rows (T2T + T2V + T2A + MLP)
 }
 
 
 def _per_layer(name, pairs, bound, failures):
     """pairs: [(layer, got, ref)] -> audits the WORST layer through report() (one audit line per block), lists every layer's use"""
-    use = []
+    use, rms = [], []
     for li, got, ref in pairs:
         g, r = got.float().cpu(), ref.float().cpu()
         tol = bound[0] * float(r.std()) + bound[1] * r.abs()
         use.append((float(((g - r).abs() / tol).max()), li, g, r))
+        rms.append((float((g - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()), li))
     print(f"[teacher-forced] {name}: tolerance use per layer " + " ".join(f"{li}:{u:.2f}" for u, li, _, _ in use))
+    print(f"[teacher-forced] {name}: rms error / rms per layer (%) " + " ".join(f"{li}:{100 * e:.3f}" for e, li in rms))
     u, li, g, r = max(use, key=lambda t: t[0])
     try:
         report(f"{name} (worst of {len(use)} layers: layer {li})", g, r, bound[0] * float(r.std()), bound[1])
+        e, lr = max(rms)
+        report(f"{name} [rms error / rms, worst layer {lr}]", torch.tensor([e]), torch.tensor([0.0]), bound[2], 0.0)
     except AssertionError as e:
         failures.append(str(e))
 

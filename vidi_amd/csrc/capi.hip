@@ -23,6 +23,9 @@ static GemmParams base_params(const void* X, const void* W, const void* bias, vo
         if (ord < 0) { const char* e = getenv("VIDI_GEMM_ORDER"); ord = e ? atoi(e) : 1; if (ord != 0) ord = 1; }     // adjacent groups on the 8 XCDs: +0.5 % on the 60-min prefill, same binary
         p.group_m = gm;
         p.order = ord;
+        // very wide outputs (the stream's gate/up projection: 112 n-tiles): 8 m-tiles per group measured +0.7…1.3 % over 4 on that shape,
+        // same binary, bit-identical (profiles/r4_gemm_lab_clock.jsonl); narrower ones keep 4 (down_proj -2 %, fc1 -0.7 % at 8)
+        if (!getenv("VIDI_GEMM_GROUP_M") && N >= 64 * 256) p.group_m = 8;
     }
     return p;
 }

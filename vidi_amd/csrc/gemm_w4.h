@@ -37,8 +37,12 @@
 // branches (about 650 of the 3 265 instructions of a bias + residual + statistics tile, 350 of a plain one); the statistics' eight row
 // reductions of a strip run as one interleaved block (row16_sum8: no hazard s_nops).  The row offset is added on the VALU into the
 // VGPR offset: the SGPR offset of a buffer instruction is NOT part of the range check.  Bit-identical results.
+// Same-box A/B against form 1, alternating builds, identical checksums (profiles/r4_gemm_lab_epi2.jsonl): bias + residual + statistics
+// 16.7 k -> 13.1 k epilogue cycles per tile (out_proj +2.8 %, fc2 +0.9 %), bias + GELU 16.4 k -> 13.5 k (SigLIP fc1 +2.3 %, Whisper fc1
+// +1.2…1.5 %), bias + residual +0.5…1.3 %; the bias-free plain epilogue and GeGLU at K >= 3 584 measured -0.3…-0.6 % (their epilogue is 4 %
+// of the tile; the descriptor set-up does not pay) and keep form 1.
 #ifndef VIDI_W4_EPI2
-#define VIDI_W4_EPI2 0
+#define VIDI_W4_EPI2 1
 #endif
 
 struct W4Geom {
@@ -342,7 +346,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             hm_col = ((size_t)which * (p.M / p.hm_seq) * p.hm_heads + hh) * p.hm_seq * p.hm_hd + (nh - hh * p.hm_hd);
         }
         // epilogue form 2: per-tile descriptors + tile-invariant lane offsets (see VIDI_W4_EPI2 above)
-        constexpr bool bufio = (VIDI_W4_EPI2 != 0) && (GLU || (MODE == MODE_PLAIN && !EPI::heads));
+        constexpr bool bufio = (VIDI_W4_EPI2 != 0) && !GLU && MODE == MODE_PLAIN && !EPI::heads &&
+                               (VIDI_W4_EPI2 == 2 || EPI::bias || EPI::res != 0 || EPI::act != ACT_NONE || EPI::lnf);     // (2: every row-major epilogue, lab)
         constexpr bool stats_on = (MODE == MODE_PLAIN) && EPI::stats && (EPI::res != 0);
         __amdgpu_buffer_rsrc_t srdY, srdR, srdS;
         unsigned vY = 0, vR = 0, vS = 0;
