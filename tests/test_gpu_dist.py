@@ -35,8 +35,8 @@ def test_two_rank_sharded_prefill_matches_single_rank():
     assert b["n_img_local"] == 2 * 16 and b["n_aud_local"] == 10            # rank 0 holds frames 0-1 and window 0
     # the exchange itself (layer 0's merged T2V / T2A output, before the layers above amplify anything): the LSE merge is exact in real
     # arithmetic; in fp32 the partials are summed in another order, which can flip the final bf16 rounding of an output by ONE ulp
-    # (2^-8 relative): 0.1 % of the spread + 0.8 % relative
-    report("sharded layer-0 merged cross-attention", b["xattn_layer0"], a["xattn_layer0"], 1e-3 * a["xattn_layer0"].std().item(), 8e-3)
+    # (2^-8 .. 2^-7 relative; measured: exactly one ulp, 0.78 % of the value): 0.2 % of the spread + 1 % relative
+    report("sharded layer-0 merged cross-attention", b["xattn_layer0"], a["xattn_layer0"], 2e-3 * a["xattn_layer0"].std().item(), 1e-2)
     # ... and after two layers + the final norm those one-ulp flips have been amplified (observed 3 % of the spread)
     report("sharded prefill hidden", b["prefill"], a["prefill"], 5e-2 * a["prefill"].std().item(), 3e-2)
     report("sharded decode hidden", b["decode"], a["decode"], 5e-2 * a["decode"].std().item(), 3e-2)
@@ -64,7 +64,7 @@ def test_rccl_exchange_on_one_rank_matches_unsharded():
     assert b["sharded"] and not a["sharded"]
     assert b["collectives_per_forward"] == b["layers"] and a["collectives_per_forward"] == 0
     # one rank holds every key: the only difference is the partial form (fp32 numerator, m, l) taking a trip through the exchange buffer
-    report("rccl one-rank layer-0 merged cross-attention", b["xattn_layer0"], a["xattn_layer0"], 1e-3 * a["xattn_layer0"].std().item(), 8e-3)
+    report("rccl one-rank layer-0 merged cross-attention", b["xattn_layer0"], a["xattn_layer0"], 2e-3 * a["xattn_layer0"].std().item(), 1e-2)
     report("rccl one-rank prefill hidden", b["prefill"], a["prefill"], 5e-2 * a["prefill"].std().item(), 3e-2)
     report("rccl one-rank decode hidden", b["decode"], a["decode"], 5e-2 * a["decode"].std().item(), 3e-2)
     assert torch.equal(b["tokens"][:, :1], a["tokens"][:, :1]) and torch.equal(b["tokens8"][:, :1], a["tokens8"][:, :1])

@@ -54,15 +54,16 @@ class LazyF32:
 
 # Teacher-forced per-layer bounds (fraction of the layer output's spread, relative part = bf16 ulps of the value), about 2x the
 # measured use (profiles/r4_tolerance_audit.jsonl); the worst layer of each block is what the audit records.
-# Measured use with these bounds: siglip 0.52 (all arms), whisper 0.57, kv 0.52, stream 0.52, text 0.54.  Worst single element of a layer's
-# output: 3 % of its spread (towers), 1-2.6 % (K / V rows: one-ulp flips), 4-5 % (a full stream / text layer: ~6 rounding points) — against
-# 12-17 % for the free-running comparison at layer 41.  RMS error of a layer's output (third entry): the statistic that a systematic
-# error of a fraction of a per cent would move.
+# Measured use with these bounds (profiles/r4_tolerance_audit.jsonl): siglip 0.48-0.52 (all arms), whisper 0.57, kv 0.52, stream 0.52, text
+# 0.54.  Worst single element of a layer's output: 3 % of its spread (towers), 1-2.6 % (K / V rows: one-ulp flips), 4-5 % (a full stream /
+# text layer: ~6 rounding points) — against 12-17 % for the free-running comparison at layer 41.  Third entry: RMS error of a layer's
+# output over its rms, the statistic a systematic error of a fraction of a per cent would move; measured worst layer: siglip 0.58 %,
+# whisper 0.65 %, K / V rows 0.010 %, stream update 0.36 %, text layer 0.75 %.
 TEACHER = {
-    "siglip": (5e-2, 3e-2, 2e-2), "whisper": (5e-2, 3e-2, 2e-2),     # one encoder layer: LN-fold / prescaled-q arms included
-    "kv": (1e-2, 1.2e-2, 5e-3),                                       # K/V rows of a layer = one GEMM of its probed input
-    "stream": (4e-2, 2.5e-2, 2e-2),                                   # one diagonal-stream update (o_proj fold, two norm pairs, GeGLU, down_proj)
-    "text": (6e-2, 3e-2, 3e-2),                                       # one decoder layer on the text rows (T2T + T2V + T2A + MLP)
+    "siglip": (5e-2, 3e-2, 1.3e-2), "whisper": (5e-2, 3e-2, 1.3e-2),     # one encoder layer: LN-fold / prescaled-q arms included
+    "kv": (1e-2, 1.2e-2, 5e-4),                                       # K/V rows of a layer = one GEMM of its probed input
+    "stream": (4e-2, 2.5e-2, 8e-3),                                   # one diagonal-stream update (o_proj fold, two norm pairs, GeGLU, down_proj)
+    "text": (6e-2, 3e-2, 1.5e-2),                                     # one decoder layer on the text rows (T2T + T2V + T2A + MLP)
 }
 
 
@@ -117,7 +118,7 @@ def test_siglip_tower_real_dims_full_depth(fold, monkeypatch):
     w16 = {k: v.to(dt) for k, v in w32.items()}
     ocfg = oracle_cfg(cfg)
     ref16 = O.siglip_forward(px[sample], w16, ocfg).float()
-    report(f"siglip real dims x26 layers (fold={fold}) free-running vs the bf16-rounding oracle", got[sample], ref16, 7e-2 * ref16.std().item(), 4e-2)
+    report(f"siglip real dims x26 layers (fold={fold}) free-running vs the bf16-rounding oracle", got[sample], ref16, 9e-2 * ref16.std().item(), 5e-2)
     # (3) teacher-forced: every layer on the input the kernels saw
     xs = [t.cpu() for t in eng.probe["vis_x"]]
     assert len(xs) == 27 and xs[0].shape == (2, 729, 1152)
@@ -148,7 +149,7 @@ def test_whisper_encoder_real_dims_full_depth():
     w16 = {k: v.to(dt) for k, v in w32.items()}
     ocfg = oracle_cfg(cfg)
     ref16 = O.whisper_encoder_forward(mel[sample], w16, ocfg).float()
-    report("whisper real dims x32 layers free-running vs the bf16-rounding oracle", got[sample], ref16, 8e-2 * ref16.std().item(), 4e-2)
+    report("whisper real dims x32 layers free-running vs the bf16-rounding oracle", got[sample], ref16, 10e-2 * ref16.std().item(), 5e-2)
     xs = [t.cpu() for t in eng.probe["aud_x"]]
     assert len(xs) == 33 and xs[0].shape == (1, 1500, 1280)
     failures = []

@@ -404,8 +404,10 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
     report("switch arms: stream K caches", a[0], b[0], *kv_tol(b[0]))
     report("switch arms: stream V caches", a[1], b[1], *kv_tol(b[1]))
     report("switch arms: prefill + decode hidden states", a[2], b[2], *tol2(b[2], False))
-    # the arm without the prescaled-q form, at the bounds that predate it (6 % of the spread for the caches)
-    kv_old = lambda x: (6e-2 * x.std().item(), 4e-2) if dt == torch.bfloat16 else (1.2e-2 * x.std().item(), 8e-3)     # noqa: E731
+    # the arm without the prescaled-q form, at the same bounds: measured (profiles/r4_tolerance_audit.jsonl) it sits at 5.2 / 6.0 % of the
+    # spread (bf16 K / V caches) against 5.7 / 6.2 % for the default arm — the prescale form accounts for ~0.3 % of the spread, the rest of
+    # the distance between the arms is the LayerNorm / repeat_kv folds and the summation orders
+    kv_old = kv_tol
     report("switch arms [prescale off vs all off]: stream K caches", c[0], b[0], *kv_old(b[0]))
     report("switch arms [prescale off vs all off]: stream V caches", c[1], b[1], *kv_old(b[1]))
     report("switch arms [prescale off vs all off]: prefill + decode hidden states", c[2], b[2], *tol2(b[2], False))

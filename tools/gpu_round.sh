@@ -38,6 +38,19 @@ verify300)
   python tools/show_bench.py $OUT/bench_verify300.json 2>/dev/null | grep -E "value|first_token|verify" || tail -5 $OUT/bench_verify300.err ;;
 epi2)
   bash tools/lab/run_epi2_ab.sh 2>&1 | tail -60 ;;
+abepi)
+  # same-box ABAB of the prefill: the product library (epilogue form 2) against tools/build_epi1.sh's build (form 1 everywhere, built in the container)
+  : > $OUT/ab_epi.jsonl
+  for r in 1 2; do for lib in libvidi_hip_epi1.so libvidi_hip.so; do
+    VIDI_HIP_LIB=$REPO/vidi_amd/$lib timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-preproc --no-verify --decode-steps 4 2> $OUT/ab_epi.err | grep '^{' | sed "s/^{/{\"lib\": \"$lib\", /" >> $OUT/ab_epi.jsonl; echo "abepi $lib rc=$?"
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/ab_epi.jsonl"):
+    d = json.loads(l)
+    print(d["lib"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "frac", round(d["roofline"]["frac"], 4), "first_token", d["first_token"])
+PY
+  ;;
 clock)
   bash tools/lab/run_clock.sh 2>&1 | tail -70 ;;
 dist8)
