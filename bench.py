@@ -233,6 +233,29 @@ def cpu_baseline(cfg, T, Nv, Na, prompt_len, quick=False, windows=None):
             "thread_sweep_gemm_tflops": {f"{d}@{n}": v for (d, n), v in probe.items()}}
 
 
+def synth_normal(first: int, count: int, stream: int, dev) -> torch.Tensor:
+    """`count` standard-normal fp32 values that depend only on (stream, global element index first .. first + count): splitmix64 of the
+    index gives two 24-bit uniforms, Box-Muller turns them into one normal.  int64 arithmetic wraps (two's complement) on every device."""
+    def s64(c):                                     # the constants of splitmix64 as signed 64-bit values
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def lsr(x, n):                                  # logical shift right of an int64 tensor
+        return (x >> n) & ((1 << (64 - n)) - 1)
+
+    def mix(z):
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        return z ^ lsr(z, 31)
+
+    i = torch.arange(first, first + count, dtype=torch.int64, device=dev)
+    z = mix((i * 2 + 0) * s64(0x9E3779B97F4A7C15) + stream)
+    u1 = (lsr(z, 40).to(torch.float32) + 0.5) * (1.0 / (1 << 24))
+    z = mix((i * 2 + 1) * s64(0x9E3779B97F4A7C15) + stream)
+    u2 = (lsr(z, 40).to(torch.float32) + 0.5) * (1.0 / (1 << 24))
+    del z, i
+    return torch.sqrt(-2.0 * torch.log(u1)).mul_(torch.cos(u2.mul_(2.0 * math.pi)))
+
+
 def _oracle_frame_embeds(O, px, t_global, T, w, ocfg, normalizer_dtype):
     """Token embeddings (inputs of the decoder's multimodal stream) of the frames `px` = frames `t_global` of a T-frame video:
     oracle/vidi_oracle.py:encode_video_images restricted to a few frames, with the GLOBAL frame count deciding the token budget and
@@ -479,18 +502,21 @@ def main():
     audio_size = int(round(secs * 100))                       # mel frames (100 per second)
     f0, f1 = shard(T, world, rank)
     c0, c1 = shard(Cw, world, rank)
-    # the synthetic video is a function of the GLOBAL frame / window index (one generator seed per frame and per window), so an N-rank
-    # run encodes exactly the video the 1-rank run does and `first_token` / `verify` are comparable across N
-    g = torch.Generator(device=dev)
+    # the synthetic video is a function of the GLOBAL element index (a counter-based generator: splitmix64 of the index -> two uniforms ->
+    # Box-Muller), so an N-rank run encodes exactly the video the 1-rank run does and `first_token` / `verify` are comparable across N;
+    # generated in chunks of 64 frames by a few large elementwise launches (one generator call per frame was 14 400 tiny launches, which
+    # rocprofv3's counter mode did not survive)
     S = cfg.vis_image_size
     pixel = torch.empty((f1 - f0, 3, S, S), dtype=dtype, device=dev)
-    for f in range(f0, f1):
-        g.manual_seed(1_000_000 + f)
-        pixel[f - f0] = (torch.randn((3, S, S), generator=g, device=dev) * 0.5).clamp_(-1, 1).to(dtype)
+    per_frame = 3 * S * S
+    for a0 in range(f0, f1, 64):
+        a1 = min(f1, a0 + 64)
+        pixel[a0 - f0: a1 - f0] = synth_normal(a0 * per_frame, (a1 - a0) * per_frame, 0x51A1, dev).mul_(0.5).clamp_(-1, 1).view(a1 - a0, 3, S, S).to(dtype)
+    per_win = cfg.aud_num_mel_bins * cfg.aud_nb_max_frames
     mel = torch.empty((c1 - c0, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), dtype=dtype, device=dev)
-    for c in range(c0, c1):
-        g.manual_seed(2_000_000 + c)
-        mel[c - c0] = (torch.randn((cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), generator=g, device=dev) * 0.3).to(dtype)
+    for a0 in range(c0, c1, 64):
+        a1 = min(c1, a0 + 64)
+        mel[a0 - c0: a1 - c0] = synth_normal(a0 * per_win, (a1 - a0) * per_win, 0xA0D1, dev).mul_(0.3).view(a1 - a0, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames).to(dtype)
     gi = torch.Generator().manual_seed(2)
     plens = [a.prompt_len] * a.queries
     if a.ragged_prompts is not None:

@@ -70,3 +70,16 @@ def test_cache_row_unpacking_matches_the_test_packer():
     rows = [0, 1, 15, 16, 31, 32, 63, 64, 100, 199]
     kg, vg = bench._cache_rows(mm, 0, rows, nkv, hd)
     assert torch.equal(kg, k[rows].reshape(len(rows), -1)) and torch.equal(vg, v[rows].reshape(len(rows), -1))
+
+
+def test_synthetic_video_is_a_function_of_the_global_index():
+    """bench.py's synthetic frames / mel: any rank's shard (a slice of the global element range) equals the same slice of the one-rank
+    video, the values are standard normal and the two streams (frames, mel) are independent"""
+    import bench
+    whole = bench.synth_normal(0, 300_000, 0x51A1, "cpu")
+    for a, b in ((0, 1000), (123_457, 200_001), (299_000, 300_000)):
+        assert torch.equal(bench.synth_normal(a, b - a, 0x51A1, "cpu"), whole[a:b])
+    assert abs(float(whole.mean())) < 0.01 and abs(float(whole.std()) - 1.0) < 0.01 and bool(torch.isfinite(whole).all())
+    other = bench.synth_normal(0, 300_000, 0xA0D1, "cpu")
+    assert abs(float(torch.corrcoef(torch.stack([whole, other]))[0, 1])) < 0.01
+    assert abs(float(torch.corrcoef(torch.stack([whole[:-1], whole[1:]]))[0, 1])) < 0.01

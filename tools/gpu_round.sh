@@ -119,6 +119,8 @@ pmc)
   done
   F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
   python tools/traffic_from_pmc.py "$F" "$W" $OUT/traffic.json 3600 vidi15_9b | head -c 4000
+  # a bench run later in this call attaches the figure when it finds it under profiles/ (it is committed from gpurun_out/ afterwards)
+  [ -n "$F" ] && [ -n "$W" ] && [ -s $OUT/traffic.json ] && cp $OUT/traffic.json $REPO/profiles/traffic.json
   # keep only the small summaries (the raw per-dispatch CSVs are tens of MB)
   rm -rf $OUT/pmc_fetch $OUT/pmc_write ;;
 esac
