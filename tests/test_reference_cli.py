@@ -276,3 +276,43 @@ def test_batch_of_videos_shares_the_token_budget_like_the_reference():
     assert out.tolist() == ref.tolist()
     logits = model.forward(ids, images=vids, audios=mels, audio_sizes=sizes, logits_to_keep=1).logits if hasattr(eng, "lm_head") else None
     assert logits is None or logits.shape[0] == 2
+
+
+def test_generate_plain_generation_kwargs_like_hf():
+    """`repetition_penalty`, `min_new_tokens`, `no_repeat_ngram_size`, `suppress_tokens` as PLAIN keyword arguments — the reference hands its
+    `**kwargs` to HF's `generate()`, which builds the processors itself (gemma.py:646-655): same tokens as passing transformers' processor
+    objects explicitly, EOS held back for `min_new_tokens` steps, no repeated bigram, suppressed tokens never emitted."""
+    from transformers import LogitsProcessorList
+    from transformers.generation.logits_process import (MinNewTokensLengthLogitsProcessor, NoRepeatNGramLogitsProcessor,
+                                                        RepetitionPenaltyLogitsProcessor, SuppressTokensLogitsProcessor)
+    model = build_model("tiny", seed=3)
+    frames, audio = media(12)
+    from vidi_amd import inference as OURS
+    cfg = model.config
+    ip, ap = processors(cfg)
+    video = OURS.process_images(frames, ip, cfg).unsqueeze(0)
+    mel, audio_size = OURS.process_audio(audio, ap)
+    ids = torch.tensor([[2, 21, 22, -200, 23, 24]])
+    kw = dict(images=video, audios=mel.unsqueeze(0), audio_sizes=[audio_size], max_new_tokens=10)
+    base = model.generate(ids, eos_token_id=999999, **kw)[0].tolist()
+    assert len(base) == 10 and len(set(base)) < 10, "the tiny random model repeats tokens: the penalties below have something to act on"
+    # repetition_penalty == the explicit processor
+    a = model.generate(ids, eos_token_id=999999, repetition_penalty=1.8, **kw)
+    b = model.generate(ids, eos_token_id=999999, logits_processor=LogitsProcessorList([RepetitionPenaltyLogitsProcessor(1.8)]), **kw)
+    assert a.tolist() == b.tolist() and a[0].tolist() != base
+    # no_repeat_ngram_size = 2: no bigram twice
+    c = model.generate(ids, eos_token_id=999999, no_repeat_ngram_size=2, **kw)[0].tolist()
+    grams = list(zip(c, c[1:]))
+    assert len(grams) == len(set(grams))
+    assert c == model.generate(ids, eos_token_id=999999, logits_processor=LogitsProcessorList([NoRepeatNGramLogitsProcessor(2)]), **kw)[0].tolist()
+    # min_new_tokens holds the EOS back: with the greedy second token as EOS the plain run stops after 2 tokens, min_new_tokens = 5 after >= 5
+    eos = base[1]
+    short = model.generate(ids, eos_token_id=eos, **kw)[0].tolist()
+    assert short == base[: base.index(eos) + 1]
+    d = model.generate(ids, eos_token_id=eos, min_new_tokens=5, **kw)[0].tolist()
+    e = model.generate(ids, eos_token_id=eos, logits_processor=LogitsProcessorList([MinNewTokensLengthLogitsProcessor(0, 5, [eos], device="cpu")]), **kw)[0].tolist()
+    assert d == e and len(d) >= 5 and eos not in d[:5]
+    # suppress_tokens
+    f = model.generate(ids, eos_token_id=999999, suppress_tokens=[base[0], base[2]], **kw)[0].tolist()
+    assert base[0] not in f and base[2] not in f
+    assert f == model.generate(ids, eos_token_id=999999, logits_processor=LogitsProcessorList([SuppressTokensLogitsProcessor([base[0], base[2]], device="cpu")]), **kw)[0].tolist()

@@ -328,8 +328,12 @@ class VidiForCausalLM:
         #   logits_processor  [callable(input_ids, scores) -> scores]   applied to the fp32 scores before the argmax / the sampling warpers
         #   stopping_criteria [callable(input_ids, scores) -> bool | BoolTensor[B]]   rows it flags finish like rows that emitted EOS
         #   streamer          .put(LongTensor[B]) per step, .end() after the last one
-        processors = list(kwargs.get("logits_processor") or [])
-        criteria = list(kwargs.get("stopping_criteria") or [])
+        # plain keyword arguments HF turns into processors / criteria itself (repetition_penalty, no_repeat_ngram_size, bad_words_ids,
+        # min_length, min_new_tokens, suppress_tokens, max_time) come first, in HF's order; the caller's own lists follow
+        from .sampling import generation_kwargs_processors
+        kw_procs, kw_crits = generation_kwargs_processors(kwargs, eos_list, eng.dev)
+        processors = kw_procs + list(kwargs.get("logits_processor") or [])
+        criteria = kw_crits + list(kwargs.get("stopping_criteria") or [])
         streamer = kwargs.get("streamer")
 
         def pick(h, step):
