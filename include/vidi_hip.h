@@ -84,9 +84,12 @@ int vidi_gemm_qkv_vt(const void* X, const void* W, const void* bias, void* Yqk, 
  *   act(Linear(LayerNorm(x))) without ever writing LayerNorm(x) (one row pass instead of a read + a write per LayerNorm).
  *   act: VIDI_ACT_NONE / GELU_TANH / GELU_ERF.  Layout of the qkv variant as vidi_gemm_qkv_vt.
  *   vidi_gemm_res_stats  is the PRODUCER of such an X (SiglipEncoderLayer out_proj / fc2 + residual, TP siglip:345-356; Whisper
- *   likewise): Y = X W^T + bias + R, and for every stored row and 128-column strip the partial sums part[m][strip] = (sum y,
- *   sum y^2) of the values it stored (strips = ceil(N / 128)); vidi_ln_finalize turns them into stats[m] = (mean, rstd).  With it
- *   the next LayerNorm costs no pass over Y at all.  (Small problems: the partials come from one pass over Y inside the call.) */
+ *   likewise): Y = X W^T + bias + R, and for every stored row the partial sums part[m][entry] = (sum y, sum y^2) of the values it
+ *   stored, over vidi_stat_strips(N) groups of columns per row (128-column strips, or the column groups of the 288-wide tile
+ *   geometry that serves N = 1152: the caller sizes `part` as M * vidi_stat_strips(N) * 2 floats); vidi_ln_finalize turns them into
+ *   stats[m] = (mean, rstd).  With it the next LayerNorm costs no pass over Y at all.  (Small problems: the partials come from one
+ *   pass over Y inside the call.) */
+int vidi_stat_strips(int N);
 int vidi_row_stats(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, void* stream);
 int vidi_gemm_res_stats(const void* X, const void* W, const void* bias, void* Y, const void* R, float* part,
                         int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int tile_cfg, int dtype, void* stream);

@@ -255,9 +255,11 @@ def test_gemm_ln_equals_layernorm_then_linear(hip, dt, act, M, N, K, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K,cfg", [(12900, 1152, 1152, -1), (12900, 1152, 4352, 5), (10001, 1280, 1280, -1), (300, 352, 192, -1), (70, 64, 64, -1)])
+@pytest.mark.parametrize("M,N,K,cfg", [(12900, 1152, 1152, -1), (12900, 1152, 4352, 5), (10001, 1280, 1280, -1), (300, 352, 192, -1), (70, 64, 64, -1),
+                                       (13217, 1152, 1152, -1), (200, 1152, 192, -1), (12900, 576, 1152, -1)])
 def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
-    """out_proj / fc2 + residual with the fused emission of the stored rows' partial sums (persistent kernel) or the one-pass
+    """out_proj / fc2 + residual with the fused emission of the stored rows' partial sums (persistent kernels: 256-wide tiles, or the
+    288 x 224 geometry for widths that are multiples of 288 and not of 256 — N = 1 152, 576; M = 13 217 ends in a 1-row tile) or the one-pass
     fallback (small problems), in place (Y aliases R, as the towers call it): Y equals the plain bias + residual GEMM bit for bit,
     and vidi_ln_finalize of the partials equals the two-pass row statistics of Y (row_stats) to fp32 round-off."""
     x = seeded((M, K), 80, dtype=dt); w = seeded((N, K), 81, 0.03, dtype=dt); b = seeded((N,), 82, dtype=dt)
@@ -265,15 +267,26 @@ def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
     y_ref = r.clone().cuda()
     hip.gemm(dev(x), dev(w), dev(b), y_ref, residual=y_ref, tile_cfg=cfg)
     y = r.clone().cuda()
-    nstr = (N + 127) // 128
+    nstr = hip.stat_strips(N)
     part = torch.full((2 * M * nstr,), float("nan"), dtype=torch.float32).cuda()
     hip.gemm_res_stats(dev(x), dev(w), dev(b), y, y, part, tile_cfg=cfg)
     assert torch.equal(y, y_ref)
     p = part.view(M, nstr, 2).cpu()
     assert torch.isfinite(p).all()
     yf = y.float().cpu()
-    pad = torch.zeros((M, nstr * 128)); pad[:, :N] = yf
-    strips = pad.view(M, nstr, 128)
+    # the column group behind every entry of a row: 128-column strips — or, for the widths of the 288-wide tile geometry run by its fused
+    # kernel, per tile the two 128-column main parts and the two 16-column tails; the one-pass fallback writes strips and pads with zeros
+    fused = cfg in (-1, 5) and ((N + 255) // 256) * ((M + 255) // 256) >= 192 and K % 64 == 0 and K >= 192
+    if nstr != (N + 127) // 128 and fused:
+        assert nstr == 4 * (N // 288)
+        groups = []
+        for t in range(N // 288):
+            groups += [range(288 * t, 288 * t + 128), range(288 * t + 128, 288 * t + 256), range(288 * t + 256, 288 * t + 272), range(288 * t + 272, 288 * t + 288)]
+    else:
+        groups = [range(128 * i, min(N, 128 * i + 128)) for i in range((N + 127) // 128)] + [range(0)] * (nstr - (N + 127) // 128)
+    strips = torch.zeros((M, nstr, 128))
+    for i, g in enumerate(groups):
+        strips[:, i, : len(g)] = yf[:, list(g)]
     # the fused emission sums the fp32 values before their rounding to the storage dtype: against sums of the STORED values that is
     # 128 independent half-ulp roundings per strip (6-sigma bound below); the fallback pass reads the stored values (exact)
     ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11           # spacing of the storage dtype relative to the value

@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vidi_amd/csrc tools/lab/gemm_lab.hip -o tools/lab/gemm_lab
 //   tools/lab/gemm_lab [set]          set: all | quick | stamps | store
 #include "gemm_w4.h"
+#include "gemm_w4n.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,7 +72,10 @@ static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; };   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh), 3 bias + GELU(erf), 4 bias + residual + row statistics
+template <typename EPI, typename LAB>
+static int lab_launch_w4n(const GemmParams& p, hipStream_t st) { return launch_w4n<BF16, EPI, LAB>(p, st); }
+
+struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; bool yonly = false; };   // yonly: checksum of Y alone, against the bias + residual reference   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh), 3 bias + GELU(erf), 4 bias + residual + row statistics
 
 #define LATE(MODE, LAB) lab_launch<BF16, 256, 256, 2, 4, 2, MODE, false, SCHED_LATE, 16, LAB>
 #define W4(MODE, PERSIST, WAITMODE, LAB) lab_launch_w4<BF16, MODE, PERSIST, LAB>
@@ -104,6 +108,16 @@ static std::vector<Variant> variants() {
         {"w4p_g1", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 1},
         {"w4p_g2", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 2},
         {"w4p_g16", W4(MODE_PLAIN, true, 0, LabNone), MODE_PLAIN, true, 1, 16},
+        // round 4: 288 x 224 tiles (gemm_w4n.h) for N = 1 152: Y must equal the 256-wide kernel's bit for bit (the partial sums have another layout)
+        {"w4n_br", lab_launch_w4n<Epi<true, ACT_NONE, 1>, LabNone>, MODE_PLAIN, true, 1, 4, 1, true},
+        {"w4n_brs", lab_launch_w4n<Epi<true, ACT_NONE, 1, false, true>, LabNone>, MODE_PLAIN, true, 1, 4, 4, true},
+        {"w4n_brs_g8", lab_launch_w4n<Epi<true, ACT_NONE, 1, false, true>, LabNone>, MODE_PLAIN, true, 1, 8, 4, true},
+        {"w4n_brs_g2", lab_launch_w4n<Epi<true, ACT_NONE, 1, false, true>, LabNone>, MODE_PLAIN, true, 1, 2, 4, true},
+        {"w4n_brs_stamps", lab_launch_w4n<Epi<true, ACT_NONE, 1, false, true>, LabStamps>, MODE_PLAIN, true, 1, 4, 4, true},
+        {"w4n_br_noepi", lab_launch_w4n<Epi<true, ACT_NONE, 1>, LabNoEpi>, MODE_PLAIN, false, 1, 4, 1, true},
+        {"w4p_br_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 1, 4, 1},
+        {"w4p_brs_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 1, 4, 4},
+        {"w4p_brs_o1_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 1, 4, 4},
         {"late_br", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 1},
         {"w4p_br", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 0, 4, 1},
         {"late_bt", LATE(MODE_PLAIN, LabNone), MODE_PLAIN, true, 0, 4, 2},
@@ -144,6 +158,7 @@ int main(int argc, char** argv) {
     else if (set == "geglu") want = {"late_geglu", "w4p_geglu"};
     else if (set == "epi") want = {"late", "w4p", "w4pc", "late_br", "w4p_br", "late_bt", "w4p_bt", "late_geglu", "w4p_geglu"};
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
+    else if (set == "w4n") want = {"w4p_br_o1", "w4n_br", "w4p_brs_o1", "w4n_brs", "w4n_brs_g8", "w4n_brs_g2", "w4n_br_noepi", "w4p_brs_o1_stamps", "w4n_brs_stamps"};
     else if (set == "clock") want = {"w4p_stamps_g1", "w4p_stamps_g2", "w4p_stamps_g4", "w4p_stamps_g8", "w4p_stamps_g16", "w4p_stamps_o0g4"};
     else if (set == "orders") want = {"w4p_g1", "w4p_g2", "w4p_o1", "w4p_o1_g8", "w4p_g16", "w4p"};
     else if (set == "stamps_epi") want = {"w4p_stamps", "w4p_br_stamps", "w4p_brs_stamps", "w4p_bt_stamps"};
@@ -181,7 +196,8 @@ int main(int argc, char** argv) {
         if (want.empty()) break;
         u16 *X, *W, *Y, *R, *Bv; float* SP;
         const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
-        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2)); CK(hipMalloc(&R, ny * 2)); CK(hipMalloc(&Bv, (size_t)sh.N * 2)); CK(hipMalloc(&SP, (size_t)sh.M * ((sh.N + 127) / 128) * 8));
+        const size_t spn = (size_t)sh.M * (size_t)((sh.N + 127) / 128 > w4n_stat_strips(sh.N) ? (sh.N + 127) / 128 : w4n_stat_strips(sh.N)) * 8;
+        CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2)); CK(hipMalloc(&R, ny * 2)); CK(hipMalloc(&Bv, (size_t)sh.N * 2)); CK(hipMalloc(&SP, spn));
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, R, ny, 0x5555u, 1.0f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, Bv, (size_t)sh.N, 0x7777u, 0.5f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, nx, 0x1234u, 1.7f, zero);
@@ -201,7 +217,8 @@ int main(int argc, char** argv) {
             if (v->epi == 1) { p.bias = Bv; p.R = R; p.ldr = sh.N; }
             if (v->epi == 2) { p.bias = Bv; p.act = ACT_GELU_TANH; }
             if (v->epi == 3) { p.bias = Bv; p.act = ACT_GELU_ERF; }
-            if (v->epi == 4) { p.bias = Bv; p.R = R; p.ldr = sh.N; p.stat_part = SP; CK(hipMemset(SP, 0, (size_t)sh.M * ((sh.N + 127) / 128) * 8)); }
+            if (v->epi == 4) { p.bias = Bv; p.R = R; p.ldr = sh.N; p.stat_part = SP; CK(hipMemset(SP, 0, spn)); }
+            if (v->yonly && !w4n_takes(sh.N)) continue;
             CK(hipMemset(Y, 0xff, ny * 2));
             CK(hipMemset(dbg, 0, 1024 * 64));
             int rc = v->fn(p, 0);
@@ -210,7 +227,7 @@ int main(int argc, char** argv) {
             CK(hipMemset(dsum, 0, 16));
             const size_t nyo = v->mode == MODE_GEGLU ? ny / 2 : ny;
             hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, Y, nyo, dsum);
-            if (v->epi == 4) hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, (const u16*)SP, (size_t)sh.M * ((sh.N + 127) / 128) * 4, dsum);   // the statistics too
+            if (v->epi == 4 && !v->yonly) hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, (const u16*)SP, (size_t)sh.M * ((sh.N + 127) / 128) * 4, dsum);   // the statistics too
             unsigned long long cs[2]; CK(hipMemcpy(cs, dsum, 16, hipMemcpyDeviceToHost));
             v->fn(p, 0);                                             // warm
             CK(hipEventRecord(e0));
@@ -219,7 +236,7 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
             const char* verdict = "n/a";
             if (v->correct) {
-                const int md = v->mode * 4 + v->epi;
+                const int md = v->mode * 4 + (v->yonly ? 1 : v->epi);
                 if (!have_ref[md]) { ref[md][0] = cs[0]; ref[md][1] = cs[1]; have_ref[md] = true; verdict = "ref"; }
                 else verdict = (cs[0] == ref[md][0] && cs[1] == ref[md][1]) ? "bit-identical" : "MISMATCH";
             }

@@ -131,21 +131,28 @@ int vidi_gemm_res_stats(const void* X, const void* W, const void* bias, void* Y,
     if ((ldr % 8) || ((uintptr_t)part & 7)) return VIDI_ERR_ALIGN;
     GemmParams p = base_params(X, W, bias, Y, R, M, N, K, ldx, ldw, ldy, ldr, 0);
     const long long t256 = (long long)((N + 255) / 256) * ((M + 255) / 256);
+    const int strips = vidi_w4n_stat_strips(N);               // entries per row of `part`: a function of N alone, whichever kernel runs
     if ((tile_cfg < 0 || tile_cfg == 5) && t256 >= 192 && K % 64 == 0 && K >= 192) {
         p.stat_part = part;                                   // fused: the persistent kernel's epilogue emits the partial sums
-        return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, 5, dtype, (hipStream_t)stream);
+        if (strips == (N + 127) / 128) return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, 5, dtype, (hipStream_t)stream);
+        // widths of the 288 x 224 geometry (N = 1 152): its kernel, or — if it cannot take this call — the unfused form below
+        const int rc = vidi_w4n_bias_res(p, dtype, (hipStream_t)stream);
+        if (rc != -100) return rc;
+        p.stat_part = nullptr;
     }
     // small problems run on a tile kernel without the fused emission: same partials from one pass over the stored rows
     const int rc = vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg == 5 ? -1 : tile_cfg, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
-    return vidi_row_partials_dispatch(Y, part, M, N, ldy, dtype, (hipStream_t)stream);
+    return vidi_row_partials_dispatch(Y, part, M, N, ldy, strips, dtype, (hipStream_t)stream);
 }
+
+int vidi_stat_strips(int N) { return N > 0 ? vidi_w4n_stat_strips(N) : 0; }
 
 int vidi_ln_finalize(const float* part, float* stats, long long rows, int N, float eps, void* stream) {
     (void)hipGetLastError();
     if (!part || !stats) return VIDI_ERR_ARG;
     if (((uintptr_t)part & 7) || ((uintptr_t)stats & 7)) return VIDI_ERR_ALIGN;
-    return vidi_ln_finalize_dispatch(part, stats, rows, (N + 127) / 128, N, eps, (hipStream_t)stream);
+    return vidi_ln_finalize_dispatch(part, stats, rows, vidi_w4n_stat_strips(N), N, eps, (hipStream_t)stream);
 }
 
 int vidi_gemm_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,

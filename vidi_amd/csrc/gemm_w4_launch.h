@@ -42,7 +42,13 @@ static int w4_plain_dispatch(const GemmParams& p, int batch, int repkv, hipStrea
     }
     if (act == ACT_NONE) {
         if (res == 0) return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 0>>(p, batch, st);   // projector second linear
-        if (res == 1) return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 1>>(p, batch, st);   // encoder out_proj / fc2 + residual
+        if (res == 1) {                                                                               // encoder out_proj / fc2 + residual
+            if (batch == 1) {                                  // widths of the 288 x 224 tile geometry (N = 1 152): gemm_w4n.h
+                const int rc = vidi_w4n_bias_res(p, T::id, st);
+                if (rc != VIDI_W4_UNSUPPORTED) return rc;
+            }
+            return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 1>>(p, batch, st);
+        }
         return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 2>>(p, batch, st);                  // patch embedding + position table
     }
     if (act == ACT_GELU_TANH) {

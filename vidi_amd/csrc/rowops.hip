@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ 
 }
 
 // ---- LayerNorm statistics from the per-strip partial sums a producing GEMM left (GemmParams::stat_part) ------------------------------
-//   part[row][strip] = (sum y, sum y^2) over a 128-column strip;  stats[row] = (mean, rsqrt(E[y^2] - mean^2 + eps)).
+//   part[row][entry] = (sum y, sum y^2) over a group of columns (a 128-column strip; for the 288-wide tile geometry 128 + 128 + 16 + 16
+//   columns of a tile: vidi_stat_strips(N) entries per row);  stats[row] = (mean, rsqrt(E[y^2] - mean^2 + eps)).
 //   One-pass variance in fp32: the relative error of var is ~1e-7 * E[y^2]/var, i.e. below the bf16 rounding of the consumer for any
 //   row whose mean is within ~50 standard deviations of zero (the towers' residual streams are within a few).
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, long long rows, int nstr,
@@ -269,8 +270,10 @@ int vidi_ln_finalize_dispatch(const float* part, float* stats, long long rows, i
 
 // the same partial sums computed from a stored matrix (small problems whose GEMM runs on a tile kernel without the fused emission)
 template <typename T>
-__global__ __launch_bounds__(256) void row_partials_kernel(const u16* __restrict__ Y, float* __restrict__ part, long long rows, int N, long long ldy) {
-    const int nstr = (N + 127) >> 7;
+__global__ __launch_bounds__(256) void row_partials_kernel(const u16* __restrict__ Y, float* __restrict__ part, long long rows, int N, long long ldy,
+                                                           int nstr) {
+    // nstr entries per row (>= ceil(N / 128): the layout the fused producers of this width write, vidi_stat_strips); entries past the last
+    // real 128-column strip are written as (0, 0)
     const long long idx = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);          // one 16-lane row per (matrix row, strip)
     const int c = threadIdx.x & 15;
     const bool live = idx < rows * nstr;
@@ -288,12 +291,12 @@ __global__ __launch_bounds__(256) void row_partials_kernel(const u16* __restrict
     if (live && c == 0) *((f32x2_t*)part + idx) = f32x2_t{s1, s2};
 }
 
-int vidi_row_partials_dispatch(const void* Y, float* part, long long rows, int N, long long ldy, int dtype, hipStream_t st) {
-    if (rows <= 0 || N <= 0 || N % 8 || ldy % 8) return VIDI_ERR_SHAPE;
-    const long long items = rows * ((N + 127) >> 7);
+int vidi_row_partials_dispatch(const void* Y, float* part, long long rows, int N, long long ldy, int nstr, int dtype, hipStream_t st) {
+    if (rows <= 0 || N <= 0 || N % 8 || ldy % 8 || nstr < ((N + 127) >> 7)) return VIDI_ERR_SHAPE;
+    const long long items = rows * nstr;
     const dim3 grid((unsigned)((items + 15) / 16));
-    if (dtype == VIDI_DT_BF16) hipLaunchKernelGGL(row_partials_kernel<BF16>, grid, dim3(256), 0, st, (const u16*)Y, part, rows, N, ldy);
-    else if (dtype == VIDI_DT_F16) hipLaunchKernelGGL(row_partials_kernel<F16>, grid, dim3(256), 0, st, (const u16*)Y, part, rows, N, ldy);
+    if (dtype == VIDI_DT_BF16) hipLaunchKernelGGL(row_partials_kernel<BF16>, grid, dim3(256), 0, st, (const u16*)Y, part, rows, N, ldy, nstr);
+    else if (dtype == VIDI_DT_F16) hipLaunchKernelGGL(row_partials_kernel<F16>, grid, dim3(256), 0, st, (const u16*)Y, part, rows, N, ldy, nstr);
     else return VIDI_ERR_DTYPE;
     return (int)hipGetLastError();
 }

@@ -400,7 +400,7 @@ class VidiEngine:
         A = None if self.patch_loader else self._buf("vis_A", (Mmax, V["kpad"]))
         fold = self.ln_fold
         ws = {"st": self._buf("vis_stats", (2 * Mmax,), dtype=torch.float32) if fold else None,
-              "part": self._buf("vis_part", (2 * Mmax * ((Hv + 127) // 128),), dtype=torch.float32) if fold else None,
+              "part": self._buf("vis_part", (2 * Mmax * hip.stat_strips(Hv),), dtype=torch.float32) if fold else None,
               "h": None if fold else self._buf("vis_h", (Mmax, Hv)),
               # Q|K rows + V^T planes of the Vt attention arm; the default arm (head-major q|k|v + transpose-read attention) needs neither
               "yqk": None if (fold and self.attn_rm) else self._buf("vis_qk", (Mmax, 2 * Hv)),
@@ -514,7 +514,7 @@ class VidiEngine:
         y1[:, 0].zero_()
         fold = self.ln_fold
         ws = {"st": self._buf("aud_stats", (2 * nb * N,), dtype=torch.float32) if fold else None,
-              "part": self._buf("aud_part", (2 * nb * N * ((Da + 127) // 128),), dtype=torch.float32) if fold else None,
+              "part": self._buf("aud_part", (2 * nb * N * hip.stat_strips(Da),), dtype=torch.float32) if fold else None,
               "h": None if fold else self._buf("aud_h", (nb * N, Da)),
               "yqk": None if (fold and self.attn_rm) else self._buf("aud_qk", (nb * N, 2 * Da)),
               "vt": None if (fold and self.attn_rm) else self._buf("aud_vt", (nb, nh, hd, Npad), zero=True),

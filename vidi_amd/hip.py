@@ -99,6 +99,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.vidi_attn_cross_workspace_bytes.argtypes = [_c_int] * 4
     lib.vidi_softcap_argmax_workspace_bytes.restype = ctypes.c_size_t
     lib.vidi_softcap_argmax_workspace_bytes.argtypes = [_c_int]
+    lib.vidi_stat_strips.restype = _c_int
+    lib.vidi_stat_strips.argtypes = [_c_int]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -336,16 +338,21 @@ def row_stats(x: torch.Tensor, stats: torch.Tensor, eps: float) -> torch.Tensor:
 
 
 def gemm_res_stats(x, w, bias, out, residual, part, *, tile_cfg: int = -1):
-    """out = x w^T + bias + residual, plus part[m][strip] = (sum, sum of squares) of the stored row values per 128-column strip
-    (the next LayerNorm's statistics without a pass over `out`: ln_finalize)"""
+    """out = x w^T + bias + residual, plus part[m][entry] = (sum, sum of squares) of the stored row values per column group — stat_strips(N)
+    entries per row (the next LayerNorm's statistics without a pass over `out`: ln_finalize)"""
     _rowmajor(x, "x"); _rowmajor(w, "w")
     M, K = x.shape
     N = w.shape[0]
-    if part.dtype != torch.float32 or not part.is_contiguous() or part.numel() < 2 * M * ((N + 127) // 128):
-        raise VidiHipError("gemm_res_stats: `part` must be a contiguous fp32 buffer of 2 * M * ceil(N/128) elements")
+    if part.dtype != torch.float32 or not part.is_contiguous() or part.numel() < 2 * M * stat_strips(N):
+        raise VidiHipError("gemm_res_stats: `part` must be a contiguous fp32 buffer of 2 * M * stat_strips(N) elements")
     _check(load_library().vidi_gemm_res_stats(_p(x), _p(w), _p(bias), _p(out), _p(residual), _p(part), M, N, K, x.stride(0), w.stride(0),
                                               out.stride(0), residual.stride(0), tile_cfg, _dt(x), _stream()), "vidi_gemm_res_stats")
     return out
+
+
+def stat_strips(N: int) -> int:
+    """(sum, sum of squares) entries per row of the `part` buffer of gemm_res_stats / ln_finalize for an output width N"""
+    return int(load_library().vidi_stat_strips(int(N)))
 
 
 def ln_finalize(part, stats, rows: int, N: int, eps: float):
