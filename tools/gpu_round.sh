@@ -38,6 +38,19 @@ verify300)
   python tools/show_bench.py $OUT/bench_verify300.json 2>/dev/null | grep -E "value|first_token|verify" || tail -5 $OUT/bench_verify300.err ;;
 epi2)
   bash tools/lab/run_epi2_ab.sh 2>&1 | tail -60 ;;
+abw4n)
+  # same-box ABAB of the prefill: 288 x 224 tiles for N = 1 152 (default) against the 256-wide kernel everywhere (VIDI_W4N=0), one library
+  : > $OUT/ab_w4n.jsonl
+  for r in 1 2; do for sw in 0 1; do
+    VIDI_W4N=$sw timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-preproc --decode-steps 4 2> $OUT/ab_w4n.err | grep '^{' | sed "s/^{/{\"VIDI_W4N\": $sw, /" >> $OUT/ab_w4n.jsonl; echo "abw4n $sw rc=$?"
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/ab_w4n.jsonl"):
+    d = json.loads(l)
+    print("VIDI_W4N", d["VIDI_W4N"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "frac", round(d["roofline"]["frac"], 4), "verify", d["verify"]["ok"], round(d["verify"]["embeds_frames_max_err"], 4), "first_token", d["first_token"])
+PY
+  ;;
 abepi)
   # same-box ABAB of the prefill: the product library (epilogue form 2) against tools/build_epi1.sh's build (form 1 everywhere, built in the container)
   : > $OUT/ab_epi.jsonl

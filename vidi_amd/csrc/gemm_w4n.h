@@ -36,6 +36,9 @@ __host__ __device__ inline int w4n_stat_strips(int N) { return 4 * ((N + W4NGeom
 // the widths this geometry takes over from the 256-wide kernel
 __host__ __device__ inline bool w4n_takes(int N) { return N >= 288 && N % 288 == 0 && N % 256 != 0; }
 
+#ifndef VIDI_W4N_LABTAIL
+#define VIDI_W4N_LABTAIL 0              // lab builds only (wrong results): 1 = the tail's global loads / stores skipped, 2 = no tail work in the epilogue
+#endif
 template <typename T, typename EPI, typename LAB = LabNone>
 __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
     using G = W4NGeom;
@@ -224,13 +227,15 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     res[b % RD][j] = __builtin_amdgcn_raw_buffer_load_b128(srdR, vR + (unsigned)((b * 16 + j * 4) * p.ldr) * 2u, 0, 0);
-                rest[b % RD] = __builtin_amdgcn_raw_buffer_load_b128(srdR, vRt + (unsigned)(b * 16 * p.ldr) * 2u, 0, 0);
+                if constexpr (VIDI_W4N_LABTAIL == 0) rest[b % RD] = __builtin_amdgcn_raw_buffer_load_b128(srdR, vRt + (unsigned)(b * 16 * p.ldr) * 2u, 0, 0);
+                else rest[b % RD] = u32x4{0, 0, 0, 0};
             }
         };
         auto fetch = [&]() {
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[j] = *(const u32x4*)(scr + (j * 4 + rr) * SROW + cc * 16);
-            valt = *(const u32x4*)(scr + tr * SROW + 256 + tc * 16);
+            if constexpr (VIDI_W4N_LABTAIL != 2) valt = *(const u32x4*)(scr + tr * SROW + 256 + tc * 16);
+            else valt = u32x4{0, 0, 0, 0};
         };
         // x (already T-rounded) + residual; (sum, sum of squares) of the fp32 sums before their rounding (as gemm_w4.h)
         auto add_res = [&](const u32x4& v, const u32x4& r, float& s1, float& s2) {
@@ -253,8 +258,10 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
             u32x4 outv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) outv[j] = add_res(val[j], res[b % RD][j], sv[2 * j], sv[2 * j + 1]);
-            const u32x4 outt = add_res(valt, rest[b % RD], st1, st2);
-            if constexpr (stats_on) {
+            u32x4 outt = {0, 0, 0, 0};
+            st1 = st2 = 0.f;
+            if constexpr (VIDI_W4N_LABTAIL != 2) outt = add_res(valt, rest[b % RD], st1, st2);
+            if constexpr (stats_on && VIDI_W4N_LABTAIL != 2) {
                 row16_sum8(sv);
                 // the tail's row: lanes 2r, 2r + 1
                 asm volatile("s_nop 1\n\t"
@@ -270,9 +277,13 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(sv[2 * j]), __float_as_uint(sv[2 * j + 1])}, srdS, vS + rowoff * strips * 8u, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(outv[j], srdY, vY + rowoff * (unsigned)p.ldy * 2u, 0, 0);
             }
-            if constexpr (stats_on)
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(st1), __float_as_uint(st2)}, srdS, vSt + (unsigned)(b * 16) * strips * 8u, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(outt, srdY, vYt + (unsigned)(b * 16) * (unsigned)p.ldy * 2u, 0, 0);
+            if constexpr (VIDI_W4N_LABTAIL == 0) {
+                if constexpr (stats_on)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(st1), __float_as_uint(st2)}, srdS, vSt + (unsigned)(b * 16) * strips * 8u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(outt, srdY, vYt + (unsigned)(b * 16) * (unsigned)p.ldy * 2u, 0, 0);
+            } else {
+                asm volatile("" :: "v"(outt), "v"(st1), "v"(st2));
+            }
         };
         load_res(std::integral_constant<int, 0>{});
         load_res(std::integral_constant<int, 1>{});
