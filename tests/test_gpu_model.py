@@ -174,6 +174,45 @@ def test_generate_matches_oracle(tiny_setup):
     assert got.shape[1] <= n_new and got.dtype == torch.int64
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_text_longer_than_the_sliding_window(dt):
+    """gemma.py:104 + TP gemma2 sliding layers (even layers: key j visible to query i iff i - W <= j <= i) with the text LONGER than the
+    window — every other model-level test keeps prompt + generation inside it.  tiny config with a window of 4: a 14-token prompt (its
+    later rows must not see the first tokens on the even layers) and 8 teacher-forced decode steps that push the window further along,
+    against the oracle's logits at every step (the oracle's window rule is the one the reference-executed goldens pin for in-window text;
+    flash-attn's window semantics themselves are restated)."""
+    from vidi_amd.config import tiny
+    from vidi_amd.model import strip_image_token
+    cfg = tiny(sliding_window=4)
+    eng, w32 = make(cfg, dt, seed=21)
+    ocfg = oracle_cfg(cfg)
+    px = seeded((2, 3, cfg.vis_image_size, cfg.vis_image_size), 130, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 131, 0.3).to(dt)
+    ids = torch.tensor([[2, 21, 22, 23, -200, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33]], dtype=torch.int64)
+    n_new = 8
+    ref_ids, dbg = O.generate_greedy(ids, [px.float()], [mel.float()], [100], w32, ocfg, n_new + 1, return_debug=True)
+    # the window must matter in the oracle itself, or this test checks nothing
+    wide = O.generate_greedy(ids, [px.float()], [mel.float()], [100], w32, dataclasses.replace(ocfg, sliding_window=4096), 1, return_debug=True)[1]
+    assert float((wide["prefill_logits"] - dbg["prefill_logits"]).abs().max()) > 1e-3 * float(dbg["prefill_logits"].std())
+    fi, mi = eng.encode_video_images(px.cuda())
+    fa, ma = eng.encode_video_audios(mel.cuda(), 100)
+    mm = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=False)
+    idt, mask, pos = strip_image_token(ids)
+    L = idt.shape[1]
+    ts = eng.new_text_state(1, L + n_new + 2)
+    hn = eng.text_forward(eng.embed_tokens(idt.cuda()), pos.reshape(-1).cuda(), ts, mm, Lq=L, new_mask=mask.cuda())
+    ts.n_valid = torch.tensor([L], device="cuda")
+    logits, _ = eng.logits_argmax(hn.view(1, L, -1)[:, -1])
+    ltol = logit_tol(dt, dbg["prefill_logits"])
+    report("prefill logits, text longer than the window", logits, dbg["prefill_logits"], ltol, 0.0)
+    for i in range(n_new):                                    # teacher-forced with the oracle's tokens: every step's logits
+        tok = torch.tensor([int(ref_ids[0, i])], dtype=torch.int64, device="cuda")
+        posn = ts.n_valid.clone(); ts.n_valid += 1
+        h = eng.text_forward(eng.embed_tokens(tok), posn, ts, mm, Lq=1)
+        lg, _ = eng.logits_argmax(h)
+        report(f"decode step {i} logits, window 4", lg, dbg["step_logits"][i], ltol, 0.0)
+
+
 def test_batch_of_videos_one_tower_pass_and_the_batch_token_budget():
     """multimodal.py:157-180 on the HIP engine: a batch of two videos goes through SigLIP / Whisper in ONE pass (the concatenated frames /
     windows) and the token-budget rule counts the frames of the WHOLE batch — 3 + 4 frames cross the (lowered) budget that neither
