@@ -7,6 +7,7 @@
 //   tools/lab/gemm_lab [set]          set: all | quick | stamps | store
 #include "gemm_w4.h"
 #include "gemm_w4n.h"
+#include "gemm_w4h.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,8 @@ struct LabNoDma : LabNone { static constexpr bool no_dma = true; };
 struct LabNoEpi : LabNone { static constexpr bool no_epilogue = true; };
 struct LabNoStore : LabNone { static constexpr bool no_store = true; };
 struct LabStamps : LabNone { static constexpr bool stamps = true; };
+struct LabStampsNoEpi : LabStamps { static constexpr bool no_epilogue = true; };
+struct LabStampsNoEpiNoDma : LabStampsNoEpi { static constexpr bool no_dma = true; };
 
 __global__ void fill_kernel(u16* p, size_t n, unsigned seed, float scale, int zero) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,6 +78,9 @@ static int lab_launch_w4(const GemmParams& p, hipStream_t st) {
 template <typename EPI, typename LAB>
 static int lab_launch_w4n(const GemmParams& p, hipStream_t st) { return launch_w4n<BF16, EPI, LAB>(p, st); }
 
+template <typename EPI, typename LAB>
+static int lab_launch_w4h(const GemmParams& p, hipStream_t st) { return launch_w4h<BF16, EPI, LAB>(p, st); }
+
 struct Variant { const char* name; launch_fn fn; int mode; bool correct; int order; int group_m; int epi = 0; bool yonly = false; };   // yonly: checksum of Y alone, against the bias + residual reference   // epi: 0 none, 1 bias + residual, 2 bias + GELU(tanh), 3 bias + GELU(erf), 4 bias + residual + row statistics
 
 #define LATE(MODE, LAB) lab_launch<BF16, 256, 256, 2, 4, 2, MODE, false, SCHED_LATE, 16, LAB>
@@ -115,6 +121,19 @@ static std::vector<Variant> variants() {
         {"w4n_brs_g2", lab_launch_w4n<Epi<true, ACT_NONE, 1, false, true>, LabNone>, MODE_PLAIN, true, 1, 2, 4, true},
         {"w4n_brs_stamps", lab_launch_w4n<Epi<true, ACT_NONE, 1, false, true>, LabStamps>, MODE_PLAIN, true, 1, 4, 4, true},
         {"w4n_br_noepi", lab_launch_w4n<Epi<true, ACT_NONE, 1>, LabNoEpi>, MODE_PLAIN, false, 1, 4, 1, true},
+        // round 4 probe: 256 x 128 tiles (gemm_w4h.h), half the accumulator file: the K-loop rate a two-accumulator-set kernel would start from
+        {"w4h_br", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabNone>, MODE_PLAIN, true, 1, 4, 1},
+        {"w4h_brs", lab_launch_w4h<Epi<true, ACT_NONE, 1, false, true>, LabNone>, MODE_PLAIN, true, 1, 4, 4},
+        {"w4h_br_g8", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabNone>, MODE_PLAIN, true, 1, 8, 1},
+        {"w4h_br_noepi", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabNoEpi>, MODE_PLAIN, false, 1, 4, 1},
+        {"w4h_br_nodma", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabNoDma>, MODE_PLAIN, false, 1, 4, 1},
+        {"w4h_br_stamps", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabStamps>, MODE_PLAIN, true, 1, 4, 1},
+        // the shader clock under the K loop alone (cycle stamps / wall time): is the MFMA-dense phase power-throttled below the whole kernel's clock?
+        {"w4p_noepi_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStampsNoEpi, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, false, 1, 4, 1},
+        {"w4p_noepi_nodma_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStampsNoEpiNoDma, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, false, 1, 4, 1},
+        {"w4h_noepi_stamps", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabStampsNoEpi>, MODE_PLAIN, false, 1, 4, 1},
+        {"w4h_noepi_nodma_stamps", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabStampsNoEpiNoDma>, MODE_PLAIN, false, 1, 4, 1},
+        {"w4p_br_noepi_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNoEpi, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, false, 1, 4, 1},
         {"w4p_br_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 1, 4, 1},
         {"w4p_brs_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 1, 4, 4},
         {"w4p_brs_o1_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 1, 4, 4},
@@ -159,6 +178,8 @@ int main(int argc, char** argv) {
     else if (set == "epi") want = {"late", "w4p", "w4pc", "late_br", "w4p_br", "late_bt", "w4p_bt", "late_geglu", "w4p_geglu"};
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
     else if (set == "w4n") want = {"w4p_br_o1", "w4n_br", "w4p_brs_o1", "w4n_brs", "w4n_brs_g8", "w4n_brs_g2", "w4n_br_noepi", "w4p_brs_o1_stamps", "w4n_brs_stamps"};
+    else if (set == "w4h") want = {"w4p_br_o1", "w4h_br", "w4p_brs_o1", "w4h_brs", "w4h_br_g8", "w4p_br_noepi_o1", "w4h_br_noepi", "w4h_br_nodma", "w4h_br_stamps"};
+    else if (set == "kclock") want = {"w4p_br_stamps", "w4p_noepi_stamps", "w4p_noepi_nodma_stamps", "w4h_br_stamps", "w4h_noepi_stamps", "w4h_noepi_nodma_stamps"};
     else if (set == "clock") want = {"w4p_stamps_g1", "w4p_stamps_g2", "w4p_stamps_g4", "w4p_stamps_g8", "w4p_stamps_g16", "w4p_stamps_o0g4"};
     else if (set == "orders") want = {"w4p_g1", "w4p_g2", "w4p_o1", "w4p_o1_g8", "w4p_g16", "w4p"};
     else if (set == "stamps_epi") want = {"w4p_stamps", "w4p_br_stamps", "w4p_brs_stamps", "w4p_bt_stamps"};
