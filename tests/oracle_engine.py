@@ -89,6 +89,15 @@ class OracleEngine:
     def new_text_state(self, B, Lmax):
         return SimpleNamespace(B=B, Lmax=Lmax, caches=O.OracleCaches(), mask=torch.zeros((B, 0), dtype=torch.bool), past_len=0, n_valid=None)
 
+    def reorder_text_state(self, ts, parents):
+        idx = parents.long().cpu()
+        c = ts.caches
+        for name in ("text", "image", "audio"):
+            setattr(c, name, [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in getattr(c, name)])
+        ts.mask = ts.mask.index_select(0, idx)
+        if ts.n_valid is not None:
+            ts.n_valid = ts.n_valid.index_select(0, idx)
+
     def embed_tokens(self, ids, normalize=True):
         ids = ids.reshape(-1).long().cpu()
         e = F.embedding(ids.clamp(min=0), self.w["model.embed_tokens.weight"])

@@ -1,0 +1,100 @@
+"""`generate(num_beams > 1)`: the product class's beam search (vidi_amd/beam.py + model.py:_generate_beams), driven over the CPU oracle
+engine, against what the REFERENCE's own `generate()` returned for the same weights, video and arguments (tests/golden/reference_beams.json,
+written by tests/golden/make_golden_beams.py from gemma.py:603-655 -> HF `_beam_search`): token-for-token, and the sequence scores."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from beam_util import forced_log_probs, hypothesis_score, trim_at_eos  # noqa: E402
+from oracle_engine import OracleEngine  # noqa: E402
+
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_beams.json")))
+_models = {}
+
+
+def golden_model(seed):
+    if seed not in _models:
+        from vidi_amd.model import VidiForCausalLM
+        from vidi_amd.config import tiny
+        from vidi_amd.weights import init_random_weights
+        cfg = tiny(sliding_window=64)                                   # make_golden_dattn.golden_config()
+        w = init_random_weights(cfg, seed=seed, dtype=torch.float32, device="cpu")
+        _models[seed] = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=OracleEngine(cfg, w))
+    return _models[seed]
+
+
+def golden_video(nrow):
+    d = np.load(os.path.join(HERE, "golden", "reference_dattn.npz"))
+    px, mel = torch.from_numpy(d["A_images"]), torch.from_numpy(d["A_audios"])
+    return dict(images=px.repeat(nrow, 1, 1, 1, 1), audios=mel.repeat(nrow, 1, 1, 1), audio_sizes=[100] * nrow)
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_beam_search_reproduces_the_reference_generate(case):
+    model = golden_model(case["seed"])
+    ids = torch.tensor(case["input_ids"], dtype=torch.int64)
+    eos = case["eos_token_id"]
+    g = model.generate(ids, do_sample=False, use_cache=True, pad_token_id=0, eos_token_id=eos if len(eos) > 1 else eos[0],
+                       output_scores=True, return_dict_in_generate=True, **golden_video(len(case["input_ids"])), **case["kwargs"])
+    assert g.sequences.tolist() == case["sequences"]
+    np.testing.assert_allclose(g.sequences_scores.numpy(), np.array(case["sequences_scores"]), rtol=0, atol=2e-4)
+    # without return_dict_in_generate: the token tensor alone
+    t = model.generate(ids, do_sample=False, pad_token_id=0, eos_token_id=eos if len(eos) > 1 else eos[0],
+                       **golden_video(len(case["input_ids"])), **case["kwargs"])
+    assert torch.is_tensor(t) and t.tolist() == case["sequences"]
+
+
+def test_one_beam_is_the_greedy_path_and_the_best_beam_never_scores_below_it():
+    """the search with the greedy sequence's log-probability as a floor: beam 1 of num_beams = 3 scores >= greedy's score"""
+    case = GOLD["cases"][0]
+    model = golden_model(case["seed"])
+    ids = torch.tensor(case["input_ids"], dtype=torch.int64)
+    mm = model.encode_mm_state(**{k: v for k, v in golden_video(1).items()})
+    greedy = model.generate(ids, mm_state=mm, do_sample=False, max_new_tokens=8, pad_token_id=0, eos_token_id=7)
+    # greedy's own score, recomputed through the logits-processor hook (sees the fp32 scores of every step)
+    seen = []
+
+    def spy(input_ids, scores):
+        seen.append(torch.log_softmax(scores.float(), -1))
+        return scores
+
+    again = model.generate(ids, mm_state=mm, do_sample=False, max_new_tokens=8, pad_token_id=0, eos_token_id=7, logits_processor=[spy])
+    assert again.tolist() == greedy.tolist()
+    lp = sum(float(seen[i][0, int(greedy[0, i])]) for i in range(greedy.shape[1])) / greedy.shape[1]
+    g = model.generate(ids, mm_state=mm, do_sample=False, num_beams=3, max_new_tokens=8, pad_token_id=0, eos_token_id=7,
+                       return_dict_in_generate=True, output_scores=True)
+    assert float(g.sequences_scores[0]) >= lp - 1e-5
+    assert g.sequences.tolist() == case["sequences"]                   # resident video state: the same answer as from raw frames
+
+
+def test_beam_search_argument_rules():
+    model = golden_model(6)
+    ids = torch.tensor(GOLD["cases"][0]["input_ids"], dtype=torch.int64)
+    with pytest.raises(ValueError, match="num_return_sequences"):
+        model.generate(ids, num_beams=2, num_return_sequences=3, max_new_tokens=2, **golden_video(1))
+    with pytest.raises(NotImplementedError, match="do_sample"):
+        model.generate(ids, num_beams=2, do_sample=True, max_new_tokens=2, **golden_video(1))
+    with pytest.raises(ValueError, match="streamer"):
+        model.generate(ids, num_beams=2, streamer=object(), max_new_tokens=2, **golden_video(1))
+
+
+@pytest.mark.parametrize("case", [c for c in GOLD["cases"] if len(c["input_ids"]) == 1], ids=lambda c: c["name"])
+def test_forced_rescoring_gives_the_reference_score(case):
+    """the checker of tests/test_gpu_beams.py, checked: scoring the reference's sequences token by token through the oracle (log-softmax,
+    then the kwargs' processors; length penalty over the new tokens) gives the reference's `sequences_scores`"""
+    model = golden_model(case["seed"])
+    ids = torch.tensor(case["input_ids"], dtype=torch.int64)
+    mm = model.encode_mm_state(**golden_video(1))
+    for seq, want in zip(case["sequences"], case["sequences_scores"]):
+        seq = trim_at_eos(seq, case["eos_token_id"])
+        lps = forced_log_probs(model, ids, mm, seq, case["kwargs"], case["eos_token_id"])
+        assert abs(hypothesis_score(lps, seq, float(case["kwargs"].get("length_penalty", 1.0))) - want) < 2e-4

@@ -699,6 +699,18 @@ class VidiEngine:
                          vc=torch.zeros((Lr, B, Lmax, kvd), dtype=self.dtype, device=self.dev),
                          kmask=torch.zeros((B, Lmax), dtype=torch.uint8, device=self.dev))
 
+    def reorder_text_state(self, ts: TextState, parents: torch.Tensor) -> None:
+        """Beam search: row i of the text K/V cache continues from row parents[i] (HF `Cache.reorder_cache(beam_idx)`, which the reference
+        gets through gemma.py:646-655).  The rows of a prompt's beams share their mask and length, the video / audio K/V belong to the
+        prompt, so only the filled part of the text K/V moves (a gather in place: data movement, a few MB per step)."""
+        n = ts.past_len
+        idx = parents.to(self.dev, torch.int64)
+        ts.kc[:, :, :n] = ts.kc[:, :, :n].index_select(1, idx)
+        ts.vc[:, :, :n] = ts.vc[:, :, :n].index_select(1, idx)
+        ts.kmask.copy_(ts.kmask.index_select(0, idx))
+        if ts.n_valid is not None:
+            ts.n_valid = ts.n_valid.index_select(0, idx)
+
     def _rope_tables(self, max_pos: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """cos/sin rows per position, fp32 math then cast (TP gemma2:118-136); host-precomputed table."""
         if self._rope_cache is None or self._rope_cache[0].shape[0] < max_pos:

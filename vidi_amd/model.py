@@ -240,6 +240,24 @@ class VidiForCausalLM:
         dist.broadcast(t, src=src, group=pg)
         return t
 
+    def _stack_rows(self, rows, pad, kwargs):
+        """answers of a batch decoded row by row ([k, n_i] each; k = num_return_sequences under beam search, else 1) -> [sum k, max n_i],
+        shorter ones padded on the right as HF pads finished rows; under `return_dict_in_generate` (beam search) the same object again"""
+        as_dict = not torch.is_tensor(rows[0])
+        seqs = [r.sequences if as_dict else r for r in rows]
+        fill = int(pad)
+        n = max(int(q.shape[1]) for q in seqs)
+        out = torch.full((sum(int(q.shape[0]) for q in seqs), n), fill, dtype=torch.int64, device=self.engine.dev)
+        at = 0
+        for q in seqs:
+            out[at: at + q.shape[0], : q.shape[1]] = q
+            at += q.shape[0]
+        if not as_dict:
+            return out
+        from types import SimpleNamespace
+        sc = [r.sequences_scores for r in rows]
+        return SimpleNamespace(sequences=out, sequences_scores=None if sc[0] is None else torch.cat(sc))
+
     # ---- text prefill + greedy decode ----
     def _prefill(self, ids: torch.Tensor, mask: torch.Tensor, pos: torch.Tensor, mm: Optional[MMState], max_new: int):
         eng = self.engine
@@ -258,18 +276,24 @@ class VidiForCausalLM:
     def generate(self, inputs: Optional[torch.Tensor] = None, images=None, image_sizes=None, audios=None,
                  audio_sizes: Optional[Sequence[int]] = None, mm_state: Optional[MMState] = None, **kwargs) -> torch.Tensor:
         """gemma.py:603-655.  Accepts do_sample/max_new_tokens/use_cache/disable_compile/pad_token_id/
-        attention_mask/position_ids, and for do_sample=True: temperature/top_k/top_p/generator (HF warper semantics,
-        vidi_amd/sampling.py); the reference CLI uses do_sample=False."""
+        attention_mask/position_ids, for do_sample=True: temperature/top_k/top_p/generator (HF warper semantics,
+        vidi_amd/sampling.py), and num_beams/length_penalty/early_stopping/num_return_sequences (HF beam search, vidi_amd/beam.py);
+        the reference CLI uses do_sample=False, one beam."""
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")            # gemma.py:615-616
         do_sample = bool(kwargs.get("do_sample", False))
-        if kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("beam search is not implemented (the reference CLI decodes greedily)")
+        num_beams = int(kwargs.get("num_beams", None) or 1)
+        if num_beams > 1 and do_sample:
+            raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
+        if num_beams > 1 and kwargs.get("streamer") is not None:
+            raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")   # HF's own rule
         max_new = int(kwargs.get("max_new_tokens", 20))
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
         eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]) if e is not None]     # HF allows a list ([1, 107] for Gemma2)
         pad = kwargs.get("pad_token_id", None)
         pad = (eos_list[0] if eos_list else 0) if pad is None else pad
+        if num_beams > 1:
+            pad = pad or (eos_list[0] if eos_list else -1)                       # HF's beam search fills with `pad_token_id or eos_token_id[0]`
         attention_mask = kwargs.get("attention_mask", None)
         eng = self.engine
         if eng.mistral and attention_mask is not None and int(attention_mask[:, -1].sum()) != attention_mask.shape[0]:
@@ -295,13 +319,9 @@ class VidiForCausalLM:
                 mm_i = self.encode_mm_state(self._row(images, i), self._row(audios, i), None if audio_sizes is None else [audio_sizes[i]],
                                             vis_features=None if vis is None else vis[i], aud_features=None if aud is None else aud[i],
                                             budget_frames=budget)
-                rows.append(self.generate(ids_i[None], mm_state=mm_i, **kw)[0])
+                rows.append(self.generate(ids_i[None], mm_state=mm_i, **kw))
                 del mm_i
-            n = max(int(r.shape[0]) for r in rows)
-            out = torch.full((B, n), int(pad), dtype=torch.int64, device=eng.dev)
-            for i, r in enumerate(rows):
-                out[i, : r.shape[0]] = r
-            return out
+            return self._stack_rows(rows, pad, kwargs)
         if mm_state is None and (images is not None or audios is not None):
             mm_state = self.encode_mm_state(images, audios, audio_sizes)
         if attention_mask is not None and inputs.shape[0] > 1 and not bool(attention_mask[:, 0].bool().all()):
@@ -311,13 +331,11 @@ class VidiForCausalLM:
             for i in range(inputs.shape[0]):
                 kw = dict(kwargs)
                 kw["attention_mask"] = None
-                rows.append(self.generate(inputs[i].cpu()[attention_mask[i].bool().cpu()][None], mm_state=mm_state, **kw)[0])
-            n = max(int(r.shape[0]) for r in rows)
-            out = torch.full((len(rows), n), int(pad), dtype=torch.int64, device=eng.dev)
-            for i, r in enumerate(rows):
-                out[i, : r.shape[0]] = r
-            return out
+                rows.append(self.generate(inputs[i].cpu()[attention_mask[i].bool().cpu()][None], mm_state=mm_state, **kw))
+            return self._stack_rows(rows, pad, kwargs)
         ids, mask, pos = strip_image_token(inputs, attention_mask)
+        if num_beams > 1:
+            return self._generate_beams(ids, mask, pos, mm_state, max_new, num_beams, eos_list, kwargs)
         ts, last = self._prefill(ids, mask, pos, mm_state, max_new)
         B = ids.shape[0]
         out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
@@ -398,6 +416,43 @@ class VidiForCausalLM:
         if streamer is not None:
             streamer.end()
         return out[:, :n_done]
+
+    def _generate_beams(self, ids, mask, pos, mm_state, max_new, num_beams, eos_list, kwargs):
+        """`num_beams > 1` (HF `GenerationMixin._beam_search`, reached through gemma.py:646-655's `**kwargs`): vidi_amd/beam.py holds the
+        search; here: the rows expanded to `num_beams` each before the text prefill, one decode step per search step with the text K/V
+        rows re-gathered from their parent beams, and HF's output conventions (the new tokens only, as under `inputs_embeds`; unfinished
+        positions hold `pad_token_id`, or the first EOS id when that is None / 0 — HF's `pad_token_id or eos_token_id[0]`;
+        `return_dict_in_generate=True` -> an object with `.sequences` and, with `output_scores=True`, `.sequences_scores`)."""
+        from types import SimpleNamespace
+        from .beam import beam_search
+        from .sampling import generation_kwargs_processors
+        eng = self.engine
+        B, nb = ids.shape[0], num_beams
+        nrs = int(kwargs.get("num_return_sequences", None) or 1)
+        if nrs > nb:
+            raise ValueError(f"`num_return_sequences` ({nrs}) has to be smaller or equal to `num_beams` ({nb}).")
+        rep = lambda t: t.repeat_interleave(nb, dim=0)                          # noqa: E731  rows b*nb .. b*nb + nb - 1 = the beams of prompt b
+        ts, last = self._prefill(rep(ids), rep(mask), rep(pos), mm_state, max_new)
+        kw_procs, kw_crits = generation_kwargs_processors(kwargs, eos_list, eng.dev)
+        processors = kw_procs + list(kwargs.get("logits_processor") or [])
+        criteria = kw_crits + list(kwargs.get("stopping_criteria") or [])
+        fill = kwargs.get("pad_token_id", None) or (eos_list[0] if eos_list else -1)
+        length_penalty = kwargs.get("length_penalty", None)
+
+        def step_logits(tokens, parents):
+            if parents is not None:
+                eng.reorder_text_state(ts, parents)
+            emb = eng.embed_tokens(tokens)
+            posn = ts.n_valid.clone()
+            ts.n_valid += 1
+            return eng.logits_argmax(eng.text_forward(emb, posn, ts, mm_state, Lq=1))[0]
+
+        seqs, scores = beam_search(step_logits, eng.logits_argmax(last)[0], B, nb, int(self.config.vocab_size), max_new, eos_list, int(fill),
+                                   processors, criteria, 1.0 if length_penalty is None else float(length_penalty),
+                                   kwargs.get("early_stopping", False) or False, nrs)
+        if kwargs.get("return_dict_in_generate"):
+            return SimpleNamespace(sequences=seqs, sequences_scores=scores if kwargs.get("output_scores") else None)
+        return seqs
 
     # ---- forward (gemma.py:484-601): prefill-style call returning logits ----
     @torch.no_grad()
