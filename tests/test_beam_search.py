@@ -21,35 +21,41 @@ GOLD = json.load(open(os.path.join(HERE, "golden", "reference_beams.json")))
 _models = {}
 
 
-def golden_model(seed):
-    if seed not in _models:
+def golden_cfg(arch):
+    from vidi_amd.config import tiny, tiny_7b
+    if arch == "vidi7b":                                                # make_golden_dattn_7b.golden_config()
+        return tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64)
+    return tiny(sliding_window=64)                                      # make_golden_dattn.golden_config()
+
+
+def golden_model(seed, arch="vidi15"):
+    if (arch, seed) not in _models:
         from vidi_amd.model import VidiForCausalLM
-        from vidi_amd.config import tiny
         from vidi_amd.weights import init_random_weights
-        cfg = tiny(sliding_window=64)                                   # make_golden_dattn.golden_config()
+        cfg = golden_cfg(arch)
         w = init_random_weights(cfg, seed=seed, dtype=torch.float32, device="cpu")
-        _models[seed] = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=OracleEngine(cfg, w))
-    return _models[seed]
+        _models[(arch, seed)] = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=OracleEngine(cfg, w))
+    return _models[(arch, seed)]
 
 
-def golden_video(nrow):
-    d = np.load(os.path.join(HERE, "golden", "reference_dattn.npz"))
+def golden_video(nrow, arch="vidi15"):
+    d = np.load(os.path.join(HERE, "golden", "reference_dattn_7b.npz" if arch == "vidi7b" else "reference_dattn.npz"))
     px, mel = torch.from_numpy(d["A_images"]), torch.from_numpy(d["A_audios"])
     return dict(images=px.repeat(nrow, 1, 1, 1, 1), audios=mel.repeat(nrow, 1, 1, 1), audio_sizes=[100] * nrow)
 
 
 @pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
 def test_beam_search_reproduces_the_reference_generate(case):
-    model = golden_model(case["seed"])
+    model = golden_model(case["seed"], case["arch"])
     ids = torch.tensor(case["input_ids"], dtype=torch.int64)
     eos = case["eos_token_id"]
     g = model.generate(ids, do_sample=False, use_cache=True, pad_token_id=0, eos_token_id=eos if len(eos) > 1 else eos[0],
-                       output_scores=True, return_dict_in_generate=True, **golden_video(len(case["input_ids"])), **case["kwargs"])
+                       output_scores=True, return_dict_in_generate=True, **golden_video(len(case["input_ids"]), case["arch"]), **case["kwargs"])
     assert g.sequences.tolist() == case["sequences"]
     np.testing.assert_allclose(g.sequences_scores.numpy(), np.array(case["sequences_scores"]), rtol=0, atol=2e-4)
     # without return_dict_in_generate: the token tensor alone
     t = model.generate(ids, do_sample=False, pad_token_id=0, eos_token_id=eos if len(eos) > 1 else eos[0],
-                       **golden_video(len(case["input_ids"])), **case["kwargs"])
+                       **golden_video(len(case["input_ids"]), case["arch"]), **case["kwargs"])
     assert torch.is_tensor(t) and t.tolist() == case["sequences"]
 
 
@@ -91,9 +97,9 @@ def test_beam_search_argument_rules():
 def test_forced_rescoring_gives_the_reference_score(case):
     """the checker of tests/test_gpu_beams.py, checked: scoring the reference's sequences token by token through the oracle (log-softmax,
     then the kwargs' processors; length penalty over the new tokens) gives the reference's `sequences_scores`"""
-    model = golden_model(case["seed"])
+    model = golden_model(case["seed"], case["arch"])
     ids = torch.tensor(case["input_ids"], dtype=torch.int64)
-    mm = model.encode_mm_state(**golden_video(1))
+    mm = model.encode_mm_state(**golden_video(1, case["arch"]))
     for seq, want in zip(case["sequences"], case["sequences_scores"]):
         seq = trim_at_eos(seq, case["eos_token_id"])
         lps = forced_log_probs(model, ids, mm, seq, case["kwargs"], case["eos_token_id"])

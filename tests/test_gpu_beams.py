@@ -19,13 +19,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "reference_beams.json")))
 
 
-def build(seed, dt):
+def build(seed, dt, arch="vidi15"):
     from types import SimpleNamespace
-    from vidi_amd.config import tiny
+    from vidi_amd.config import tiny, tiny_7b
     from vidi_amd.engine import VidiEngine
     from vidi_amd.model import VidiForCausalLM
     from vidi_amd.weights import init_random_weights
-    cfg = tiny(sliding_window=64)
+    cfg = (tiny_7b(num_attention_heads=2, num_key_value_heads=1, head_dim=128, query_pre_attn_scalar=128.0, sliding_window=64) if arch == "vidi7b"
+           else tiny(sliding_window=64))                                # the golden configs of tests/golden/make_golden_dattn*.py
     w = init_random_weights(cfg, seed=seed, dtype=dt, device="cpu")
     eng = VidiEngine(cfg, dict(w), dtype=dt, device="cuda", free_source=False)
     model = VidiForCausalLM.__new__(VidiForCausalLM)
@@ -37,9 +38,9 @@ def build(seed, dt):
     return cfg, model, ref
 
 
-def video(nrow, dt, dev, out=None):
+def video(nrow, dt, dev, out=None, arch="vidi15"):
     """case A's frames / mel rounded to the model dtype (the oracle gets the same rounded values, as fp32)"""
-    d = np.load(os.path.join(HERE, "golden", "reference_dattn.npz"))
+    d = np.load(os.path.join(HERE, "golden", "reference_dattn_7b.npz" if arch == "vidi7b" else "reference_dattn.npz"))
     px, mel = torch.from_numpy(d["A_images"]).to(dt).to(out or dt), torch.from_numpy(d["A_audios"]).to(dt).to(out or dt)
     return dict(images=px.repeat(nrow, 1, 1, 1, 1).to(dev), audios=mel.repeat(nrow, 1, 1, 1).to(dev), audio_sizes=[100] * nrow)
 
@@ -78,17 +79,17 @@ def test_reorder_text_state_equals_a_fresh_prefill(dt):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [c for c in GOLD["cases"] if len(c["input_ids"]) == 1], ids=lambda c: c["name"])
 def test_beam_search_on_the_hip_engine(case, dt):
-    cfg, model, ref = build(case["seed"], dt)
+    cfg, model, ref = build(case["seed"], dt, case["arch"])
     ids = torch.tensor(case["input_ids"], dtype=torch.int64)
     eos = case["eos_token_id"]
     calls = []
     inner = model.engine.reorder_text_state
     model.engine.reorder_text_state = lambda ts, parents: (calls.append(1), inner(ts, parents))[1]
     g = model.generate(ids, do_sample=False, pad_token_id=0, eos_token_id=eos if len(eos) > 1 else eos[0], output_scores=True,
-                       return_dict_in_generate=True, **video(1, dt, "cuda"), **case["kwargs"])
+                       return_dict_in_generate=True, **video(1, dt, "cuda", arch=case["arch"]), **case["kwargs"])
     seqs, scores = g.sequences.cpu(), g.sequences_scores.cpu()
     assert seqs.shape[0] == len(case["sequences"]) and seqs.shape[1] <= case["kwargs"]["max_new_tokens"]
-    mm32 = ref.encode_mm_state(**video(1, dt, "cpu", out=torch.float32))
+    mm32 = ref.encode_mm_state(**video(1, dt, "cpu", out=torch.float32, arch=case["arch"]))
     lpen = float(case["kwargs"].get("length_penalty", 1.0))
     for r in range(seqs.shape[0]):
         seq = trim_at_eos(seqs[r].tolist(), eos)                        # an EOS ends the hypothesis; what follows is padding
