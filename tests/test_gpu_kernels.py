@@ -304,6 +304,24 @@ def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
     report("finalize mean", a[:, 0], bb[:, 0], mean_tol + 1e-6, 1e-5)
     report("finalize rstd", a[:, 1], bb[:, 1], 0.0, 1e-3 if dt == torch.bfloat16 else 2e-4)
 
+@pytest.mark.parametrize("N", [64, 352, 1152, 1280, 3968, 4096, 8192])
+@pytest.mark.parametrize("rows", [1, 255, 256, 257, 5000])
+def test_ln_finalize_rows_and_widths(hip, rows, N):
+    """vidi_ln_finalize alone: block edges (a block finalizes 256 rows), every entry count of vidi_stat_strips (1 .. 16 staged through
+    LDS with consecutive lanes on consecutive entries, >= 32 on the row-per-thread kernel), against float64 sums of the same partials"""
+    nstr = hip.stat_strips(N)
+    part = torch.stack((seeded((rows, nstr), 90, 40.0) + 3.0, seeded((rows, nstr), 91, 30.0).abs() * N / nstr + 50.0), dim=-1).float()
+    st = torch.full((2 * rows + 2,), float("nan"), dtype=torch.float32).cuda()
+    hip.ln_finalize(part.reshape(-1).cuda(), st, rows, N, 1e-6)
+    got = st.cpu()
+    assert torch.isnan(got[2 * rows:]).all()                              # nothing written past the last row
+    s = part.double().sum(1)
+    mean = s[:, 0] / N
+    var = (s[:, 1] / N - mean * mean).clamp_min(0)
+    report("mean", got[: 2 * rows].view(rows, 2)[:, 0], mean.float(), 1e-6 * float(mean.abs().max()), 1e-6)
+    report("rstd", got[: 2 * rows].view(rows, 2)[:, 1], (var + 1e-6).rsqrt().float(), 0.0, 2e-5)
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 5])
 @pytest.mark.parametrize("hd,N,nh,B", [(72, 729, 4, 2), (16, 49, 4, 2), (64, 1500, 4, 12)])
 def test_gemm_qkv_vt_ln(hip, hd, N, nh, B, cfg):
