@@ -104,3 +104,20 @@ def test_forced_rescoring_gives_the_reference_score(case):
         seq = trim_at_eos(seq, case["eos_token_id"])
         lps = forced_log_probs(model, ids, mm, seq, case["kwargs"], case["eos_token_id"])
         assert abs(hypothesis_score(lps, seq, float(case["kwargs"].get("length_penalty", 1.0))) - want) < 2e-4
+
+
+SAMP = json.load(open(os.path.join(HERE, "golden", "reference_sampling.json")))
+
+
+@pytest.mark.parametrize("case", SAMP["cases"], ids=lambda c: f"{c['arch']}-{'_'.join(f'{k}{v}' for k, v in c['kwargs'].items()) or 'defaults'}")
+def test_sampling_replays_the_reference_generate_draw_for_draw(case):
+    """`do_sample=True`: the reference's own `generate()` under `torch.manual_seed` (tests/golden/make_golden_sampling.py) against the
+    product class under the same seed — same warpers in the same order with HF's defaults where a knob is absent (top_k = 50; an
+    explicit `top_k=None` / 0 switches it off), one multinomial draw per step: token for token, EOS stops included"""
+    if torch.__version__ != SAMP["torch"]:
+        pytest.skip("the draws are those of the torch build that wrote the golden")
+    model = golden_model(case["seed"], case["arch"])
+    ids = torch.tensor(case["input_ids"], dtype=torch.int64)
+    torch.manual_seed(case["torch_seed"])
+    got = model.generate(ids, do_sample=True, max_new_tokens=10, pad_token_id=0, **golden_video(1, case["arch"]), **case["kwargs"])
+    assert got.tolist() == case["tokens"]

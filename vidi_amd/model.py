@@ -90,7 +90,10 @@ class VidiForCausalLM:
         self.dtype = dtype
         self.device = torch.device(device)
         self.engine = engine if engine is not None else VidiEngine(config, weights, dtype=dtype, device=device)
-        self.generation_config = SimpleNamespace(eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id)
+        # HF `GenerationConfig` defaults for the sampling knobs (transformers 4.50 / 4.44: top_k = 50 unless the checkpoint's
+        # generation_config.json or the caller says otherwise — the reference forwards **kwargs to HF's generate(), gemma.py:646-655)
+        self.generation_config = SimpleNamespace(eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id,
+                                                 temperature=1.0, top_k=50, top_p=1.0)
         self.model = _Inner(self)
         self._mm_cache: Optional[Tuple[Any, MMState]] = None
 
@@ -364,8 +367,9 @@ class VidiForCausalLM:
             if not do_sample:
                 return idx, logits
             from .sampling import sample, warp_logits
-            return sample(warp_logits(logits, kwargs.get("temperature"), kwargs.get("top_k"), kwargs.get("top_p")),
-                          kwargs.get("generator")), logits
+            gc = self.generation_config
+            knob = lambda k: kwargs[k] if k in kwargs else getattr(gc, k, None)     # noqa: E731  an explicit None switches a warper off
+            return sample(warp_logits(logits, knob("temperature"), knob("top_k"), knob("top_p")), kwargs.get("generator")), logits
 
         # sharded + sampling: the replicated text streams must draw the SAME token on every rank (each rank has its own RNG state, and
         # a divergent token or stop decision would mix partials of different queries in the next all-gather or strand a rank in it)
@@ -551,4 +555,12 @@ def load_pretrained_model(model_name_or_path: str, load_8bit: bool = False, load
             warnings.warn(f"synthetic model without tokenizer/processor files ({type(e).__name__}: {e}); processors are None")
     model.get_model().text_tokenizer, model.get_model().image_processor, model.get_model().audio_processor = tok, img_proc, aud_proc
     model.generation_config.eos_token_id = cfg.eos_token_id
+    gc_path = os.path.join(str(model_name_or_path), "generation_config.json")
+    if os.path.isfile(gc_path):                                          # the checkpoint's own sampling defaults, as HF's from_pretrained reads them
+        import json
+        with open(gc_path) as f:
+            gc = json.load(f)
+        for k in ("temperature", "top_k", "top_p", "pad_token_id"):
+            if gc.get(k) is not None:
+                setattr(model.generation_config, k, gc[k])
     return model, tok, img_proc, aud_proc
