@@ -4,7 +4,7 @@
 
     python tests/golden/make_golden_sampling.py
 
-writes tests/golden/reference_sampling.json; tests/test_beam_search.py::test_sampling_* replays the same seeds through the product class
+writes tests/golden/reference_sampling.json; tests/test_generate_api.py::test_sampling_* replays the same seeds through the product class
 over the CPU oracle engine: same draws, token for token — which pins the warpers' order and thresholds AND the defaults HF applies when a
 knob is not passed (`top_k = 50`)."""
 import json

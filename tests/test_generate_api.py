@@ -1,6 +1,7 @@
-"""`generate(num_beams > 1)`: the product class's beam search (vidi_amd/beam.py + model.py:_generate_beams), driven over the CPU oracle
-engine, against what the REFERENCE's own `generate()` returned for the same weights, video and arguments (tests/golden/reference_beams.json,
-written by tests/golden/make_golden_beams.py from gemma.py:603-655 -> HF `_beam_search`): token-for-token, and the sequence scores."""
+"""`generate()`'s HF surface against what the REFERENCE's own `generate()` returned for the same weights, video and arguments (the product
+class driven over the CPU oracle engine; goldens written by tests/golden/make_golden_beams.py / make_golden_sampling.py / make_golden_dattn.py
+from gemma.py:603-655 / mistral.py:629-681 -> HF `GenerationMixin`): beam search token for token with the sequence scores; `do_sample=True`
+draw for draw under the same `torch.manual_seed`; `return_dict_in_generate` / `output_scores`; `max_length`."""
 import json
 import os
 import sys
@@ -121,3 +122,24 @@ def test_sampling_replays_the_reference_generate_draw_for_draw(case):
     torch.manual_seed(case["torch_seed"])
     got = model.generate(ids, do_sample=True, max_new_tokens=10, pad_token_id=0, **golden_video(1, case["arch"]), **case["kwargs"])
     assert got.tolist() == case["tokens"]
+
+
+def test_return_dict_scores_and_max_length_like_the_reference():
+    """golden case E (make_golden_dattn.py: the reference's greedy `generate(output_scores=True, return_dict_in_generate=True)`): the same
+    object shape here — `.sequences`, `.scores` per step; and `max_length` counts the embedded prompt (HF under `inputs_embeds`)"""
+    d = np.load(os.path.join(HERE, "golden", "reference_dattn.npz"))
+    model = golden_model(6)
+    ids = torch.from_numpy(d["E_input_ids"])
+    g = model.generate(ids, do_sample=False, max_new_tokens=8, use_cache=True, pad_token_id=0, output_scores=True, output_logits=True,
+                       return_dict_in_generate=True, **golden_video(1))
+    assert g.sequences.tolist() == d["E_tokens"].tolist()
+    assert len(g.scores) == g.sequences.shape[1] == len(g.logits)
+    np.testing.assert_allclose(torch.stack(g.scores, dim=1).numpy(), d["E_scores"], rtol=0, atol=2e-4)
+    assert all(torch.equal(a, b) for a, b in zip(g.scores, g.logits))          # no processors: the scores are the raw logits
+    n_prompt = ids.shape[1] - 1                                                 # the <image> placeholder is not an embedded position
+    t = model.generate(ids, do_sample=False, max_length=n_prompt + 5, pad_token_id=0, **golden_video(1))
+    assert t.tolist() == [d["E_tokens"][0, :5].tolist()]
+    t = model.generate(ids, do_sample=False, max_length=n_prompt + 5, max_new_tokens=3, pad_token_id=0, **golden_video(1))
+    assert t.shape[1] == 3                                                      # max_new_tokens wins
+    with pytest.raises(ValueError, match="max_length"):
+        model.generate(ids, do_sample=False, max_length=n_prompt, **golden_video(1))

@@ -258,8 +258,18 @@ class VidiForCausalLM:
         if not as_dict:
             return out
         from types import SimpleNamespace
-        sc = [r.sequences_scores for r in rows]
-        return SimpleNamespace(sequences=out, sequences_scores=None if sc[0] is None else torch.cat(sc))
+        if hasattr(rows[0], "sequences_scores"):                                  # beam search
+            sc = [r.sequences_scores for r in rows]
+            return SimpleNamespace(sequences=out, sequences_scores=None if sc[0] is None else torch.cat(sc))
+
+        def steps(name):                                                          # per-step [B, V] tensors; rows that stopped earlier: -inf / 0 rows are not invented
+            per = [getattr(r, name) for r in rows]
+            if per[0] is None:
+                return None
+            if len({len(p) for p in per}) != 1:
+                raise NotImplementedError(f"`{name}` of a batch decoded row by row whose rows stop at different lengths")
+            return tuple(torch.cat([p[i] for p in per], dim=0) for i in range(len(per[0])))
+        return SimpleNamespace(sequences=out, scores=steps("scores"), logits=steps("logits"), past_key_values=None)
 
     # ---- text prefill + greedy decode ----
     def _prefill(self, ids: torch.Tensor, mask: torch.Tensor, pos: torch.Tensor, mm: Optional[MMState], max_new: int):
@@ -290,7 +300,18 @@ class VidiForCausalLM:
             raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
         if num_beams > 1 and kwargs.get("streamer") is not None:
             raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")   # HF's own rule
-        max_new = int(kwargs.get("max_new_tokens", 20))
+        max_new = kwargs.get("max_new_tokens", None)
+        if max_new is None:
+            # HF's `_prepare_generated_length` under `inputs_embeds` (how the reference drives it, gemma.py:646-655): `max_length` (default
+            # 20) counts the batch's embedded prompt positions only when the caller set it; `max_new_tokens` wins when both are given
+            max_length = kwargs.get("max_length", None)
+            n_prompt = int(strip_image_token(inputs, kwargs.get("attention_mask", None))[0].shape[1])
+            max_new = 20 if max_length is None else int(max_length) - n_prompt
+            if max_new <= 0:
+                raise ValueError(f"Input length of input_ids is {n_prompt}, but `max_length` is set to {max_length}. This can lead to "
+                                 "unexpected behavior. You should consider increasing `max_length` or, better yet, setting `max_new_tokens`.")
+            kwargs = dict(kwargs, max_new_tokens=int(max_new))               # the row-by-row paths below pass it on
+        max_new = int(max_new)
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
         eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]) if e is not None]     # HF allows a list ([1, 107] for Gemma2)
         pad = kwargs.get("pad_token_id", None)
@@ -357,19 +378,30 @@ class VidiForCausalLM:
         criteria = kw_crits + list(kwargs.get("stopping_criteria") or [])
         streamer = kwargs.get("streamer")
 
+        # `return_dict_in_generate=True`: HF's GenerateDecoderOnlyOutput fields that have a meaning here — `.sequences`, and per step
+        # `.scores` (output_scores: the fp32 scores after the processors and, when sampling, the warpers) / `.logits` (output_logits: raw)
+        as_dict = bool(kwargs.get("return_dict_in_generate"))
+        keep_scores = [] if as_dict and kwargs.get("output_scores") else None
+        keep_logits = [] if as_dict and kwargs.get("output_logits") else None
+
         def pick(h, step):
             logits, idx = eng.logits_argmax(h)                          # lm_head + final softcap (in place) + argmax
+            if keep_logits is not None:
+                keep_logits.append(logits.float().clone())
             if processors:
                 logits = logits.float()
                 for proc in processors:
                     logits = proc(out[:, :step], logits)
                 idx = torch.argmax(logits, dim=-1)
-            if not do_sample:
-                return idx, logits
-            from .sampling import sample, warp_logits
-            gc = self.generation_config
-            knob = lambda k: kwargs[k] if k in kwargs else getattr(gc, k, None)     # noqa: E731  an explicit None switches a warper off
-            return sample(warp_logits(logits, knob("temperature"), knob("top_k"), knob("top_p")), kwargs.get("generator")), logits
+            if do_sample:
+                from .sampling import sample, warp_logits
+                gc = self.generation_config
+                knob = lambda k: kwargs[k] if k in kwargs else getattr(gc, k, None)     # noqa: E731  an explicit None switches a warper off
+                logits = warp_logits(logits, knob("temperature"), knob("top_k"), knob("top_p"))
+                idx = sample(logits, kwargs.get("generator"))
+            if keep_scores is not None:
+                keep_scores.append(logits.float().clone())
+            return idx, logits
 
         # sharded + sampling: the replicated text streams must draw the SAME token on every rank (each rank has its own RNG state, and
         # a divergent token or stop decision would mix partials of different queries in the next all-gather or strand a rank in it)
@@ -381,7 +413,7 @@ class VidiForCausalLM:
         # VIDI_DECODE_GRAPH=1: decode steps are replayed from a hipGraph (device-side cache position, no per-launch
         # host work).  Measured on MI355X (60-min video): replay 19.3 ms/token vs 21.0 eager, capture 126 ms —
         # it only pays for generations of ~80+ tokens, so it is opt-in; the sharded path stays eager.
-        use_graph = (not do_sample and not processors and not criteria and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
+        use_graph = (not do_sample and not processors and not criteria and not as_dict and max_new >= int(os.environ.get("VIDI_DECODE_GRAPH_MIN", "8"))
                      and os.environ.get("VIDI_DECODE_GRAPH", "0") == "1" and (eng.world == 1 or self._backend() == "nccl"))
         replay = None
         if streamer is not None:
@@ -419,6 +451,11 @@ class VidiForCausalLM:
                 nxt = self._bcast0(nxt)
         if streamer is not None:
             streamer.end()
+        if as_dict:
+            from types import SimpleNamespace
+            # (a step's scores exist only if the loop went on to that step: n_done entries, like HF's tuples)
+            return SimpleNamespace(sequences=out[:, :n_done], scores=None if keep_scores is None else tuple(keep_scores[:n_done]),
+                                   logits=None if keep_logits is None else tuple(keep_logits[:n_done]), past_key_values=None)
         return out[:, :n_done]
 
     def _generate_beams(self, ids, mask, pos, mm_state, max_new, num_beams, eos_list, kwargs):
