@@ -1,0 +1,74 @@
+"""Golden `forward()` outputs produced by EXECUTING THE REFERENCE'S OWN `DattnGemma2ForCausalLM.forward` (gemma.py:484-601) on CPU in fp32
+with the call shapes a user of the reference can make: `logits_to_keep` 0 / 1 / 3, images only, audios only, a right-padded batch of
+two videos, and `labels` (the loss of gemma.py:571-590 over the labels `prepare_inputs_labels_for_multimodal` re-aligns,
+multimodal.py:358-437).  Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden_forward.py
+
+writes tests/golden/reference_forward.npz, checked by tests/test_generate_api.py::test_forward_call_shapes_like_the_reference."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+OUT = os.path.join(HERE, "reference_forward.npz")
+
+import make_golden_dattn as MG  # noqa: E402
+
+IDS = [[2, 21, 22, 23, -200, 24, 25, 26, 300, 301]]
+IDS2 = [[2, 21, 22, 23, -200, 24, 25, 26, 300, 301], [2, 40, -200, 41, 0, 0, 0, 0, 0, 0]]
+AM2 = [[1] * 10, [1] * 4 + [0] * 6]
+
+
+def cases():
+    """name -> (input_ids, attention_mask, labels or None, which modalities, logits_to_keep)"""
+    ids, ids2, am2 = torch.tensor(IDS), torch.tensor(IDS2), torch.tensor(AM2, dtype=torch.bool)
+    ones = torch.ones_like(ids, dtype=torch.bool)
+    lab = torch.where(ids == 23, torch.full_like(ids, -100), ids)
+    lab2 = torch.where(ids2 < 0, torch.full_like(ids2, -100), ids2)
+    return {"keep0": (ids, ones, None, "va", 0), "keep1": (ids, ones, None, "va", 1), "keep3": (ids, ones, None, "va", 3),
+            "images_only": (ids, ones, None, "v", 1), "audios_only": (ids, ones, None, "a", 1),
+            "batch2_right_pad": (ids2, am2, None, "va", 0), "labels": (ids, ones, lab, "va", 0), "labels_batch2": (ids2, am2, lab2, "va", 0)}
+
+
+def call_kwargs(case, px, mel):
+    ids, am, lab, which, keep = case
+    n = ids.shape[0]
+    kw = dict(input_ids=ids, attention_mask=am, logits_to_keep=keep)
+    if lab is not None:
+        kw["labels"] = lab
+    if "v" in which:
+        kw["images"] = px.repeat(n, 1, 1, 1, 1)
+    if "a" in which:
+        kw["audios"] = mel.repeat(n, 1, 1, 1)
+        kw["audio_sizes"] = [100] * n
+    return kw
+
+
+def main():
+    from vidi_amd.weights import init_random_weights
+    cfg = MG.golden_config()
+    model, _ = MG.build_reference_model(cfg)
+    MG.load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
+    d = np.load(os.path.join(HERE, "reference_dattn.npz"))
+    px, mel = torch.from_numpy(d["A_images"]), torch.from_numpy(d["A_audios"])
+    res = {}
+    for name, case in cases().items():
+        with torch.no_grad():
+            o = model.forward(**call_kwargs(case, px, mel))
+        res[name + "_logits"] = o.logits.float().numpy()
+        if o.loss is not None:
+            res[name + "_loss"] = np.array([float(o.loss)])
+        print(name, tuple(o.logits.shape), None if o.loss is None else float(o.loss))
+    np.savez_compressed(OUT, **res)
+    print("wrote", OUT, f"{os.path.getsize(OUT) / 1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,39 @@ def strip_image_token(input_ids: torch.Tensor, attention_mask: Optional[torch.Te
     return out, mask, pos
 
 
+def strip_image_labels(input_ids: torch.Tensor, labels: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                       padding_side: str = "right") -> torch.Tensor:
+    """The labels' half of the same function (multimodal.py:358-363, 379-400, 407-437): a row's labels at its attended positions, minus the
+    <image> placeholder's, re-padded with IGNORE_INDEX (-100) on the side `strip_image_token` pads."""
+    ids_cpu, lab_cpu = input_ids.detach().cpu(), labels.detach().cpu()
+    am = torch.ones_like(ids_cpu, dtype=torch.bool) if attention_mask is None else attention_mask.detach().cpu().bool()
+    rows = [lab[m][row[m] != IMAGE_TOKEN_INDEX] for row, lab, m in zip(ids_cpu, lab_cpu, am)]
+    L = max(int(r.shape[0]) for r in rows)
+    out = torch.full((len(rows), L), IGNORE_INDEX, dtype=torch.int64)
+    for i, r in enumerate(rows):
+        n = int(r.shape[0])
+        if n:
+            if padding_side == "left":
+                out[i, -n:] = r
+            else:
+                out[i, :n] = r
+    return out
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor, loss_thres: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """gemma.py:571-590: fp32 logits flattened to [B * L, V] (that flattened tensor is also what the reference RETURNS as `.logits` when
+    labels are given), labels shifted by one with IGNORE_INDEX at the end, mean cross-entropy over the counted positions — or, with
+    `config.loss_thres`, over the positions whose loss exceeds it (all of them when none does).  -> (loss, flattened logits)"""
+    import torch.nn.functional as F
+    flat = logits.float().reshape(-1, logits.shape[-1])
+    shift = F.pad(labels.to(flat.device), (0, 1), value=IGNORE_INDEX)[..., 1:].reshape(-1)
+    if loss_thres is not None:
+        per = F.cross_entropy(flat, shift, ignore_index=IGNORE_INDEX, reduction="none")
+        thres = 0.0 if bool(torch.all(per < loss_thres)) else loss_thres
+        return torch.mean(per[per > thres]), flat
+    return F.cross_entropy(flat, shift, ignore_index=IGNORE_INDEX, reduction="mean"), flat
+
+
 class _Inner:
     """what `model.get_model()` returns in the reference (DattnGemma2MMModel)"""
 
@@ -499,7 +532,7 @@ class VidiForCausalLM:
     @torch.no_grad()
     def forward(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 images=None, audios=None, audio_sizes=None, mm_state: Optional[MMState] = None,
-                logits_to_keep: int = 0, **kwargs) -> DattnCausalLMOutputWithPast:
+                logits_to_keep: int = 0, labels: Optional[torch.Tensor] = None, **kwargs) -> DattnCausalLMOutputWithPast:
         eng = self.engine
         if mm_state is None and self._n_videos(images, audios) > 1:
             # one video per row: rows are independent -> run them one by one, unpadded, and lay the logits back out in the
@@ -523,7 +556,10 @@ class VidiForCausalLM:
             for i, o in enumerate(outs):
                 full[i, : o.shape[0]] = o                                         # right padding (multimodal.py:423-432)
             keep = full if logits_to_keep == 0 else full[:, -logits_to_keep:]
-            return DattnCausalLMOutputWithPast(logits=keep, past_key_values=[s[0] for s in states],
+            loss = None
+            if labels is not None:
+                loss, keep = causal_lm_loss(keep, strip_image_labels(input_ids, labels, attention_mask), getattr(self.config, "loss_thres", None))
+            return DattnCausalLMOutputWithPast(loss=loss, logits=keep, past_key_values=[s[0] for s in states],
                                                past_image_key_values=[s[1] for s in states],
                                                past_audio_key_values=[s[1] for s in states])
         ids, mask, pos = strip_image_token(input_ids, attention_mask)
@@ -536,12 +572,11 @@ class VidiForCausalLM:
         hn = hn.view(B, L, -1)
         keep = hn if logits_to_keep == 0 else hn[:, -logits_to_keep:]
         Bk, Lk, H = keep.shape
-        from . import hip
-        flat = keep.reshape(Bk * Lk, H).contiguous()
-        logits = hip.gemm(flat, eng.lm_head, None) if flat.shape[0] > 8 else hip.gemv(flat, eng.lm_head)
-        idx = torch.empty((Bk * Lk,), dtype=torch.int64, device=eng.dev)
-        hip.softcap_argmax(logits, idx, self.config.final_logit_softcapping, eng.argmax_workspace(Bk * Lk))
-        return DattnCausalLMOutputWithPast(logits=logits.view(Bk, Lk, -1), past_key_values=ts,
+        logits = eng.logits_argmax(keep.reshape(Bk * Lk, H).contiguous())[0].view(Bk, Lk, -1)      # lm_head + final softcap (gemma.py:562-569)
+        loss = None
+        if labels is not None:
+            loss, logits = causal_lm_loss(logits, strip_image_labels(input_ids, labels, attention_mask), getattr(self.config, "loss_thres", None))
+        return DattnCausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=ts,
                                            past_image_key_values=mm_state, past_audio_key_values=mm_state)
 
     __call__ = forward
