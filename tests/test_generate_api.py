@@ -167,3 +167,10 @@ def test_forward_call_shapes_like_the_reference():
             assert abs(float(o.loss) - float(gold[name + "_loss"][0])) < 1e-5, name
         else:
             assert o.loss is None
+
+
+def test_num_return_sequences_without_beams_follows_hf():
+    model = golden_model(6)
+    ids = torch.tensor(GOLD["cases"][0]["input_ids"], dtype=torch.int64)
+    with pytest.raises(ValueError, match="num_return_sequences"):
+        model.generate(ids, do_sample=False, num_return_sequences=2, max_new_tokens=2, **golden_video(1))

@@ -331,6 +331,10 @@ class VidiForCausalLM:
         num_beams = int(kwargs.get("num_beams", None) or 1)
         if num_beams > 1 and do_sample:
             raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
+        n_ret = int(kwargs.get("num_return_sequences", None) or 1)
+        if num_beams == 1 and n_ret > 1 and not do_sample:
+            raise ValueError("Greedy methods (do_sample != True) without beam search do not support `num_return_sequences` different than 1 "
+                             f"(got {n_ret}).")                                    # HF's own rule
         if num_beams > 1 and kwargs.get("streamer") is not None:
             raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")   # HF's own rule
         max_new = kwargs.get("max_new_tokens", None)
@@ -393,6 +397,10 @@ class VidiForCausalLM:
         ids, mask, pos = strip_image_token(inputs, attention_mask)
         if num_beams > 1:
             return self._generate_beams(ids, mask, pos, mm_state, max_new, num_beams, eos_list, kwargs)
+        if n_ret > 1:
+            # sampling with several answers per prompt: HF expands every row `num_return_sequences` times before the prefill
+            # (`_expand_inputs_for_generation`) and draws all rows of a step in one multinomial call — same here, same draws
+            ids, mask, pos = (t.repeat_interleave(n_ret, dim=0) for t in (ids, mask, pos))
         ts, last = self._prefill(ids, mask, pos, mm_state, max_new)
         B = ids.shape[0]
         out = torch.full((B, max_new), int(pad), dtype=torch.int64, device=eng.dev)
