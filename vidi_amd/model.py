@@ -16,12 +16,12 @@ import os
 
 from dataclasses import dataclass
 from types import SimpleNamespace
-from typing import Any, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Optional, Sequence, Tuple
 
 import torch
 
 from .config import VidiConfig
-from .engine import MMState, TextState, VidiEngine
+from .engine import MMState, VidiEngine
 
 IGNORE_INDEX = -100
 IMAGE_TOKEN_INDEX = -200
