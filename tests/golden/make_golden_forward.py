@@ -53,19 +53,29 @@ def call_kwargs(case, px, mel):
 
 def main():
     from vidi_amd.weights import init_random_weights
-    cfg = MG.golden_config()
-    model, _ = MG.build_reference_model(cfg)
-    MG.load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
-    d = np.load(os.path.join(HERE, "reference_dattn.npz"))
-    px, mel = torch.from_numpy(d["A_images"]), torch.from_numpy(d["A_audios"])
+    import make_golden_dattn_7b as MG7
     res = {}
-    for name, case in cases().items():
-        with torch.no_grad():
-            o = model.forward(**call_kwargs(case, px, mel))
-        res[name + "_logits"] = o.logits.float().numpy()
-        if o.loss is not None:
-            res[name + "_loss"] = np.array([float(o.loss)])
-        print(name, tuple(o.logits.shape), None if o.loss is None else float(o.loss))
+    # Vidi-7B (mistral.py:503-627: the same loss code, no `logits_to_keep` argument — transformers 4.44; single rows: its attention rejects right padding)
+    for tag, mod, npz, only in (("", MG, "reference_dattn.npz", None), ("7b_", MG7, "reference_dattn_7b.npz", ("keep0", "labels"))):
+        cfg = mod.golden_config()
+        model, _ = mod.build_reference_model(cfg)
+        mod.load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
+        d = np.load(os.path.join(HERE, npz))
+        px, mel = torch.from_numpy(d["A_images"]), torch.from_numpy(d["A_audios"])
+        for name, case in cases().items():
+            if only is not None and name not in only:
+                continue
+            kw = call_kwargs(case, px, mel)
+            if tag:
+                kw.pop("logits_to_keep")
+                kw["input_ids"] = torch.where(kw["input_ids"] == 2, torch.ones_like(kw["input_ids"]), kw["input_ids"])      # BOS = 1
+            with torch.no_grad():
+                o = model.forward(**kw)
+            if o.logits is not None:                                   # Vidi-7B returns no logits with labels (mistral.py:587-588)
+                res[tag + name + "_logits"] = o.logits.float().numpy()
+            if o.loss is not None:
+                res[tag + name + "_loss"] = np.array([float(o.loss)])
+            print(tag + name, None if o.logits is None else tuple(o.logits.shape), None if o.loss is None else float(o.loss))
     np.savez_compressed(OUT, **res)
     print("wrote", OUT, f"{os.path.getsize(OUT) / 1e3:.0f} kB")
 

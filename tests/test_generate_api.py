@@ -145,28 +145,43 @@ def test_return_dict_scores_and_max_length_like_the_reference():
         model.generate(ids, do_sample=False, max_length=n_prompt, **golden_video(1))
 
 
-def test_forward_call_shapes_like_the_reference():
+@pytest.mark.parametrize("arch", ["vidi15", "vidi7b"])
+def test_forward_call_shapes_like_the_reference(arch):
     """`forward()` as a user of the reference can call it (tests/golden/make_golden_forward.py ran the reference's own forward): logits
     for `logits_to_keep` 0 / 1 / 3, one modality alone, a right-padded two-video batch (valid positions; the reference's pad slots are
-    unspecified), and `labels` -> the reference's loss AND its flattened fp32 `.logits`"""
+    unspecified), and `labels` -> the reference's loss AND its flattened fp32 `.logits` (Vidi-7B: no logits with labels, no
+    `logits_to_keep`)"""
     import make_golden_forward as MF
     gold = np.load(os.path.join(HERE, "golden", "reference_forward.npz"))
-    model = golden_model(6)
-    v = golden_video(1)
+    tag = "7b_" if arch == "vidi7b" else ""
+    model = golden_model(6, arch)
+    v = golden_video(1, arch)
+    seen = 0
     for name, case in MF.cases().items():
-        o = model.forward(**MF.call_kwargs(case, v["images"], v["audios"]))
-        want = torch.from_numpy(gold[name + "_logits"])
-        got = o.logits.float()
-        assert got.shape == want.shape, name
-        if "batch2" in name:                                           # row 1 has 3 embedded positions; beyond them the reference holds pad-slot values
-            L = want.shape[-2] // 2 if want.dim() == 2 else want.shape[1]
-            got, want = got.reshape(2, L, -1), want.reshape(2, L, -1)
-            got, want = torch.cat((got[0], got[1, :3])), torch.cat((want[0], want[1, :3]))
-        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=5e-6, err_msg=name)
-        if name + "_loss" in gold:
-            assert abs(float(o.loss) - float(gold[name + "_loss"][0])) < 1e-5, name
+        if tag + name + "_logits" not in gold and tag + name + "_loss" not in gold:
+            continue
+        seen += 1
+        kw = MF.call_kwargs(case, v["images"], v["audios"])
+        if tag:
+            kw.pop("logits_to_keep")
+            kw["input_ids"] = torch.where(kw["input_ids"] == 2, torch.ones_like(kw["input_ids"]), kw["input_ids"])
+        o = model.forward(**kw)
+        if tag + name + "_logits" not in gold:
+            assert o.logits is None, name
+        else:
+            want = torch.from_numpy(gold[tag + name + "_logits"])
+            got = o.logits.float()
+            assert got.shape == want.shape, name
+            if "batch2" in name:                                       # row 1 has 3 embedded positions; beyond them the reference holds pad-slot values
+                L = want.shape[-2] // 2 if want.dim() == 2 else want.shape[1]
+                got, want = got.reshape(2, L, -1), want.reshape(2, L, -1)
+                got, want = torch.cat((got[0], got[1, :3])), torch.cat((want[0], want[1, :3]))
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=5e-6, err_msg=name)
+        if tag + name + "_loss" in gold:
+            assert abs(float(o.loss) - float(gold[tag + name + "_loss"][0])) < 1e-5, name
         else:
             assert o.loss is None
+    assert seen == (2 if tag else 8)
 
 
 def test_num_return_sequences_without_beams_follows_hf():

@@ -584,6 +584,10 @@ class VidiForCausalLM:
         loss = None
         if labels is not None:
             loss, logits = causal_lm_loss(logits, strip_image_labels(input_ids, labels, attention_mask), getattr(self.config, "loss_thres", None))
+        if eng.mistral:
+            # Vidi-7B (mistral.py:586-616): the same mean cross-entropy (over the positions that are not IGNORE_INDEX) but NO logits when
+            # labels are given, and fp32 logits otherwise
+            logits = None if labels is not None else logits.float()
         return DattnCausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=ts,
                                            past_image_key_values=mm_state, past_audio_key_values=mm_state)
 
