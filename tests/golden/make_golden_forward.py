@@ -51,6 +51,22 @@ def call_kwargs(case, px, mel):
     return kw
 
 
+SEAM_NAMES = ("input_ids", "position_ids", "attention_mask", "past_key_values", "inputs_embeds", "labels", "image_embeds", "image_attention_mask",
+              "audio_embeds", "audio_attention_mask")
+
+
+def seam_inputs(cfg):
+    S, M, Fr = cfg.vis_image_size, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames
+    g = torch.Generator().manual_seed(5)
+    px = (torch.randn((2, 3, 3, S, S), generator=g) * 0.5).clamp(-1, 1)
+    mel = torch.randn((2, 2, M, Fr), generator=g) * 0.3
+    px[1, 2] = 0
+    ids = torch.tensor([[2, 21, -200, 22, 23, 24], [2, 30, 31, -200, 0, 0]])
+    am = torch.tensor([[1] * 6, [1] * 4 + [0] * 2], dtype=torch.bool)
+    return dict(images=px, audios=mel, audio_sizes=[130, 60], input_ids=ids, attention_mask=am, labels=torch.where(ids < 0, torch.full_like(ids, -100), ids),
+                position_ids=torch.arange(6)[None].repeat(2, 1))
+
+
 def main():
     from vidi_amd.weights import init_random_weights
     import make_golden_dattn_7b as MG7
@@ -76,6 +92,22 @@ def main():
             if o.loss is not None:
                 res[tag + name + "_loss"] = np.array([float(o.loss)])
             print(tag + name, None if o.logits is None else tuple(o.logits.shape), None if o.loss is None else float(o.loss))
+    # ---- the inner seams: encode_videos (multimodal.py:254-265) and prepare_inputs_labels_for_multimodal (:339-451) on a
+    # batch of two videos of different audio lengths, one with an all-zero frame, a right-padded prompt batch, labels and position ids
+    cfg = MG.golden_config()
+    model, _ = MG.build_reference_model(cfg)
+    MG.load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
+    s = seam_inputs(cfg)
+    with torch.no_grad():
+        ev = model.encode_videos(s["images"], s["audios"], s["audio_sizes"])
+        pr = model.prepare_inputs_labels_for_multimodal(s["input_ids"], s["position_ids"], s["attention_mask"], None, s["labels"], s["images"], None,
+                                                        s["audios"], s["audio_sizes"])
+    for n, t in zip(("img", "imask", "aud", "amask"), ev):
+        res["seam_encode_" + n] = t.float().numpy() if t.dtype != torch.bool else t.numpy()
+    for n, t in zip(SEAM_NAMES, pr):
+        if t is not None:
+            res["seam_prepare_" + n] = t.detach().float().numpy() if t.is_floating_point() else t.numpy()
+    print("seams:", [k for k in res if k.startswith("seam_")])
     np.savez_compressed(OUT, **res)
     print("wrote", OUT, f"{os.path.getsize(OUT) / 1e3:.0f} kB")
 

@@ -595,7 +595,7 @@ class VidiForCausalLM:
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
                                              images, image_sizes, audios, audio_sizes):
-        """multimodal.py:339-451 signature; returns the same 10-tuple (labels untouched: inference only)."""
+        """multimodal.py:339-451 signature; returns the same 10-tuple (labels re-aligned with the embedded positions, IGNORE_INDEX at pads)."""
         if input_ids.shape[1] == 1:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels, None, None
         ids, mask, pos = strip_image_token(input_ids, attention_mask)
@@ -603,8 +603,9 @@ class VidiForCausalLM:
         # raw embed_tokens output like the reference (multimodal.py:372-432): the sqrt(H) normalizer is the decoder's (gemma.py:353-356)
         emb = eng.embed_tokens(ids.to(eng.dev), normalize=False).view(ids.shape[0], ids.shape[1], -1)
         fi, mi, fa, ma = self.encode_videos(images, audios, audio_sizes)
+        new_labels = None if labels is None else strip_image_labels(input_ids, labels, attention_mask).to(labels.device)
         return (None, pos if position_ids is not None else None, mask if attention_mask is not None else None,
-                past_key_values, emb, labels, fi, mi, fa, ma)
+                past_key_values, emb, new_labels, fi, mi, fa, ma)
 
 
 def load_pretrained_model(model_name_or_path: str, load_8bit: bool = False, load_4bit: bool = False, device_map: str = "auto",
