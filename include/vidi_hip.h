@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VIDI_ABI_VERSION 2 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state) */
+#define VIDI_ABI_VERSION 3 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny */
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
 #define VIDI_DT_F32 2 /* output type of the preprocessing kernels only */
@@ -116,6 +116,15 @@ int vidi_gemm_kv_cache(const void* X, const void* W, void* Kc, void* Vtc, void* 
  * lm_head (gemma.py:565) at Lq = 1. */
 int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy,
               int dtype, void* stream);
+/* Projection of a FEW rows (8 < M <= 128: the text prompt at prefill — HF Gemma2Attention q/k/v/o and Gemma2MLP down_proj through
+ * gemma.py:165-175, 116-123 at Lq > 1; vidi_gemm serves any M, this entry point streams the weights at several times its rate for
+ * these M): Y[M,N] = X W^T (+ bias), split-K with fp32 partial sums in the caller's workspace, rounded once.
+ * vidi_gemm_skinny_workspace_bytes: bytes of `workspace` for (M, N, K), or 0 when the shape is not taken (M outside 1..128, N % 64,
+ * K % 256) — then call vidi_gemm.  The library keeps no state: the workspace must stay untouched until the call's work on `stream`
+ * is done. */
+size_t vidi_gemm_skinny_workspace_bytes(int M, int N, int K);
+int vidi_gemm_skinny(const void* X, const void* W, const void* bias, void* Y, void* workspace, int M, int N, int K, int ldx, int ldw,
+                     int ldy, int dtype, void* stream);
 /* Skinny gated-MLP front half (M <= 8): Y[m][i] = T( T(act(T(gate_i . x_m))) * T(up_i . x_m) ) on the vidi_gemm_geglu weight
  * layout (gate/up rows interleaved in blocks of 32); act = VIDI_ACT_GELU_TANH (Gemma2MLP) or VIDI_ACT_SILU (MistralMLP).
  * Same values as vidi_gemv + vidi_geglu_unpack / vidi_glu_unpack, one launch. */

@@ -28,14 +28,14 @@ def test_every_header_symbol_is_exported(lib_path):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in vidi_hip.h but not exported: {missing}"
     lib.vidi_abi_version.restype = ctypes.c_int
-    assert lib.vidi_abi_version() == 2
+    assert lib.vidi_abi_version() == 3
     lib.vidi_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in lib.vidi_build_info()
 
 
 def test_python_binding_covers_the_header(lib_path):
     from vidi_amd import hip
-    bound = set(hip.SIGNATURES) | {"vidi_abi_version", "vidi_build_info", "vidi_attn_cross_workspace_bytes", "vidi_softcap_argmax_workspace_bytes", "vidi_stat_strips"}
+    bound = set(hip.SIGNATURES) | {"vidi_abi_version", "vidi_build_info", "vidi_attn_cross_workspace_bytes", "vidi_softcap_argmax_workspace_bytes", "vidi_gemm_skinny_workspace_bytes", "vidi_stat_strips"}
     assert set(header_symbols()) == bound, set(header_symbols()) ^ bound
     lib = hip.load_library()
     assert lib.vidi_attn_cross_workspace_bytes(2, 8, 32, 256) == 2 * 8 * 32 * 258 * 4

@@ -304,6 +304,43 @@ def test_gemm_res_stats_and_finalize(hip, dt, M, N, K, cfg):
     report("finalize mean", a[:, 0], bb[:, 0], mean_tol + 1e-6, 1e-5)
     report("finalize rstd", a[:, 1], bb[:, 1], 0.0, 1e-3 if dt == torch.bfloat16 else 2e-4)
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(39, 4096, 3584), (117, 3584, 4096), (39, 3584, 14336), (9, 64, 256), (16, 128, 512), (17, 192, 768), (64, 3584, 4096),
+                                   (65, 256, 1024), (128, 1024, 2048), (1, 64, 256), (33, 8192, 3584)])
+def test_gemm_skinny(hip, dt, M, N, K):
+    """vidi_gemm_skinny (a prompt's 9..128 rows against a weight matrix, split-K, fp32 partial sums in the caller's workspace): against
+    the fp32 product of the same bf16 / fp16 operands to the output rounding, and against vidi_gemm on the same operands (both round one
+    fp32 sum per element: they may differ by the summation order only)."""
+    x = seeded((M, K), 92, dtype=dt); w = seeded((N, K), 93, 0.05, dtype=dt); b = seeded((N,), 94, dtype=dt)
+    need = hip.gemm_skinny_workspace_bytes(M, N, K)
+    assert need > 0 and need % (4 * M * N) == 0
+    ws = torch.full((need // 4 + 16,), float("nan"), dtype=torch.float32).cuda()
+    ref = x.float() @ w.float().T
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    for bias in (None, b):
+        want = ref if bias is None else ref + bias.float()
+        y = hip.gemm_skinny(dev(x), dev(w), ws, bias=None if bias is None else dev(bias))
+        assert torch.isnan(ws[need // 4:]).all()                       # nothing written past the stated workspace
+        report("skinny vs fp32", y, want, 1e-3 * float(want.abs().max()), ulp)
+        y2 = hip.gemm(dev(x), dev(w), None if bias is None else dev(bias))
+        report("skinny vs vidi_gemm", y, y2.float(), 1e-3 * float(want.abs().max()), 2 * ulp)
+    # a view with a row stride (the engine projects slices of wider buffers) and an output slice
+    xw = torch.zeros((M, K + 64), dtype=dt); xw[:, :K] = x
+    yw = torch.full((M, N + 32), 7.0, dtype=dt).cuda()
+    hip.gemm_skinny(dev(xw)[:, :K], dev(w), ws, out=yw[:, :N])
+    report("strided", yw[:, :N], ref, 1e-3 * float(ref.abs().max()), ulp)
+    assert bool((yw[:, N:] == 7.0).all())
+
+
+def test_gemm_skinny_shapes_it_does_not_take(hip):
+    assert hip.gemm_skinny_workspace_bytes(129, 4096, 3584) == 0       # rows
+    assert hip.gemm_skinny_workspace_bytes(39, 4096 + 32, 3584) == 0   # N % 64
+    assert hip.gemm_skinny_workspace_bytes(39, 4096, 3584 + 64) == 0   # K % 256
+    x = torch.zeros((39, 320), dtype=torch.bfloat16).cuda(); w = torch.zeros((64, 320), dtype=torch.bfloat16).cuda()
+    with pytest.raises(Exception, match="does not take"):
+        hip.gemm_skinny(x, w, torch.zeros(1 << 20, dtype=torch.float32).cuda())
+
+
 @pytest.mark.parametrize("N", [64, 352, 1152, 1280, 3968, 4096, 8192])
 @pytest.mark.parametrize("rows", [1, 255, 256, 257, 5000])
 def test_ln_finalize_rows_and_widths(hip, rows, N):

@@ -1,6 +1,7 @@
 // extern "C" entry points of libvidi_hip.so (declared in include/vidi_hip.h).
 #include "kernels.h"
 #include "attn_text_decode.h"
+#include "gemm_skinny_api.h"
 #include <stdlib.h>
 #include "../../include/vidi_hip.h"
 
@@ -144,6 +145,22 @@ int vidi_gemm_res_stats(const void* X, const void* W, const void* bias, void* Y,
     const int rc = vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg == 5 ? -1 : tile_cfg, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
     return vidi_row_partials_dispatch(Y, part, M, N, ldy, strips, dtype, (hipStream_t)stream);
+}
+
+size_t vidi_gemm_skinny_workspace_bytes(int M, int N, int K) {
+    if (M < 1 || M > 128 || N <= 0 || K <= 0) return 0;
+    return (size_t)vidi_gemm_skinny_ksplit(N, K) * (size_t)M * (size_t)N * sizeof(float);
+}
+
+int vidi_gemm_skinny(const void* X, const void* W, const void* bias, void* Y, void* workspace, int M, int N, int K, int ldx, int ldw, int ldy,
+                     int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !W || !Y || !workspace) return VIDI_ERR_ARG;
+    if (vidi_gemm_skinny_workspace_bytes(M, N, K) == 0) return VIDI_ERR_SHAPE;
+    if ((ldx % 8) || (ldw % 8) || (ldy % 4) || ldx < K || ldw < K || ldy < N) return VIDI_ERR_ALIGN;
+    if (((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || ((uintptr_t)workspace & 15) || (bias && ((uintptr_t)bias & 1))) return VIDI_ERR_ALIGN;
+    const int rc = vidi_gemm_skinny_dispatch(X, W, bias, Y, (float*)workspace, M, N, K, ldx, ldw, ldy, dtype, (hipStream_t)stream);
+    return rc == -100 ? VIDI_ERR_SHAPE : rc;
 }
 
 int vidi_stat_strips(int N) { return N > 0 ? vidi_w4n_stat_strips(N) : 0; }

@@ -135,6 +135,7 @@ class VidiEngine:
         self.stream_norm2 = os.environ.get("VIDI_STREAM_NORM2", "1") != "0"
         # decode step: rope + cache append + T2T as one launch (VIDI_DECODE_ATTN=0: rope_cache + attn_text), T2V + T2A partial passes as
         # one launch (VIDI_CROSS_DUAL=0: one launch per modality) — the A/B arms of tools/ab_decode.py
+        self.skinny_gemm = os.environ.get("VIDI_SKINNY_GEMM", "1") != "0"      # prompts of 9..128 rows: csrc/gemm_skinny.h instead of the tile GEMM
         self.decode_attn = os.environ.get("VIDI_DECODE_ATTN", "1") != "0"
         self.cross_dual = os.environ.get("VIDI_CROSS_DUAL", "1") != "0"
         # decode step: the Gemma2 norm pairs folded into the gate/up and the next layer's q/k/v projections (VIDI_DECODE_NORM_GEMV=0:
@@ -319,9 +320,15 @@ class VidiEngine:
         return t[:n].view(*shape)
 
     def proj(self, x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """bias-free projection: weight-streaming GEMV for M<=8 (decode), MFMA GEMM otherwise."""
-        if x.shape[0] <= 8:
+        """bias-free projection: weight-streaming GEMV for M <= 8 (decode), the split-K weight-streaming MFMA kernel for a prompt's
+        9..128 rows (VIDI_SKINNY_GEMM=0: the tile GEMM, the A/B arm), the tile / persistent MFMA GEMM otherwise."""
+        M = x.shape[0]
+        if M <= 8:
             return hip.gemv(x, w, out)
+        if M <= 128 and self.skinny_gemm:
+            need = hip.gemm_skinny_workspace_bytes(M, w.shape[0], x.shape[1])
+            if need:
+                return hip.gemm_skinny(x, w, self._buf("skinny_ws", (need // 4,), torch.float32), out)
         return hip.gemm(x, w, None, out)
 
     def sample_flag(self, x: torch.Tensor) -> torch.Tensor:

@@ -38,6 +38,7 @@ SIGNATURES = {
     "vidi_ln_finalize": [_c_vp, _c_vp, _c_ll, _c_int, _c_f, _c_vp],
     "vidi_gemm_qkv_vt_ln": [_c_vp] * 7 + [_c_int] * 13 + [_c_vp],
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
+    "vidi_gemm_skinny": [_c_vp] * 5 + [_c_int] * 7 + [_c_vp],
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemv_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
     "vidi_gemv_glu_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
@@ -99,6 +100,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.vidi_attn_cross_workspace_bytes.argtypes = [_c_int] * 4
     lib.vidi_softcap_argmax_workspace_bytes.restype = ctypes.c_size_t
     lib.vidi_softcap_argmax_workspace_bytes.argtypes = [_c_int]
+    lib.vidi_gemm_skinny_workspace_bytes.restype = ctypes.c_size_t
+    lib.vidi_gemm_skinny_workspace_bytes.argtypes = [_c_int] * 3
     lib.vidi_stat_strips.restype = _c_int
     lib.vidi_stat_strips.argtypes = [_c_int]
     for name, args in SIGNATURES.items():
@@ -123,6 +126,8 @@ def _work(name, a):
         return "gemm", 2.0 * a[5] * a[6] * a[7] * a[16], "flop"
     if name == "vidi_gemm_geglu":
         return "gemm", 2.0 * a[3] * (2 * a[4]) * a[5], "flop"
+    if name == "vidi_gemm_skinny":
+        return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
     if name == "vidi_patch_embed":                      # the convolution's products: T (S/P)^2 patches x N x 3 P^2 (not the loader's padded K)
         return "gemm", 2.0 * a[5] * (a[6] // a[7]) ** 2 * a[8] * 3 * a[7] * a[7], "flop"
     if name == "vidi_conv_window":                      # T (side-k+1)^2 outputs x N x k^2 C
@@ -174,6 +179,8 @@ def _alg_bytes(name, a):
         return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6]) * a[16]
     if name == "vidi_gemm_geglu":
         return 2.0 * (a[3] * a[5] + 2 * a[4] * a[5] + a[3] * a[4])
+    if name == "vidi_gemm_skinny":
+        return 2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6])
     if name == "vidi_conv_window":                      # features + weight + output
         return 2.0 * (a[3] * a[4] * a[4] * a[5] + a[7] * a[6] * a[6] * a[5] + a[3] * (a[4] - a[6] + 1) ** 2 * a[7])
     if name == "vidi_patch_embed":                      # pixels + weight + output
@@ -403,6 +410,31 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     _check(lib.vidi_gemv(_p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _dt(x), _stream()), "vidi_gemv")
+    return out
+
+
+def gemm_skinny_workspace_bytes(M: int, N: int, K: int) -> int:
+    """bytes of fp32 split-K workspace vidi_gemm_skinny needs for (M, N, K); 0: the shape is not taken (use gemm / gemv)"""
+    lib = load_library()
+    return int(lib.vidi_gemm_skinny_workspace_bytes(int(M), int(N), int(K)))
+
+
+def gemm_skinny(x: torch.Tensor, w: torch.Tensor, workspace: torch.Tensor, out: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x @ w.T (+ bias) for 1 <= M <= 128 rows: split-K weight streaming (csrc/gemm_skinny.h); `workspace`: a tensor of at least
+    gemm_skinny_workspace_bytes(M, N, K) bytes owned by the caller (the library keeps no state)"""
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0]
+    need = gemm_skinny_workspace_bytes(M, N, K)
+    if need == 0:
+        raise VidiHipError(f"vidi_gemm_skinny does not take M={M}, N={N}, K={K}")
+    if workspace.numel() * workspace.element_size() < need:
+        raise VidiHipError(f"vidi_gemm_skinny: workspace of {workspace.numel() * workspace.element_size()} bytes, {need} needed")
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _check(lib.vidi_gemm_skinny(_p(x), _p(w), _p(bias), _p(out), _p(workspace), M, N, K, x.stride(0), w.stride(0), out.stride(0), _dt(x), _stream()),
+           "vidi_gemm_skinny")
     return out
 
 
