@@ -327,7 +327,10 @@ class VidiEngine:
             return hip.gemv(x, w, out)
         if M <= 128 and self.skinny_gemm:
             need = hip.gemm_skinny_workspace_bytes(M, w.shape[0], x.shape[1])
-            if need:
+            have = self._ws.get("skinny_ws")
+            # (a workspace that would have to be allocated in the middle of a graph capture — a decode step of 9+ rows whose prefill ran on
+            # the tile kernel: stay on the tile kernel for that step)
+            if need and ((have is not None and have.numel() * 4 >= need) or not torch.cuda.is_current_stream_capturing()):
                 return hip.gemm_skinny(x, w, self._buf("skinny_ws", (need // 4,), torch.float32), out)
         return hip.gemm(x, w, None, out)
 
