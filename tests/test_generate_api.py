@@ -219,3 +219,16 @@ def test_inner_seams_like_the_reference():
                 assert np.array_equal(t.numpy().astype(want.dtype), want), n
         else:
             np.testing.assert_allclose(t.float().numpy(), want.astype(np.float32), rtol=0, atol=2e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("kw", [dict(min_p=0.1, do_sample=True), dict(typical_p=0.5, do_sample=True), dict(num_beam_groups=2, num_beams=4, diversity_penalty=0.5),
+                                dict(penalty_alpha=0.6, top_k=4), dict(begin_suppress_tokens=[5]), dict(forced_eos_token_id=7), dict(renormalize_logits=True),
+                                dict(sequence_bias={(5,): -1.0}), dict(stop_strings=["."])], ids=lambda k: next(iter(k)))
+def test_generation_arguments_without_a_counterpart_are_refused_not_ignored(kw):
+    model = golden_model(6)
+    ids = torch.tensor(GOLD["cases"][0]["input_ids"], dtype=torch.int64)
+    with pytest.raises(NotImplementedError, match=next(iter(kw))):
+        model.generate(ids, max_new_tokens=2, **golden_video(1), **kw)
+    # the neutral values pass
+    t = model.generate(ids, max_new_tokens=2, typical_p=1.0, num_beam_groups=1, renormalize_logits=False, min_p=None, **golden_video(1))
+    assert t.shape == (1, 2)

@@ -102,6 +102,17 @@ def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor, loss_thres: Optio
     return F.cross_entropy(flat, shift, ignore_index=IGNORE_INDEX, reduction="mean"), flat
 
 
+# HF `GenerationConfig` fields with their neutral values: arguments that alter the decoding and have no counterpart here
+_UNSUPPORTED_GENERATION_KWARGS = {
+    "min_p": None, "typical_p": 1.0, "epsilon_cutoff": 0.0, "eta_cutoff": 0.0, "top_h": None, "num_beam_groups": 1, "diversity_penalty": 0.0,
+    "penalty_alpha": None, "dola_layers": None, "encoder_repetition_penalty": 1.0, "begin_suppress_tokens": None, "forced_bos_token_id": None,
+    "forced_eos_token_id": None, "exponential_decay_length_penalty": None, "sequence_bias": None, "renormalize_logits": False,
+    "guidance_scale": None, "watermarking_config": None, "prompt_lookup_num_tokens": None, "assistant_model": None, "constraints": None,
+    "force_words_ids": None, "prefix_allowed_tokens_fn": None, "remove_invalid_values": False, "token_healing": False, "stop_strings": None,
+    "encoder_no_repeat_ngram_size": 0,
+}
+
+
 class _Inner:
     """what `model.get_model()` returns in the reference (DattnGemma2MMModel)"""
 
@@ -327,6 +338,13 @@ class VidiForCausalLM:
         the reference CLI uses do_sample=False, one beam."""
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")            # gemma.py:615-616
+        # HF generation arguments that WOULD change the output and that this loop does not implement: refuse them instead of ignoring them
+        # (anything a caller needs from this list can be handed over as a ready `logits_processor` / `stopping_criteria` object)
+        for k in _UNSUPPORTED_GENERATION_KWARGS:
+            v = kwargs.get(k, None)
+            if v is not None and v is not False and v != _UNSUPPORTED_GENERATION_KWARGS[k]:
+                raise NotImplementedError(f"generate(): `{k}` is not implemented by the MI355X path (pass an equivalent `logits_processor` / "
+                                          "`stopping_criteria` object, or use the arguments listed in INTEGRATION.md section 5)")
         do_sample = bool(kwargs.get("do_sample", False))
         num_beams = int(kwargs.get("num_beams", None) or 1)
         if num_beams > 1 and do_sample:
