@@ -101,7 +101,9 @@ def _worker(rank, world, port, frames, windows, audio_size, ret, over=None):
         out = model.generate(bids, mm_state=mm, attention_mask=bmask, max_new_tokens=4, do_sample=False)
         smp = model.generate(bids[:2], mm_state=mm, attention_mask=bmask[:2], max_new_tokens=4, do_sample=True, top_k=5,
                              generator=torch.Generator().manual_seed(1000 + rank))
-        ret.put((rank, out.tolist(), smp.tolist()))
+        # beam search over the sharded video: the beams' text caches are re-gathered on every rank alike (replicated text stream)
+        bm = model.generate(bids[:2], mm_state=mm, attention_mask=bmask[:2], max_new_tokens=4, num_beams=3, num_return_sequences=2)
+        ret.put((rank, out.tolist(), smp.tolist(), bm.tolist()))
     else:
         out = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=5, do_sample=False)
         ret.put((rank, out.tolist(), getattr(eng, "last_shard", None)))
@@ -162,11 +164,13 @@ def test_world8_with_the_baseline_partition_shapes(windows, clip):
 
 def test_batch_of_eight_ragged_queries_under_set_dist():
     """8 prompts of different lengths share one sharded video (world 2): greedy tokens equal the single-rank run on every rank, and a
-    SAMPLED generation ends with identical tokens on both ranks although their RNG states differ (rank 0's draw is broadcast)."""
+    SAMPLED generation ends with identical tokens on both ranks although their RNG states differ (rank 0's draw is broadcast); beam
+    search (3 beams, 2 returned per prompt) returns the single-rank sequences on every rank."""
     ref = _run(1, -5, 2, 173)[0]
     got = _run(2, -5, 2, 173)
-    for rank, toks, smp in got:
+    for rank, toks, smp, bm in got:
         assert toks == ref[1], (rank, toks, ref[1])
+        assert bm == ref[3] and len(bm) == 4, (rank, bm, ref[3])        # beam search: the single-rank sequences on every rank
     assert got[0][2] == got[1][2], (got[0][2], got[1][2])
 
 
