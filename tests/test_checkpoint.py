@@ -83,3 +83,22 @@ def test_real_checkpoint_without_tokenizer_is_an_error(tmp_path):
     with pytest.raises(Exception) as e:
         load_pretrained_model(str(tmp_path), engine_factory=lambda c, ww, dt: object())
     assert "okenizer" in str(e.value) or "tokenizer" in str(e.value).lower() or isinstance(e.value, (OSError, ValueError))
+
+
+def test_checkpoint_from_sharded_torch_pickles(tmp_path):
+    """a directory without safetensors: pytorch_model-0000x-of-0000y.bin shards (HF's older export format) load to the same tensors"""
+    cfg = C.tiny()
+    w = init_random_weights(cfg, seed=4, dtype=torch.float16)
+    write_checkpoint(str(tmp_path), cfg, w)
+    from vidi_amd.weights import load_safetensors_dir
+    sd = load_safetensors_dir(str(tmp_path))
+    for f in os.listdir(str(tmp_path)):
+        if f.endswith(".safetensors"):
+            os.remove(os.path.join(str(tmp_path), f))
+    keys = sorted(sd)
+    half = len(keys) // 2
+    torch.save({k: sd[k] for k in keys[:half]}, os.path.join(str(tmp_path), "pytorch_model-00001-of-00002.bin"))
+    torch.save({k: sd[k] for k in keys[half:]}, os.path.join(str(tmp_path), "pytorch_model-00002-of-00002.bin"))
+    sd2 = load_checkpoint(str(tmp_path), C.VidiConfig.from_pretrained(str(tmp_path)))
+    for k in weight_shapes(cfg):
+        assert torch.equal(sd2[k], w[k]), k

@@ -132,7 +132,13 @@ def load_safetensors_dir(path: str, device="cpu") -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
     if not files:
-        raise FileNotFoundError(f"no *.safetensors under {path}")
+        # older exports: pytorch_model.bin / pytorch_model-0000x-of-0000y.bin (what HF's from_pretrained falls back to, builder.py:41-43)
+        bins = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+        if not bins:
+            raise FileNotFoundError(f"no *.safetensors (or pytorch_model*.bin) under {path}")
+        for f in bins:
+            out.update(torch.load(f, map_location=str(device), weights_only=True))
+        return out
     for f in files:
         out.update(load_file(f, device=str(device)))
     return out
