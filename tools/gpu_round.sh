@@ -51,6 +51,20 @@ for l in open("gpurun_out/ab_w4n.jsonl"):
     print("VIDI_W4N", d["VIDI_W4N"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "frac", round(d["roofline"]["frac"], 4), "verify", d["verify"]["ok"], round(d["verify"]["embeds_frames_max_err"], 4), "first_token", d["first_token"])
 PY
   ;;
+abskinny)
+  # same-box ABAB of the 5-min config (text prefill is a visible share there): the prompt's projections on vidi_gemm_skinny (default) against
+  # the tile GEMM (VIDI_SKINNY_GEMM=0); `stage_ms_per_step.text_prefill` is the number to read
+  : > $OUT/ab_skinny.jsonl
+  for r in 1 2; do for sw in 0 1; do
+    VIDI_SKINNY_GEMM=$sw timeout 300 python bench.py --frames 300 --steps 5 --warmup 2 --no-cpu-baseline --no-preproc --decode-steps 4 2> $OUT/ab_skinny.err | grep '^{' | sed "s/^{/{\"VIDI_SKINNY_GEMM\": $sw, /" >> $OUT/ab_skinny.jsonl; echo "abskinny $sw rc=$?"
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/ab_skinny.jsonl"):
+    d = json.loads(l)
+    print("VIDI_SKINNY_GEMM", d["VIDI_SKINNY_GEMM"], round(d["value"]), {k: round(v, 1) for k, v in d["stage_ms_per_step"].items()}, "verify", d["verify"]["ok"], "first_token", d["first_token"])
+PY
+  ;;
 abepi)
   # same-box ABAB of the prefill: the product library (epilogue form 2) against tools/build_epi1.sh's build (form 1 everywhere, built in the container)
   : > $OUT/ab_epi.jsonl
