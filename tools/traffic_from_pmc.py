@@ -13,7 +13,7 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-PAT = re.compile(r"gemm_w4n?_kernel|gemm_kernel<|gemm_kernel\(")
+PAT = re.compile(r"gemm_w4n?_kernel|gemm_kernel<|gemm_kernel\(|skinny_kernel<")     # one kernel per vidi_gemm* call (skinny_reduce_kernel rides along uncounted: < 1 % of its launch's bytes)
 
 
 def agg(path, counter):
