@@ -88,8 +88,6 @@ def test_beam_search_argument_rules():
     ids = torch.tensor(GOLD["cases"][0]["input_ids"], dtype=torch.int64)
     with pytest.raises(ValueError, match="num_return_sequences"):
         model.generate(ids, num_beams=2, num_return_sequences=3, max_new_tokens=2, **golden_video(1))
-    with pytest.raises(NotImplementedError, match="do_sample"):
-        model.generate(ids, num_beams=2, do_sample=True, max_new_tokens=2, **golden_video(1))
     with pytest.raises(ValueError, match="streamer"):
         model.generate(ids, num_beams=2, streamer=object(), max_new_tokens=2, **golden_video(1))
 
