@@ -365,6 +365,10 @@ class VidiForCausalLM:
                                  "unexpected behavior. You should consider increasing `max_length` or, better yet, setting `max_new_tokens`.")
             kwargs = dict(kwargs, max_new_tokens=int(max_new))               # the row-by-row paths below pass it on
         max_new = int(max_new)
+        if kwargs.get("min_length"):
+            # `min_length` counts the embedded prompt too (HF's `_prepare_generated_length` under `inputs_embeds`): what is left applies to the new tokens
+            n_prompt = int(strip_image_token(inputs, kwargs.get("attention_mask", None))[0].shape[1])
+            kwargs = dict(kwargs, min_length=max(int(kwargs["min_length"]) - n_prompt, 0))
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
         eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]) if e is not None]     # HF allows a list ([1, 107] for Gemma2)
         pad = kwargs.get("pad_token_id", None)
