@@ -125,3 +125,78 @@ def test_return_dict_scores_equal_hf():
             assert torch.allclose(torch.nan_to_num(x, neginf=0.0), torch.nan_to_num(y, neginf=0.0), atol=1e-5)
         for x, y in zip(a.logits, b.logits):
             assert torch.allclose(x, y, atol=1e-5)
+
+
+class _StopOn(transformers.StoppingCriteria):
+    """stop a row once it has emitted `tok` twice"""
+
+    def __init__(self, tok):
+        self.tok = tok
+
+    def __call__(self, input_ids, scores, **kw):
+        return (input_ids == self.tok).sum(-1) >= 2
+
+
+class _Collect:
+    def __init__(self):
+        self.calls = []
+
+    def put(self, x):
+        self.calls.append(x.tolist())
+
+    def end(self):
+        self.calls.append("end")
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_hooks_padding_and_streams_equal_hf(seed):
+    """caller-supplied logits processors / stopping criteria (they see the new tokens only), a streamer's call sequence, pad / EOS
+    conventions (`pad_token_id=None` -> the first EOS), and a LEFT-padded ragged batch (HF positions from the mask; here every row is decoded
+    unpadded against the same prompt) — all against HF"""
+    lm, model = build(10 + seed)
+    g = torch.Generator().manual_seed(40 + seed)
+    prompt = torch.randint(2, V, (1, 7), generator=g)
+    LP = transformers.LogitsProcessorList
+    bad = []
+    cases = [dict(max_new_tokens=10, logits_processor=LP([transformers.SuppressTokensLogitsProcessor([2, 3, 4, 5], device="cpu")])),
+             dict(max_new_tokens=12, stopping_criteria=transformers.StoppingCriteriaList([_StopOn(int(prompt[0, 0]))])),
+             dict(max_new_tokens=12, logits_processor=LP([transformers.NoRepeatNGramLogitsProcessor(2)]), repetition_penalty=1.2, eos_token_id=[1, 8]),
+             dict(max_new_tokens=8, do_sample=True, top_k=6, logits_processor=LP([transformers.TemperatureLogitsWarper(0.5)]))]
+    for i, kw in enumerate(cases):
+        kw = dict(kw); kw.setdefault("do_sample", False)
+        a, b = hf(lm, prompt, seed=60 + i, **kw), ours(model, prompt, seed=60 + i, **kw)
+        if a.tolist() != b.tolist():
+            bad.append((kw, a.tolist(), b.tolist()))
+    # the stopping-criterion case on a batch of two different prompts: rows stop independently, finished rows are padded
+    p2 = torch.randint(2, V, (2, 7), generator=g)
+    crit = lambda: transformers.StoppingCriteriaList([_StopOn(int(p2[0, 0])), _StopOn(int(p2[1, 1]))])          # noqa: E731
+    a, b = hf(lm, p2, do_sample=False, max_new_tokens=14, stopping_criteria=crit()), ours(model, p2, do_sample=False, max_new_tokens=14, stopping_criteria=crit())
+    if a.tolist() != b.tolist():
+        bad.append(("criteria, batch 2", a.tolist(), b.tolist()))
+    # pad conventions: no pad_token_id -> HF pads finished rows with the first EOS
+    with torch.no_grad():
+        a = lm.generate(inputs_embeds=lm.transformer.wte(p2), attention_mask=torch.ones_like(p2), do_sample=False, max_new_tokens=12, eos_token_id=[int(p2[0, 0]), 1])
+    b = model.generate(p2, do_sample=False, max_new_tokens=12, eos_token_id=[int(p2[0, 0]), 1])
+    if a.tolist() != b.tolist():
+        bad.append(("pad = first EOS", a.tolist(), b.tolist()))
+    # streamer: the same sequence of put() / end() calls (B = 1: HF's streamers take one row)
+    sa, sb = _Collect(), _Collect()
+    hf(lm, prompt, do_sample=False, max_new_tokens=6, streamer=sa)
+    ours(model, prompt, do_sample=False, max_new_tokens=6, streamer=sb)
+    norm = lambda calls: [c if c == "end" else [t for row in (c if isinstance(c[0], list) else [c]) for t in row] if c else [] for c in calls]      # noqa: E731
+    if norm(sa.calls) != norm(sb.calls):
+        bad.append(("streamer", sa.calls, sb.calls))
+    # left-padded ragged batch
+    lens = [7, 4, 6]
+    rag = torch.randint(2, V, (3, 7), generator=g)
+    am = torch.zeros((3, 7), dtype=torch.long)
+    for r, n in enumerate(lens):
+        am[r, 7 - n:] = 1
+        rag[r, : 7 - n] = 0
+    with torch.no_grad():
+        pos = (am.cumsum(-1) - 1).clamp(min=0)
+        a = lm.generate(inputs_embeds=lm.transformer.wte(rag), attention_mask=am, position_ids=pos, do_sample=False, max_new_tokens=8, pad_token_id=0, eos_token_id=[1, 5])
+    b = model.generate(rag, attention_mask=am, do_sample=False, max_new_tokens=8, pad_token_id=0, eos_token_id=[1, 5])
+    if a.tolist() != b.tolist():
+        bad.append(("left-padded ragged batch", a.tolist(), b.tolist()))
+    assert not bad, f"{len(bad)} differ from HF; first: {bad[0]}"
