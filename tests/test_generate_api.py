@@ -232,3 +232,22 @@ def test_generation_arguments_without_a_counterpart_are_refused_not_ignored(kw):
     # the neutral values pass
     t = model.generate(ids, max_new_tokens=2, typical_p=1.0, num_beam_groups=1, renormalize_logits=False, min_p=None, **golden_video(1))
     assert t.shape == (1, 2)
+
+
+def test_min_length_on_a_multi_video_batch_counts_the_padded_prompt_once():
+    """HF resolves `min_length` / `max_length` once, against the batch's padded embedded prompt (`inputs_embeds.shape[1]`); the product's
+    multi-video path answers row by row and must hand each row the RESOLVED value (round 4 subtracted the row's prompt a second time)."""
+    model = golden_model(3)
+    v = golden_video(2)
+    ids = torch.tensor([[2, 21, 22, -200, 24, 25, 26, 27, 28], [2, 31, -200, 33, 34, 0, 0, 0, 0]])
+    am = torch.tensor([[1] * 9, [1] * 5 + [0] * 4])
+    n_prompt = 8                                                       # the padded batch without its <image> position
+    free = [model.generate(ids[i:i + 1, : int(am[i].sum())], images=v["images"][i:i + 1], audios=v["audios"][i:i + 1], audio_sizes=[100],
+                           do_sample=False, max_new_tokens=3) for i in range(2)]
+    eos = sorted({int(f[0, 0]) for f in free})                         # every row would stop at once: only `min_length` keeps it going
+    got = model.generate(ids, attention_mask=am, **v, do_sample=False, max_new_tokens=9, min_length=n_prompt + 5, eos_token_id=eos, pad_token_id=0)
+    for i in range(2):
+        want = model.generate(ids[i:i + 1, : int(am[i].sum())], images=v["images"][i:i + 1], audios=v["audios"][i:i + 1], audio_sizes=[100],
+                              do_sample=False, max_new_tokens=9, min_new_tokens=5, eos_token_id=eos, pad_token_id=0)
+        assert got[i, : want.shape[1]].tolist() == want[0].tolist() and want.shape[1] >= 5
+        assert not (got[i, :5].unsqueeze(-1) == torch.tensor(eos)).any()

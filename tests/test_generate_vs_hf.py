@@ -199,4 +199,16 @@ def test_hooks_padding_and_streams_equal_hf(seed):
     b = model.generate(rag, attention_mask=am, do_sample=False, max_new_tokens=8, pad_token_id=0, eos_token_id=[1, 5])
     if a.tolist() != b.tolist():
         bad.append(("left-padded ragged batch", a.tolist(), b.tolist()))
+    # ... with `min_length` / `max_length` ABOVE the prompt length: HF resolves both once against the batch's padded prompt (7 positions),
+    # not per row (the row-by-row path once subtracted each row's own length a second time)
+    with torch.no_grad():
+        free = lm.generate(inputs_embeds=lm.transformer.wte(rag), attention_mask=am, position_ids=pos, do_sample=False, max_new_tokens=4, pad_token_id=0)
+    first = sorted({int(t) for t in free[:, 0]})                # every row's favourite first token as EOS: only `min_length` keeps a row going
+    for kw in (dict(min_length=9, max_new_tokens=8, eos_token_id=first), dict(min_length=12, max_length=18, eos_token_id=first),
+               dict(min_length=14, max_new_tokens=12, eos_token_id=first + [int(free[0, 1])])):
+        with torch.no_grad():
+            a = lm.generate(inputs_embeds=lm.transformer.wte(rag), attention_mask=am, position_ids=pos, do_sample=False, pad_token_id=0, **kw)
+        b = model.generate(rag, attention_mask=am, do_sample=False, pad_token_id=0, **kw)
+        if a.tolist() != b.tolist():
+            bad.append(("left-padded ragged batch, lengths counted on the padded prompt", kw, a.tolist(), b.tolist()))
     assert not bad, f"{len(bad)} differ from HF; first: {bad[0]}"

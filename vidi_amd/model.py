@@ -353,6 +353,9 @@ class VidiForCausalLM:
                              f"(got {n_ret}).")                                    # HF's own rule
         if num_beams > 1 and kwargs.get("streamer") is not None:
             raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")   # HF's own rule
+        # the row-by-row paths below call generate() again per row with kwargs whose lengths are ALREADY resolved against the batch's padded
+        # prompt (HF resolves them once, against `inputs_embeds.shape[1]` of the whole batch): the nested call must not subtract again
+        resolved = bool(kwargs.pop("_lengths_resolved", False))
         max_new = kwargs.get("max_new_tokens", None)
         if max_new is None:
             # HF's `_prepare_generated_length` under `inputs_embeds` (how the reference drives it, gemma.py:646-655): `max_length` (default
@@ -365,10 +368,11 @@ class VidiForCausalLM:
                                  "unexpected behavior. You should consider increasing `max_length` or, better yet, setting `max_new_tokens`.")
             kwargs = dict(kwargs, max_new_tokens=int(max_new))               # the row-by-row paths below pass it on
         max_new = int(max_new)
-        if kwargs.get("min_length"):
+        if kwargs.get("min_length") and not resolved:
             # `min_length` counts the embedded prompt too (HF's `_prepare_generated_length` under `inputs_embeds`): what is left applies to the new tokens
             n_prompt = int(strip_image_token(inputs, kwargs.get("attention_mask", None))[0].shape[1])
             kwargs = dict(kwargs, min_length=max(int(kwargs["min_length"]) - n_prompt, 0))
+        kwargs = dict(kwargs)
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
         eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]) if e is not None]     # HF allows a list ([1, 107] for Gemma2)
         pad = kwargs.get("pad_token_id", None)
@@ -393,7 +397,7 @@ class VidiForCausalLM:
             budget = self._batch_frames(images)
             rows = []
             for i in range(B):
-                kw = dict(kwargs)
+                kw = dict(kwargs, _lengths_resolved=True)
                 kw["attention_mask"] = None
                 am_i = None if attention_mask is None else attention_mask[i].bool().cpu()
                 ids_i = inputs[i].cpu() if am_i is None else inputs[i].cpu()[am_i]
@@ -410,7 +414,7 @@ class VidiForCausalLM:
             # on the tokenizer's side): rows never interact, so every row is decoded unpadded against the shared video state
             rows = []
             for i in range(inputs.shape[0]):
-                kw = dict(kwargs)
+                kw = dict(kwargs, _lengths_resolved=True)
                 kw["attention_mask"] = None
                 rows.append(self.generate(inputs[i].cpu()[attention_mask[i].bool().cpu()][None], mm_state=mm_state, **kw))
             return self._stack_rows(rows, pad, kwargs)
