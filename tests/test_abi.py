@@ -28,7 +28,7 @@ def test_every_header_symbol_is_exported(lib_path):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in vidi_hip.h but not exported: {missing}"
     lib.vidi_abi_version.restype = ctypes.c_int
-    assert lib.vidi_abi_version() == 3
+    assert lib.vidi_abi_version() == 4
     lib.vidi_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in lib.vidi_build_info()
 
