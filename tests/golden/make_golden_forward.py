@@ -55,14 +55,18 @@ SEAM_NAMES = ("input_ids", "position_ids", "attention_mask", "past_key_values", 
               "audio_embeds", "audio_attention_mask")
 
 
-def seam_inputs(cfg):
+def seam_inputs(cfg, right_pad=True):
     S, M, Fr = cfg.vis_image_size, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames
     g = torch.Generator().manual_seed(5)
     px = (torch.randn((2, 3, 3, S, S), generator=g) * 0.5).clamp(-1, 1)
     mel = torch.randn((2, 2, M, Fr), generator=g) * 0.3
     px[1, 2] = 0
-    ids = torch.tensor([[2, 21, -200, 22, 23, 24], [2, 30, 31, -200, 0, 0]])
-    am = torch.tensor([[1] * 6, [1] * 4 + [0] * 2], dtype=torch.bool)
+    if right_pad:
+        ids = torch.tensor([[2, 21, -200, 22, 23, 24], [2, 30, 31, -200, 0, 0]])
+        am = torch.tensor([[1] * 6, [1] * 4 + [0] * 2], dtype=torch.bool)
+    else:
+        ids = torch.tensor([[1, 21, -200, 22, 23, 24], [1, 30, 31, -200, 24, 25]])
+        am = torch.ones((2, 6), dtype=torch.bool)
     return dict(images=px, audios=mel, audio_sizes=[130, 60], input_ids=ids, attention_mask=am, labels=torch.where(ids < 0, torch.full_like(ids, -100), ids),
                 position_ids=torch.arange(6)[None].repeat(2, 1))
 
@@ -94,19 +98,20 @@ def main():
             print(tag + name, None if o.logits is None else tuple(o.logits.shape), None if o.loss is None else float(o.loss))
     # ---- the inner seams: encode_videos (multimodal.py:254-265) and prepare_inputs_labels_for_multimodal (:339-451) on a
     # batch of two videos of different audio lengths, one with an all-zero frame, a right-padded prompt batch, labels and position ids
-    cfg = MG.golden_config()
-    model, _ = MG.build_reference_model(cfg)
-    MG.load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
-    s = seam_inputs(cfg)
-    with torch.no_grad():
-        ev = model.encode_videos(s["images"], s["audios"], s["audio_sizes"])
-        pr = model.prepare_inputs_labels_for_multimodal(s["input_ids"], s["position_ids"], s["attention_mask"], None, s["labels"], s["images"], None,
-                                                        s["audios"], s["audio_sizes"])
-    for n, t in zip(("img", "imask", "aud", "amask"), ev):
-        res["seam_encode_" + n] = t.float().numpy() if t.dtype != torch.bool else t.numpy()
-    for n, t in zip(SEAM_NAMES, pr):
-        if t is not None:
-            res["seam_prepare_" + n] = t.detach().float().numpy() if t.is_floating_point() else t.numpy()
+    for tag, mod in (("", MG), ("7b_", MG7)):
+        cfg = mod.golden_config()
+        model, _ = mod.build_reference_model(cfg)
+        mod.load_weights(model, init_random_weights(cfg, seed=6, dtype=torch.float32, device="cpu"))
+        s = seam_inputs(cfg, right_pad=not tag)               # (Vidi-7B's attention rejects right-padded batches: full rows there)
+        with torch.no_grad():
+            ev = model.encode_videos(s["images"], s["audios"], s["audio_sizes"])
+            pr = model.prepare_inputs_labels_for_multimodal(s["input_ids"], s["position_ids"], s["attention_mask"], None, s["labels"], s["images"], None,
+                                                            s["audios"], s["audio_sizes"])
+        for n, t in zip(("img", "imask", "aud", "amask"), ev):
+            res[tag + "seam_encode_" + n] = t.float().numpy() if t.dtype != torch.bool else t.numpy()
+        for n, t in zip(SEAM_NAMES, pr):
+            if t is not None:
+                res[tag + "seam_prepare_" + n] = t.detach().float().numpy() if t.is_floating_point() else t.numpy()
     print("seams:", [k for k in res if k.startswith("seam_")])
     np.savez_compressed(OUT, **res)
     print("wrote", OUT, f"{os.path.getsize(OUT) / 1e3:.0f} kB")

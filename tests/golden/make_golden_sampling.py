@@ -25,7 +25,8 @@ import make_golden_dattn as MG  # noqa: E402
 import make_golden_dattn_7b as MG7  # noqa: E402
 
 KW = [dict(), dict(temperature=0.7, top_k=20), dict(temperature=1.3, top_p=0.8), dict(top_k=5, top_p=0.9, temperature=0.9), dict(top_k=0, top_p=0.6),
-      dict(temperature=2.0, top_k=None), dict(num_return_sequences=3, top_k=10)]
+      dict(temperature=2.0, top_k=None), dict(num_return_sequences=3, top_k=10),
+      dict(num_beams=3, top_k=10), dict(num_beams=2, num_return_sequences=2, temperature=1.4, top_p=0.9)]       # beam-search multinomial sampling
 
 
 def main():

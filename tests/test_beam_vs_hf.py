@@ -63,3 +63,42 @@ def test_beam_search_equals_hf(seed):
         if not ok:
             bad.append((c, seqs.tolist(), want.tolist(), scores.tolist(), ref.sequences_scores.tolist()))
     assert not bad, f"{len(bad)} of {len(CASES)} configurations differ; first: {bad[0]}"
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_beam_sampling_equals_hf_draw_for_draw(seed):
+    """`num_beams > 1` with `do_sample=True`: HF draws a row's continuations from softmax(accumulated log-probabilities) after its warpers;
+    the same seed, the same draws (the warpers — temperature, top-k, top-p with HF's `min_tokens_to_keep = n_eos + 1` under beams — go
+    through vidi_amd.sampling.warp_logits, as in the product)."""
+    from vidi_amd.sampling import warp_logits
+    lm = tiny_lm(seed)
+    g = torch.Generator().manual_seed(200 + seed)
+    prompt = torch.randint(2, V, (2, 4), generator=g)
+    B, L = prompt.shape
+    max_new = 7
+    bad = []
+    for nb, eos, kw in itertools.product((2, 3), ([1], [1, 5]), (dict(top_k=8), dict(top_k=0, top_p=0.8, temperature=1.5), dict(top_k=12, temperature=0.7))):
+        torch.manual_seed(500 + seed)
+        with torch.no_grad():
+            ref = lm.generate(prompt, attention_mask=torch.ones_like(prompt), do_sample=True, num_beams=nb, max_new_tokens=max_new, eos_token_id=eos, pad_token_id=0,
+                              output_scores=True, return_dict_in_generate=True, **kw)
+        state = {"seq": prompt.repeat_interleave(nb, dim=0)}
+
+        def logits_of(seq):
+            with torch.no_grad():
+                return lm(seq).logits[:, -1].float()
+
+        def step(tokens, parents):
+            if parents is not None:
+                state["seq"] = state["seq"][parents]
+            state["seq"] = torch.cat((state["seq"], tokens[:, None]), dim=1)
+            return logits_of(state["seq"])
+
+        keep = max(2, len(eos) + 1)
+        warper = lambda ids, sc: warp_logits(sc, kw.get("temperature"), kw.get("top_k", 50), kw.get("top_p"), keep)        # noqa: E731
+        torch.manual_seed(500 + seed)
+        seqs, scores = beam_search(step, logits_of(state["seq"]), B, nb, V, max_new, eos, eos[0], [warper], [], 1.0, False, 1, do_sample=True)
+        want = ref.sequences[:, L:]
+        if not (seqs.shape == want.shape and torch.equal(seqs, want) and torch.allclose(scores, ref.sequences_scores, atol=1e-5, rtol=0)):
+            bad.append((nb, eos, kw, seqs.tolist(), want.tolist()))
+    assert not bad, f"{len(bad)} configurations differ; first: {bad[0]}"

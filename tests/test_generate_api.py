@@ -88,8 +88,6 @@ def test_beam_search_argument_rules():
     ids = torch.tensor(GOLD["cases"][0]["input_ids"], dtype=torch.int64)
     with pytest.raises(ValueError, match="num_return_sequences"):
         model.generate(ids, num_beams=2, num_return_sequences=3, max_new_tokens=2, **golden_video(1))
-    with pytest.raises(NotImplementedError, match="do_sample"):
-        model.generate(ids, num_beams=2, do_sample=True, max_new_tokens=2, **golden_video(1))
     with pytest.raises(ValueError, match="streamer"):
         model.generate(ids, num_beams=2, streamer=object(), max_new_tokens=2, **golden_video(1))
 
@@ -191,29 +189,31 @@ def test_num_return_sequences_without_beams_follows_hf():
         model.generate(ids, do_sample=False, num_return_sequences=2, max_new_tokens=2, **golden_video(1))
 
 
-def test_inner_seams_like_the_reference():
+@pytest.mark.parametrize("arch", ["vidi15", "vidi7b"])
+def test_inner_seams_like_the_reference(arch):
     """`encode_videos` and `prepare_inputs_labels_for_multimodal` (SURVEY 8b's inner seam) on a two-video batch with different audio lengths,
-    an all-zero frame, a right-padded prompt batch, labels and position ids: every returned tensor against the reference's own"""
+    an all-zero frame, a (right-padded, Vidi1.5) prompt batch, labels and position ids: every returned tensor against the reference's own"""
     import make_golden_forward as MF
     gold = np.load(os.path.join(HERE, "golden", "reference_forward.npz"))
-    model = golden_model(6)
-    s = MF.seam_inputs(model.config)
+    tag = "7b_" if arch == "vidi7b" else ""
+    model = golden_model(6, arch)
+    s = MF.seam_inputs(model.config, right_pad=not tag)
     ev = model.encode_videos(s["images"], s["audios"], s["audio_sizes"])
     for n, t in zip(("img", "imask", "aud", "amask"), ev):
-        want = gold["seam_encode_" + n]
+        want = gold[tag + "seam_encode_" + n]
         assert tuple(t.shape) == want.shape and (t.dtype == torch.bool) == (want.dtype == np.bool_), n
         np.testing.assert_allclose(t.float().numpy(), want.astype(np.float32), rtol=0, atol=2e-6, err_msg=n)
     pr = model.prepare_inputs_labels_for_multimodal(s["input_ids"], s["position_ids"], s["attention_mask"], None, s["labels"], s["images"], None,
                                                     s["audios"], s["audio_sizes"])
     for n, t in zip(MF.SEAM_NAMES, pr):
-        if "seam_prepare_" + n not in gold:
+        if tag + "seam_prepare_" + n not in gold:
             assert t is None, n
             continue
-        want = gold["seam_prepare_" + n]
+        want = gold[tag + "seam_prepare_" + n]
         assert tuple(t.shape) == want.shape, n
         if n in ("position_ids", "attention_mask", "labels", "image_attention_mask", "audio_attention_mask"):
             if n == "position_ids":                                     # pad slots hold unspecified positions in the reference (zeros): compare attended ones
-                m = torch.from_numpy(gold["seam_prepare_attention_mask"]).bool()
+                m = torch.from_numpy(gold[tag + "seam_prepare_attention_mask"]).bool()
                 assert torch.equal(t[m].long(), torch.from_numpy(want)[m].long())
             else:
                 assert np.array_equal(t.numpy().astype(want.dtype), want), n

@@ -38,11 +38,13 @@ def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 def beam_search(step_logits: Callable[[torch.Tensor, Union[torch.Tensor, None]], torch.Tensor], first_logits: torch.Tensor, batch: int,
                 num_beams: int, vocab: int, max_new: int, eos_ids: Sequence[int], fill: int, processors: List, criteria: List,
                 length_penalty: float = 1.0, early_stopping: Union[bool, str] = False,
-                num_return_sequences: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+                num_return_sequences: int = 1, do_sample: bool = False, generator=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """`first_logits` [batch * num_beams, vocab]: the prefill's next-token logits of the expanded rows.  `step_logits(tokens, parents)`
     feeds one token per expanded row ([batch * num_beams] int64) after re-gathering the rows' text caches from `parents` (global row
-    indices, or None when every row continues itself) and returns the next logits.  -> (sequences [batch * num_return_sequences, n],
-    their scores [batch * num_return_sequences])."""
+    indices, or None when every row continues itself) and returns the next logits.  `do_sample`: beam-search multinomial sampling — the K
+    continuations of a row are DRAWN without replacement from softmax(accumulated log-probabilities) instead of taken from its top (HF's
+    `_get_top_k_continuations`; the sampling warpers belong to `processors`, applied to the log-probabilities like every other processor).
+    -> (sequences [batch * num_return_sequences, n], their scores [batch * num_return_sequences])."""
     dev = first_logits.device
     nb, B, V = num_beams, batch, vocab
     K = max(2, 1 + len(eos_ids)) * nb
@@ -64,7 +66,11 @@ def beam_search(step_logits: Callable[[torch.Tensor, Union[torch.Tensor, None]],
         for proc in processors:
             logp = proc(flat, logp)
         acc = (logp.view(B, nb, V) + run_score[:, :, None]).reshape(B, nb * V)
-        top_lp, top_i = torch.topk(acc, K, dim=1)
+        if do_sample:
+            top_i = torch.multinomial(torch.softmax(acc, dim=-1), num_samples=K, generator=generator)
+            top_lp = torch.gather(acc, 1, top_i)
+        else:
+            top_lp, top_i = torch.topk(acc, K, dim=1)
         parent = torch.div(top_i, V, rounding_mode="floor")
         tok = top_i - parent * V
         cand = _take(run_seq, parent)

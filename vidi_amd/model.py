@@ -347,8 +347,6 @@ class VidiForCausalLM:
                                           "`stopping_criteria` object, or use the arguments listed in INTEGRATION.md section 5)")
         do_sample = bool(kwargs.get("do_sample", False))
         num_beams = int(kwargs.get("num_beams", None) or 1)
-        if num_beams > 1 and do_sample:
-            raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
         n_ret = int(kwargs.get("num_return_sequences", None) or 1)
         if num_beams == 1 and n_ret > 1 and not do_sample:
             raise ValueError("Greedy methods (do_sample != True) without beam search do not support `num_return_sequences` different than 1 "
@@ -536,6 +534,16 @@ class VidiForCausalLM:
         kw_procs, kw_crits = generation_kwargs_processors(kwargs, eos_list, eng.dev)
         processors = kw_procs + list(kwargs.get("logits_processor") or [])
         criteria = kw_crits + list(kwargs.get("stopping_criteria") or [])
+        do_sample = bool(kwargs.get("do_sample", False))
+        if do_sample:
+            # beam-search multinomial sampling: HF appends the warpers to the processors (they see the log-probabilities)
+            from .sampling import warp_logits
+            gc = self.generation_config
+            knob = lambda k: kwargs[k] if k in kwargs else getattr(gc, k, None)     # noqa: E731
+            keep = max(2, len(eos_list) + 1)                               # HF: top-k / top-p keep at least n_eos + 1 tokens under beams
+            processors = processors + [lambda input_ids, scores: warp_logits(scores, knob("temperature"), knob("top_k"), knob("top_p"), keep)]
+            if eng.world > 1:
+                raise NotImplementedError("beam-search sampling over a sharded video (every rank would draw its own continuations)")
         fill = kwargs.get("pad_token_id", None) or (eos_list[0] if eos_list else -1)
         length_penalty = kwargs.get("length_penalty", None)
 
@@ -549,7 +557,7 @@ class VidiForCausalLM:
 
         seqs, scores = beam_search(step_logits, eng.logits_argmax(last)[0], B, nb, int(self.config.vocab_size), max_new, eos_list, int(fill),
                                    processors, criteria, 1.0 if length_penalty is None else float(length_penalty),
-                                   kwargs.get("early_stopping", False) or False, nrs)
+                                   kwargs.get("early_stopping", False) or False, nrs, do_sample=do_sample, generator=kwargs.get("generator"))
         if kwargs.get("return_dict_in_generate"):
             return SimpleNamespace(sequences=seqs, sequences_scores=scores if kwargs.get("output_scores") else None)
         return seqs
