@@ -42,6 +42,37 @@ __global__ void checksum_kernel(const u16* p, size_t n, unsigned long long* out)
     atomicXor(out + 1, x);
 }
 
+// LayerNorm-fold operands of the lab: per-row (mean, rstd) of X (one thread per row, fp32), per-column sums of W, zero shift
+__global__ void rowstats_kernel(const u16* X, float* st, int M, int K, float eps) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < K; ++k) { const float v = bf16_to_f32(X[(size_t)m * K + k]); s1 += v; s2 = __builtin_fmaf(v, v, s2); }
+    const float mean = s1 / K;
+    st[2 * m] = mean; st[2 * m + 1] = rsqrtf(fmaxf(s2 / K - mean * mean, 0.f) + eps);
+}
+__global__ void colsum_kernel(const u16* W, float* cs, float* sh, int N, int K) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += bf16_to_f32(W[(size_t)n * K + k]);
+    cs[n] = s; sh[n] = 0.01f * (float)(n % 17);
+}
+// out[0] = max |a - b| (as float bits), out[1] = number of elements that differ by more than one bf16 ulp of the larger magnitude
+__global__ void ydiff_kernel(const u16* A, const u16* B, size_t n, unsigned* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float d = 0.f; unsigned bad = 0;
+    for (; i < n; i += stride) {
+        const float a = bf16_to_f32(A[i]), b = bf16_to_f32(B[i]);
+        const float e = fabsf(a - b);
+        d = fmaxf(d, e);
+        if (e > fmaxf(fabsf(a), fabsf(b)) * (1.0f / 128.0f) + 1e-3f) ++bad;
+    }
+    atomicMax(out, __float_as_uint(d));
+    atomicAdd(out + 1, bad);
+}
+
 // store-path micro-benchmark: every block writes `bytes` with 16-byte coalesced stores
 __global__ void store_kernel(u32x4* out, int chunks_per_thread) {
     u32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
@@ -133,6 +164,13 @@ static std::vector<Variant> variants() {
         {"w4p_noepi_nodma_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStampsNoEpiNoDma, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, false, 1, 4, 1},
         {"w4h_noepi_stamps", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabStampsNoEpi>, MODE_PLAIN, false, 1, 4, 1},
         {"w4h_noepi_nodma_stamps", lab_launch_w4h<Epi<true, ACT_NONE, 1>, LabStampsNoEpiNoDma>, MODE_PLAIN, false, 1, 4, 1},
+        // next step (profiles/r4_notes.md): LayerNorm statistics in the consumer's K loop (Epi::lnf == 2) against the statistics input (lnf == 1)
+        {"w4p_lnf1_bt", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_TANH, 0, 1>>, MODE_PLAIN, false, 1, 4, 5},
+        {"w4p_lnf2_bt", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_GELU_TANH, 0, 2>>, MODE_PLAIN, false, 1, 4, 6},
+        {"w4p_lnf1_noepi", lab_launch_w4<BF16, MODE_PLAIN, true, LabNoEpi, Epi<true, ACT_GELU_TANH, 0, 1>>, MODE_PLAIN, false, 1, 4, 5},
+        {"w4p_lnf2_noepi", lab_launch_w4<BF16, MODE_PLAIN, true, LabNoEpi, Epi<true, ACT_GELU_TANH, 0, 2>>, MODE_PLAIN, false, 1, 4, 6},
+        {"w4p_lnf1_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_GELU_TANH, 0, 1>>, MODE_PLAIN, false, 1, 4, 5},
+        {"w4p_lnf2_stamps", lab_launch_w4<BF16, MODE_PLAIN, true, LabStamps, Epi<true, ACT_GELU_TANH, 0, 2>>, MODE_PLAIN, false, 1, 4, 6},
         {"w4p_br_noepi_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNoEpi, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, false, 1, 4, 1},
         {"w4p_br_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1>>, MODE_PLAIN, true, 1, 4, 1},
         {"w4p_brs_o1", lab_launch_w4<BF16, MODE_PLAIN, true, LabNone, Epi<true, ACT_NONE, 1, false, true>>, MODE_PLAIN, true, 1, 4, 4},
@@ -179,6 +217,7 @@ int main(int argc, char** argv) {
     else if (set == "all") want = {"late", "late_o1", "w4s", "w4p", "w4pc", "w4p_o1", "w4pc_o1", "w4p_o1_g2", "w4p_g8", "w4p_o1_g8", "w4p_nodma", "w4p_noepi", "w4p_nostore", "late_stamps", "w4p_stamps", "late_geglu", "w4p_geglu"};
     else if (set == "w4n") want = {"w4p_br_o1", "w4n_br", "w4p_brs_o1", "w4n_brs", "w4n_brs_g8", "w4n_brs_g2", "w4n_br_noepi", "w4p_brs_o1_stamps", "w4n_brs_stamps"};
     else if (set == "w4h") want = {"w4p_br_o1", "w4h_br", "w4p_brs_o1", "w4h_brs", "w4h_br_g8", "w4p_br_noepi_o1", "w4h_br_noepi", "w4h_br_nodma", "w4h_br_stamps"};
+    else if (set == "lnstats") want = {"w4p_lnf1_bt", "w4p_lnf2_bt", "w4p_lnf1_noepi", "w4p_lnf2_noepi", "w4p_lnf1_stamps", "w4p_lnf2_stamps"};
     else if (set == "kclock") want = {"w4p_br_stamps", "w4p_noepi_stamps", "w4p_noepi_nodma_stamps", "w4h_br_stamps", "w4h_noepi_stamps", "w4h_noepi_nodma_stamps"};
     else if (set == "clock") want = {"w4p_stamps_g1", "w4p_stamps_g2", "w4p_stamps_g4", "w4p_stamps_g8", "w4p_stamps_g16", "w4p_stamps_o0g4"};
     else if (set == "orders") want = {"w4p_g1", "w4p_g2", "w4p_o1", "w4p_o1_g8", "w4p_g16", "w4p"};
@@ -219,10 +258,19 @@ int main(int argc, char** argv) {
         const size_t nx = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ny = (size_t)sh.M * sh.N;
         const size_t spn = (size_t)sh.M * (size_t)((sh.N + 127) / 128 > w4n_stat_strips(sh.N) ? (sh.N + 127) / 128 : w4n_stat_strips(sh.N)) * 8;
         CK(hipMalloc(&X, nx * 2)); CK(hipMalloc(&W, nw * 2)); CK(hipMalloc(&Y, ny * 2)); CK(hipMalloc(&R, ny * 2)); CK(hipMalloc(&Bv, (size_t)sh.N * 2)); CK(hipMalloc(&SP, spn));
+        float *LNst = nullptr, *LNs = nullptr, *LNc = nullptr; u16* Yref = nullptr;
+        const bool want_ln = set == "lnstats";
+        if (want_ln) {
+            CK(hipMalloc(&LNst, (size_t)sh.M * 8)); CK(hipMalloc(&LNs, (size_t)sh.N * 4)); CK(hipMalloc(&LNc, (size_t)sh.N * 4)); CK(hipMalloc(&Yref, ny * 2));
+        }
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, R, ny, 0x5555u, 1.0f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, Bv, (size_t)sh.N, 0x7777u, 0.5f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, nx, 0x1234u, 1.7f, zero);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 0x9876u, 0.035f, zero);
+        if (want_ln) {
+            hipLaunchKernelGGL(rowstats_kernel, dim3((sh.M + 255) / 256), dim3(256), 0, 0, X, LNst, sh.M, sh.K, 1e-6f);
+            hipLaunchKernelGGL(colsum_kernel, dim3((sh.N + 255) / 256), dim3(256), 0, 0, W, LNs, LNc, sh.N, sh.K);
+        }
         CK(hipDeviceSynchronize());
         unsigned long long ref[16][2] = {};
         bool have_ref[16] = {};
@@ -239,6 +287,11 @@ int main(int argc, char** argv) {
             if (v->epi == 2) { p.bias = Bv; p.act = ACT_GELU_TANH; }
             if (v->epi == 3) { p.bias = Bv; p.act = ACT_GELU_ERF; }
             if (v->epi == 4) { p.bias = Bv; p.R = R; p.ldr = sh.N; p.stat_part = SP; CK(hipMemset(SP, 0, spn)); }
+            if (v->epi == 5 || v->epi == 6) {
+                if (!want_ln) continue;
+                p.bias = Bv; p.act = ACT_GELU_TANH; p.ln_s = LNs; p.ln_c = LNc; p.ln_eps = 1e-6f;
+                p.ln_stats = v->epi == 5 ? LNst : nullptr;
+            }
             if (v->yonly && !w4n_takes(sh.N)) continue;
             CK(hipMemset(Y, 0xff, ny * 2));
             CK(hipMemset(dbg, 0, 1024 * 64));
@@ -250,6 +303,15 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, Y, nyo, dsum);
             if (v->epi == 4 && !v->yonly) hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, 0, (const u16*)SP, (size_t)sh.M * ((sh.N + 127) / 128) * 4, dsum);   // the statistics too
             unsigned long long cs[2]; CK(hipMemcpy(cs, dsum, 16, hipMemcpyDeviceToHost));
+            if (wn == "w4p_lnf1_bt") CK(hipMemcpy(Yref, Y, ny * 2, hipMemcpyDeviceToDevice));
+            if (wn == "w4p_lnf2_bt") {
+                unsigned* dd; CK(hipMalloc(&dd, 8)); CK(hipMemset(dd, 0, 8));
+                hipLaunchKernelGGL(ydiff_kernel, dim3(2048), dim3(256), 0, 0, Y, Yref, ny, dd);
+                unsigned hd[2]; CK(hipMemcpy(hd, dd, 8, hipMemcpyDeviceToHost)); CK(hipFree(dd));
+                float md; memcpy(&md, &hd[0], 4);
+                printf("{\"shape\": \"%s\", \"check\": \"Y of the in-loop statistics against Y with the statistics input\", \"max_abs_diff\": %.6f, \"elements_beyond_one_ulp\": %u, \"elements\": %zu}\n",
+                       sh.name, md, hd[1], ny);
+            }
             v->fn(p, 0);                                             // warm
             CK(hipEventRecord(e0));
             for (int i = 0; i < iters; ++i) v->fn(p, 0);
@@ -283,6 +345,7 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
         CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y)); CK(hipFree(R)); CK(hipFree(Bv)); CK(hipFree(SP));
+        if (want_ln) { CK(hipFree(LNst)); CK(hipFree(LNs)); CK(hipFree(LNc)); CK(hipFree(Yref)); }
     }
     return 0;
 }

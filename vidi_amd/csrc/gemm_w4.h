@@ -59,11 +59,15 @@ struct W4Geom {
 // i.e. a wait for the in-flight DMA and for all earlier stores — on the path without a residual): bias add, activation
 // (ACT_NONE / ACT_GELU_TANH / ACT_GELU_ERF), residual (0 none, 1 row m, 2 row m % rmod)
 // LNF: LayerNorm folded into the projection (GemmParams::ln_stats / ln_s / ln_c): y = rstd_m * (acc - mean_m * s_n) + c_n replaces
-// the bias add (c carries the bias)
+// the bias add (c carries the bias).  1 (true): (mean, rstd) of the rows come from GemmParams::ln_stats.  2: they are computed HERE, in the
+// K loop, from the X fragments the wave multiplies anyway (the contraction length is the LayerNorm width, so a tile sees whole rows): both
+// n-waves of a row block read the same X fragments, each accumulates (sum, sum of squares) of its own 128 rows — one v_dot2c per MFMA slot,
+// on registers that are live anyway — and the results land in the lanes the epilogue reads them from: no exchange, no statistics input,
+// no statistics epilogue in the producer.  GemmParams::ln_eps is the LayerNorm's epsilon.
 // STATS: the stored rows' per-strip partial sums go to GemmParams::stat_part (bias + residual producers of a LayerNorm input)
 // HEADS: head-major output Y[which][frame][head][token][d] (GemmParams::hm_*): the q/k/v projection of the encoder towers
-template <bool BIAS, int ACT, int RES, bool LNF = false, bool STATS = false, bool HEADS = false>
-struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES; static constexpr bool lnf = LNF, stats = STATS, heads = HEADS; };
+template <bool BIAS, int ACT, int RES, int LNF = 0, bool STATS = false, bool HEADS = false>
+struct Epi { static constexpr bool bias = BIAS; static constexpr int act = ACT, res = RES, lnf = LNF; static constexpr bool stats = STATS, heads = HEADS; };
 
 // PATCH: the X operand is gathered by the loader instead of read from a row-major matrix (GemmParams::pe_*):
 //   1  SigLIP patch embedding from NCHW pixels (no im2col buffer)
@@ -201,15 +205,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
     // under the K loop removes every load from the bias / folded-LayerNorm epilogues.
     //   bias epilogues : wave 0 fetches bias[n0 .. n0+255] (bf16, 512 B; the upper half of the piece is never read)
     //   folded LN      : wave 0 colsum[n0 ..], wave 1 shift[n0 ..] (fp32, 1 KB each), waves 2, 3 (mean, rstd) of rows m0 .. m0+255
-    constexpr bool cst_lnf = (MODE != MODE_GEGLU) && EPI::lnf;
-    constexpr bool cst_bias = (MODE != MODE_GEGLU) && EPI::bias && !EPI::lnf;
+    constexpr bool cst_lnf = (MODE != MODE_GEGLU) && EPI::lnf != 0;
+    constexpr bool ln_inloop = (MODE != MODE_GEGLU) && EPI::lnf == 2 && PATCH == 0 && !REPKV;      // row statistics from the X fragments (see Epi)
+    static_assert(EPI::lnf != 2 || ln_inloop, "in-loop LayerNorm statistics need a plain row-major X");
+    constexpr bool cst_bias = (MODE != MODE_GEGLU) && EPI::bias && EPI::lnf == 0;
     __amdgpu_buffer_rsrc_t srdC0, srdC1;
     int tpar = 0;                                           // parity of the current tile (constant buffer)
     auto rsrc_of = [](const void* base, unsigned long long bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
     };
     if constexpr (cst_lnf) {
-        srdC0 = rsrc_of(wave == 0 ? p.ln_s : (wave == 1 ? p.ln_c : p.ln_stats), wave < 2 ? (unsigned long long)p.N * 4 : (unsigned long long)p.M * 8);
+        srdC0 = rsrc_of(wave == 0 ? p.ln_s : (wave == 1 || ln_inloop ? p.ln_c : p.ln_stats), wave < 2 || ln_inloop ? (unsigned long long)p.N * 4 : (unsigned long long)p.M * 8);
     } else if constexpr (cst_bias) {
         srdC0 = rsrc_of(p.bias, (unsigned long long)p.N * 2);
     }
@@ -220,13 +226,28 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         if constexpr (cst_lnf) {
             // out-of-range columns / rows read as zeros (buffer range check); they are masked in the epilogue
             const unsigned voff = wave < 2 ? (unsigned)(n0 + 4 * lane) * 4u : (unsigned)(m0 + (wave - 2) * 128 + 2 * lane) * 8u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, voff, 0, 0, 0);
+            if (!ln_inloop || wave < 2)                              // (in-loop statistics: no (mean, rstd) pieces; only waves 0, 1 count one more DMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, voff, 0, 0, 0);
         } else if constexpr (cst_bias) {
             if (wave == 0)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)(n0 + 8 * lane) * 2u, 0, 0, 0);
         }
     };
 
+    // in-loop LayerNorm statistics: (sum, sum of squares) of this lane's k-subset of rows wm*128 + b*16 + l15, b = 0..7
+    float rs1[ln_inloop ? TM : 1], rs2[ln_inloop ? TM : 1];
+    auto row_dot = [&](unsigned w, bool square, float& s1, float& s2) {
+        // ONE v_dot2c per call (one dword of a fragment = 2 elements, picked at the call site; fp32 accumulate): against ones (sum) or
+        // against itself (sum of squares).  64 calls per phase — one per MFMA — cover the phase's 8 fragments x 4 dwords x {sum, squares}.
+        // asm volatile like the MFMAs: as ordinary instructions the last iteration's 256 were sunk below the K loop (seen in the ISA)
+        if constexpr (T::id == VIDI_DT_BF16) {
+            if (square) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(s2) : "v"(w));
+            else asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(s1) : "v"(w));
+        } else {
+            if (square) asm volatile("v_dot2c_f32_f16 %0, %1, %1" : "+v"(s2) : "v"(w));
+            else asm volatile("v_dot2c_f32_f16 %0, 0x3c003c00, %1" : "+v"(s1) : "v"(w));
+        }
+    };
     // one K iteration: 128 MFMAs on slice kt; slice kt+1's step-0 fragments are fetched and slice kt+2 is DMA'd over slice kt's
     // buffer.  FIRST: first slice of a tile, the step-0 MFMAs take C = 0 (no accumulator clearing).  NEXT: the last two iterations
     // of a tile — slices kt+1 / kt+2 are the NEXT tile's (slice kt+2-nk of its operands), issued only when `more` (a next tile
@@ -244,6 +265,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         };
         VIDI_PIN;
         if constexpr (FIRST) issue_cst();
+        if constexpr (FIRST && ln_inloop) {
+#pragma unroll
+            for (int b = 0; b < TM; ++b) { rs1[b] = 0.f; rs2[b] = 0.f; }
+        }
         VIDI_PIN;
         // ---------------- phase 1: step-0 MFMAs ----------------
 #pragma unroll
@@ -252,6 +277,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             if constexpr (FIRST) T::mfma16_agpr_first(acc[a][b], fW[0][a], fX[0][b]);
             else T::mfma16_agpr(acc[a][b], fW[0][a], fX[0][b]);
             if (i < 16 && (i & 1) == 0) fX[1][i >> 1] = rdX(bufc, i >> 1, 1);                 // 8 X-fragment reads
+            // in-loop statistics: the step-0 fragments (live through this phase), one v_dot2c in every MFMA's shadow
+            if constexpr (ln_inloop) row_dot(fX[0][i >> 3][(i & 7) >> 1], (i & 1) != 0, rs1[i >> 3], rs2[i >> 3]);
             if constexpr (HAS2) {
                 if (i == 19) wait_lgkm0();
                 if (i == 20) bar();                                                            // barrier 1: X part of bufc is dead
@@ -274,6 +301,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
         for (int i = 0; i < 64; ++i) {
             const int a = i >> 3, b = i & 7;
             T::mfma16_agpr(acc[a][b], fW[1][a], fX[1][b]);
+            if constexpr (ln_inloop) row_dot(fX[1][i >> 3][(i & 7) >> 1], (i & 1) != 0, rs1[i >> 3], rs2[i >> 3]);      // the step-1 fragments
             if constexpr (HAS2) {
                 if (i == 1) dma(9);
                 if (i == 21) dma(10);
@@ -331,9 +359,21 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             }
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const f32x2_t ms = *(const f32x2_t*)(cst + 2048 + (wm * 128 + b * 16 + l15) * 8);
-                lnMu[b] = ms[0];
-                lnRs[b] = ms[1];
+                if constexpr (ln_inloop) {
+                    // the four lanes l15 + 16 hi hold the row's four k-subsets: two exchanges through the LDS crossbar (no memory), then the
+                    // one-pass (mean, rstd) — the same arithmetic as vidi_ln_finalize, on the STORED values of the row
+                    float s1 = rs1[b], s2 = rs2[b];
+                    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    const float invK = 1.0f / (float)p.K;
+                    const float mean = s1 * invK;
+                    lnMu[b] = mean;
+                    lnRs[b] = rsqrtf(fmaxf(s2 * invK - mean * mean, 0.f) + p.ln_eps);
+                } else {
+                    const f32x2_t ms = *(const f32x2_t*)(cst + 2048 + (wm * 128 + b * 16 + l15) * 8);
+                    lnMu[b] = ms[0];
+                    lnRs[b] = ms[1];
+                }
             }
         }
         const int rr = lane / CPRW, cc = lane % CPRW;                // this lane's (row in read group, chunk) of the read-back
@@ -691,6 +731,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p, int batch) {
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b) asm volatile("" ::"a"(acc[a][b]));
+            if constexpr (ln_inloop) {                              // (lab: keep the K loop's statistics alive without an epilogue)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) asm volatile("" ::"v"(rs1[b]), "v"(rs2[b]));
+            }
         } else {
             epilogue(m0, n0, bz);
         }

@@ -37,6 +37,7 @@ struct GemmParams {
     //   ln_stats[m] = (mean_m, rstd_m)  (vidi_row_stats),  ln_s[n] = sum_k W'[n][k],  ln_c[n] = sum_k W[n][k] * beta[k] + bias[n]   (fp32)
     // == Linear(LayerNorm(x)) without materialising LayerNorm(x).  Null ln_stats: plain bias epilogue.
     const float* ln_stats; const float* ln_s; const float* ln_c;
+    float ln_eps;                 // Epi::lnf == 2 (statistics computed in the consumer's K loop): the LayerNorm's epsilon
     // producer side of the same fusion: a bias + residual epilogue that also leaves, per output row and 128-column strip, the
     // partial sums (sum y, sum y^2) of the values it stored — stat_part[m][strip][2], strips = ceil(N / 128) — so the NEXT
     // LayerNorm's statistics need no pass over Y (vidi_ln_finalize turns them into (mean, rstd)).  Null: off.
