@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VIDI_ABI_VERSION 4 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny; 4: + vidi_gemm_ln_rows[_heads] */
+#define VIDI_ABI_VERSION 5 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny; 4: + vidi_gemm_ln_rows[_heads]; 5: + vidi_gemv_mfma (a batch of decode rows on the matrix pipe) */
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
 #define VIDI_DT_F32 2 /* output type of the preprocessing kernels only */
@@ -135,6 +135,14 @@ int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ld
 size_t vidi_gemm_skinny_workspace_bytes(int M, int N, int K);
 int vidi_gemm_skinny(const void* X, const void* W, const void* bias, void* Y, void* workspace, int M, int N, int K, int ldx, int ldw,
                      int ldy, int dtype, void* stream);
+/* The same projections for a BATCH of decode rows (several queries sharing one video, BASELINE configs[4]: 8 rows; their o_proj over the
+ * three attention streams: 24 rows) on the matrix pipe — vidi_gemv's FMAs are VALU work that saturates near M = 8.  One pass over W, no
+ * workspace, 1 <= M <= 32: Y[M,N] = X W^T;  with glu_act = VIDI_ACT_GELU_TANH / VIDI_ACT_SILU (M <= 16): vidi_gemv_glu's gated pair on the
+ * interleaved gate/up weight (N = I features).  glu_act < 0: plain.  vidi_gemv_mfma_fits: 1 when (M, N, K) is taken (N % 16, K % 64),
+ * otherwise call vidi_gemv / vidi_gemm.  Values: vidi_gemv's up to the fp32 summation order. */
+int vidi_gemv_mfma_fits(int M, int N, int K, int glu);
+int vidi_gemv_mfma(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int glu_act, int dtype,
+                   void* stream);
 /* Skinny gated-MLP front half (M <= 8): Y[m][i] = T( T(act(T(gate_i . x_m))) * T(up_i . x_m) ) on the vidi_gemm_geglu weight
  * layout (gate/up rows interleaved in blocks of 32); act = VIDI_ACT_GELU_TANH (Gemma2MLP) or VIDI_ACT_SILU (MistralMLP).
  * Same values as vidi_gemv + vidi_geglu_unpack / vidi_glu_unpack, one launch. */

@@ -11,6 +11,7 @@ BUILD = os.path.join(ROOT, "vidi_amd", "csrc", "build")
 HOT = {
     "gemm.resources.txt": ["gemm_kernel", "gemm_f32_kernel"],
     "gemv.resources.txt": ["gemv_kernel", "gemv_glu_kernel", "gemv_norm2_kernel"],
+    "gemv_mfma.resources.txt": ["gemvm_kernel"],
     "gemm_w4_bf16.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_f16.resources.txt": ["gemm_w4_kernel"],
     "gemm_w4_modes.resources.txt": ["gemm_w4_kernel"],

@@ -462,6 +462,60 @@ def test_gemv(hip, dt, M):
     report("gemv", y, ref, *tol(dt, ref.std().item()))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(8, 8192, 3584), (24, 3584, 4096), (8, 3584, 14336), (1, 16, 64), (2, 48, 128), (5, 1008, 3584), (16, 256, 512),
+                                   (17, 64, 192), (32, 3584, 4096), (8, 4000, 3584), (3, 32, 320), (8, 6144, 4096)])
+def test_gemv_mfma(hip, dt, M, N, K):
+    """vidi_gemv_mfma (a batch of decode rows on the matrix pipe; every K split 1 / 2 / 4 / 8, one and two 16-row groups, blocks that walk
+    several feature groups): against the fp32 product of the same operands to the output rounding, and against vidi_gemv (M <= 8: both
+    round one fp32 sum per element, they differ by the summation order only); a strided input / output slice leaves its surroundings alone."""
+    assert hip.gemv_mfma_fits(M, N, K)
+    x = seeded((M, K), 95, dtype=dt); w = seeded((N, K), 96, 0.05, dtype=dt)
+    ref = x.float() @ w.float().T
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    y = hip.gemv_mfma(dev(x), dev(w))
+    report("gemv_mfma vs fp32", y, ref, 1e-3 * float(ref.abs().max()), ulp)
+    if M <= 8:
+        report("gemv_mfma vs vidi_gemv", y, hip.gemv(dev(x), dev(w)).float(), 1e-3 * float(ref.abs().max()), 2 * ulp)
+    xw = torch.zeros((M, K + 64), dtype=dt); xw[:, :K] = x
+    yw = torch.full((M + 1, N + 32), 7.0, dtype=dt).cuda()
+    hip.gemv_mfma(dev(xw)[:, :K], dev(w), out=yw[:M, :N])
+    report("strided", yw[:M, :N], ref, 1e-3 * float(ref.abs().max()), ulp)
+    assert bool((yw[:M, N:] == 7.0).all()) and bool((yw[M] == 7.0).all())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,I,K,act", [(8, 14336, 3584, "gelu"), (5, 512, 256, "gelu"), (1, 96, 64, "silu"), (8, 64, 128, "silu"), (16, 1024, 4096, "silu"),
+                                       (2, 14336, 4096, "silu")])
+def test_gemv_mfma_glu(hip, dt, M, I, K, act):
+    """the gated pair on the interleaved gate/up weight: against the oracle's rounding points (T(act(T(g))) * T(u), gemma.py:116-123 via HF
+    Gemma2MLP / mistral.py:131-137) from fp32 dot products, and against vidi_gemv_glu for M <= 8 (same rounding points, other summation
+    order: an element may move by one rounding of g or u)"""
+    code = hip.ACT_GELU_TANH if act == "gelu" else hip.ACT_SILU
+    assert hip.gemv_mfma_fits(M, I, K, True)
+    x = seeded((M, K), 97, dtype=dt); w = seeded((2 * I, K), 98, 0.05, dtype=dt)
+    full = (x.float() @ w.float().T).view(M, I // 32, 2, 32)
+    g, u = full[:, :, 0].reshape(M, I).to(dt).float(), full[:, :, 1].reshape(M, I).to(dt).float()
+    a = F.gelu(g, approximate="tanh") if act == "gelu" else F.silu(g)
+    ref = a.to(dt).float() * u
+    out = torch.full((M, I), 7.0, dtype=dt, device="cuda")
+    hip.gemv_mfma(dev(x), dev(w), out, glu_act=code)
+    report("gemv_mfma glu", out, ref, *tol(dt, ref.std().item(), k=2))
+    if M <= 8:
+        o2 = torch.empty_like(out)
+        hip.gemv_glu(dev(x), dev(w), o2, code)
+        report("gemv_mfma glu vs vidi_gemv_glu", out, o2.float(), *tol(dt, ref.std().item(), k=2))
+
+
+def test_gemv_mfma_shapes_it_does_not_take(hip):
+    assert not hip.gemv_mfma_fits(33, 4096, 3584) and not hip.gemv_mfma_fits(17, 4096, 3584, True)
+    assert not hip.gemv_mfma_fits(8, 4096 + 8, 3584) and not hip.gemv_mfma_fits(8, 4096, 3584 + 32)
+    x = torch.zeros((8, 96), dtype=torch.bfloat16).cuda(); w = torch.zeros((64, 96), dtype=torch.bfloat16).cuda()
+    with pytest.raises(Exception, match="vidi_gemv_mfma"):
+        hip.gemv_mfma(x, w)
+
+
+
 def test_gemm_f32(hip):
     from vidi_amd import hip as H
     M, N, K = 150, 256, 256

@@ -2,6 +2,7 @@
 #include "kernels.h"
 #include "attn_text_decode.h"
 #include "gemm_skinny_api.h"
+#include "gemv_mfma_api.h"
 #include <stdlib.h>
 #include "../../include/vidi_hip.h"
 
@@ -280,6 +281,15 @@ int vidi_gemv(const void* X, const void* W, void* Y, int M, int N, int K, int ld
     (void)hipGetLastError();   // a launch status must not inherit an earlier, unrelated runtime error
     if (!X || !W || !Y) return VIDI_ERR_ARG;
     return vidi_gemv_dispatch(X, W, Y, M, N, K, ldx, ldw, ldy, dtype, (hipStream_t)stream);
+}
+
+int vidi_gemv_mfma_fits(int M, int N, int K, int glu) { return vidi_gemvm_fits(M, N, K, glu); }
+
+int vidi_gemv_mfma(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int glu_act, int dtype,
+                   void* stream) {
+    (void)hipGetLastError();
+    if (!X || !W || !Y) return VIDI_ERR_ARG;
+    return vidi_gemv_mfma_dispatch(X, W, Y, M, N, K, ldx, ldw, ldy, glu_act, dtype, (hipStream_t)stream);
 }
 
 int vidi_gemv_glu(const void* X, const void* Wgu, void* Y, int M, int I, int K, int ldx, int ldw, int ldy, int act, int dtype,

@@ -1,0 +1,221 @@
+// Weight-streaming projection of a FEW rows on the matrix pipe (2 <= M <= 32): the decode step of a BATCH of queries sharing one video
+// (BASELINE configs[4]: 8 rows; their o_proj over the three attention streams: 24 rows) — the decoder's nn.Linear calls at q_len = 1
+// (gemma.py:57-60, :94, Gemma2MLP :119 via HF gemma2; mistral.py:131-137) with a batch dimension.
+// Why not gemv.hip: its FMAs are VALU work — per 16-byte weight chunk and lane 8 unpacks + 8 x M FMAs (+ the X unpacks); at M = 8 that is
+// ~100 VALU operations per 16 B, i.e. the whole VALU rate of the chip at 6 TB/s: the 8-row step ran at 16.0 ms against an 8.9 ms floor
+// (round-4 verdict, item 5).  Why not gemm_skinny.h: split-K through an fp32 workspace + a reduce launch, sized for 39..128 rows.
+// Here (HBM-bound, algorithmic bytes = N K 2, one pass over W, no workspace):
+//   * a block owns 16 output features (GLU: 16 gate rows + their 16 up rows) and ALL of K; its KS waves take the 64-wide k steps
+//     round-robin (wave w: steps w, w + KS, ... — at any moment the block reads KS adjacent 128-byte lines of each of its rows) and
+//     their partial accumulators are added in LDS once per feature group;
+//   * W goes HBM -> registers, 32 contiguous bytes per lane (lane (row l15, hi): k = 64 s + 16 hi .. + 15), non-temporal, D - 1 steps
+//     ahead in a register ring; the X rows (<= 32, L2-resident) are loaded the same way — lane (m = l15, hi) takes the same k bytes of its
+//     row, which IS the B fragment of MFMA 16x16x32 under the k permutation the W fragment uses ({16 hi + 0..7} then {16 hi + 8..15});
+//   * the ring runs over the flattened (feature group, step) sequence of a block (grid-stride over the groups), so the pipe never
+//     drains between groups; loads are asm with counted vmcnt waits (ordinary loads get a vmcnt(0) at the loop header: gemm_skinny.h).
+//   * C[i = 4 hi + r][j = l15] = feature n0 + 4 hi + r, X row 16 g + l15.  Output rounding: T(sum); GLU: T( T(act(T(g))) * T(u) ) —
+//     the values of gemv.hip's kernels up to the fp32 summation order.
+#include "kernels.h"
+#include "gemv_mfma_api.h"
+
+template <int V> struct GmInt { static constexpr int value = V; };
+
+__device__ __forceinline__ void gm_load_nt(u32x4& a, u32x4& b, const u16* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(a) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16 nt" : "=v"(b) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gm_load(u32x4& a, u32x4& b, const u16* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(b) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gm_wait_vm(u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+__device__ __forceinline__ void gm_pin(u32x4& a) { asm volatile("" : "+v"(a)); }            // keeps a consumer behind the wait above
+
+struct GemvmParams {
+    const u16* X; const u16* W; u16* Y;
+    int M, N, K, ldx, ldw, ldy, silu;
+};
+
+template <typename T, int MT, int KS, int D, bool GLU>
+__global__ __launch_bounds__(KS * 64) void gemvm_kernel(GemvmParams p) {
+    constexpr int NW = GLU ? 2 : 1;                      // weight rows per feature
+    constexpr int OPS = 2 * NW + 2 * MT;                 // memory operations per step and wave (a compile-time constant: counted waits)
+    static_assert((D - 2) * OPS <= 63, "vmcnt is a 6-bit counter");
+    __shared__ f32x4 red[2][KS][NW * MT][64];            // partial accumulators, double-buffered by group parity
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, hi = lane >> 4;
+    const int spw = p.K / 64 / KS;                       // steps per wave and group
+    const int ngroups = p.N / 16;
+    const int mine = blockIdx.x < ngroups ? (ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int T_steps = mine * spw;
+
+    const u16* xp[MT];
+#pragma unroll
+    for (int g = 0; g < MT; ++g) xp[g] = p.X + (size_t)min(g * 16 + l15, p.M - 1) * p.ldx + wave * 64 + hi * 16;
+    const size_t wlane = (size_t)wave * 64 + hi * 16;
+
+    u32x4 wr[D][NW][2], xr[D][MT][2];
+    f32x4 acc[NW][MT];
+#pragma unroll
+    for (int a = 0; a < NW; ++a)
+#pragma unroll
+        for (int g = 0; g < MT; ++g) acc[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int ig = blockIdx.x, is = 0;                         // (group, step) the next issue fetches
+    auto issue = [&](auto slot_t) {
+        constexpr int slot = decltype(slot_t)::value;
+        const int g = min(ig, ngroups - 1);              // past the end: re-load the last group (never consumed; keeps the counts exact)
+        const int f = g * 16 + l15;
+        const size_t k = (size_t)is * KS * 64;
+        if constexpr (GLU) {
+            const u16* wg = p.W + ((size_t)(f >> 5) * 64 + (f & 31)) * p.ldw + wlane + k;
+            gm_load_nt(wr[slot][0][0], wr[slot][0][1], wg);
+            gm_load_nt(wr[slot][1][0], wr[slot][1][1], wg + (size_t)32 * p.ldw);
+        } else {
+            gm_load_nt(wr[slot][0][0], wr[slot][0][1], p.W + (size_t)f * p.ldw + wlane + k);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) gm_load(xr[slot][m][0], xr[slot][m][1], xp[m] + k);
+        if (++is == spw) { is = 0; ig += gridDim.x; }
+    };
+    auto land = [&](auto slot_t) {                       // the slot's step landed; the D - 2 younger steps may be in flight
+        constexpr int slot = decltype(slot_t)::value;
+        gm_wait_vm<(D - 2) * OPS>(wr[slot][0][0]);
+        gm_pin(wr[slot][0][1]);
+        if constexpr (GLU) { gm_pin(wr[slot][1][0]); gm_pin(wr[slot][1][1]); }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { gm_pin(xr[slot][m][0]); gm_pin(xr[slot][m][1]); }
+    };
+    auto compute = [&](auto slot_t) {
+        constexpr int slot = decltype(slot_t)::value;
+#pragma unroll
+        for (int a = 0; a < NW; ++a)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[a][m] = T::mfma16(wr[slot][a][0], xr[slot][m][0], acc[a][m]);
+                acc[a][m] = T::mfma16(wr[slot][a][1], xr[slot][m][1], acc[a][m]);
+            }
+    };
+    // end of a feature group: the KS waves' partial tiles are added in LDS and the 16 x (16 MT) results stored.  Raw s_barrier
+    // (__syncthreads() carries a fence for which the compiler drains vmcnt, i.e. the whole ring); one barrier per group: the buffer
+    // alternates, and a wave cannot run two groups ahead of another without passing the barrier in between.
+    int cs = 0, cg = blockIdx.x, par = 0;
+    auto finish_group = [&]() {
+#pragma unroll
+        for (int a = 0; a < NW; ++a)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                red[par][wave][a * MT + m][lane] = acc[a][m];
+                acc[a][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* rf = (const float*)&red[par][0][0][0];
+        constexpr int WSTR = NW * MT * 256;              // floats between two waves' tiles
+        for (int idx = tid; idx < MT * 256; idx += KS * 64) {
+            const int m16 = idx >> 8, L = (idx >> 2) & 63, r = idx & 3;
+            const int n = cg * 16 + 4 * (L >> 4) + r, m = m16 * 16 + (L & 15);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; ++w) {
+                s0 += rf[w * WSTR + m16 * 256 + (idx & 255)];
+                if constexpr (GLU) s1 += rf[w * WSTR + (MT + m16) * 256 + (idx & 255)];
+            }
+            if (m < p.M) {
+                if constexpr (GLU) {
+                    const float g = rnd<T>(s0), u = rnd<T>(s1);
+                    p.Y[(size_t)m * p.ldy + n] = T::from_f32(rnd<T>(p.silu ? silu_f(g) : gelu_tanh_f(g)) * u);
+                } else {
+                    p.Y[(size_t)m * p.ldy + n] = T::from_f32(s0);
+                }
+            }
+        }
+        par ^= 1;
+        cg += gridDim.x;
+    };
+    auto step = [&](auto slot_t, auto prev_t, int t) {
+        if (t < T_steps) {
+            land(slot_t);
+            issue(prev_t);                               // refill the slot consumed one step ago with step t + D - 1
+            compute(slot_t);
+            if (++cs == spw) { cs = 0; finish_group(); }
+        }
+    };
+    // prologue: steps 0 .. D - 2
+    if (T_steps > 0) {
+        issue(GmInt<0>{});
+        if constexpr (D > 2) issue(GmInt<1>{});
+        if constexpr (D > 3) issue(GmInt<2>{});
+        if constexpr (D > 4) issue(GmInt<3>{});
+        if constexpr (D > 5) issue(GmInt<4>{});
+        if constexpr (D > 6) issue(GmInt<5>{});
+        if constexpr (D > 7) issue(GmInt<6>{});
+    }
+    for (int t0 = 0; t0 < T_steps; t0 += D) {
+        step(GmInt<0>{}, GmInt<D - 1>{}, t0);
+        step(GmInt<1>{}, GmInt<0>{}, t0 + 1);
+        if constexpr (D > 2) step(GmInt<2>{}, GmInt<1>{}, t0 + 2);
+        if constexpr (D > 3) step(GmInt<3>{}, GmInt<2>{}, t0 + 3);
+        if constexpr (D > 4) step(GmInt<4>{}, GmInt<3>{}, t0 + 4);
+        if constexpr (D > 5) step(GmInt<5>{}, GmInt<4>{}, t0 + 5);
+        if constexpr (D > 6) step(GmInt<6>{}, GmInt<5>{}, t0 + 6);
+        if constexpr (D > 7) step(GmInt<7>{}, GmInt<6>{}, t0 + 7);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's tail (clamped re-loads) must not outlive the wave's registers
+}
+
+// waves per block: the largest of 8, 4, 2, 1 that divides the K steps and leaves every wave >= 4 steps
+static inline int gemvm_ks(int K) {
+    const int steps = K / 64;
+    for (int ks : {8, 4, 2, 1})
+        if (steps % ks == 0 && steps / ks >= 4) return ks;
+    return 1;
+}
+
+int vidi_gemvm_fits(int M, int N, int K, int glu) {
+    if (M < 1 || M > (glu ? 16 : 32) || N <= 0 || N % 16 || K <= 0 || K % 64) return 0;
+    return 1;
+}
+
+#ifndef VIDI_GEMVM_BLOCKS_PER_CU
+#define VIDI_GEMVM_BLOCKS_PER_CU 4
+#endif
+
+template <typename T>
+static int launch_gemvm(const GemvmParams& p, bool glu, hipStream_t st) {
+    const int ks = gemvm_ks(p.K);
+    const int ngroups = p.N / 16;
+    // resident blocks: ~16 waves per CU
+    const int cap = 256 * (ks == 8 ? VIDI_GEMVM_BLOCKS_PER_CU / 2 : VIDI_GEMVM_BLOCKS_PER_CU);
+    const int blocks = ngroups < cap ? ngroups : cap;
+    const int mt = (p.M + 15) / 16;
+#define VIDI_GM(MT_, KS_, D_, GLU_) hipLaunchKernelGGL((gemvm_kernel<T, MT_, KS_, D_, GLU_>), dim3(blocks), dim3(KS_ * 64), 0, st, p)
+#define VIDI_GM_KS(MT_, D_, GLU_)                                                    \
+    do {                                                                             \
+        if (ks == 8) VIDI_GM(MT_, 8, D_, GLU_);                                      \
+        else if (ks == 4) VIDI_GM(MT_, 4, D_, GLU_);                                 \
+        else if (ks == 2) VIDI_GM(MT_, 2, D_, GLU_);                                 \
+        else VIDI_GM(MT_, 1, D_, GLU_);                                              \
+    } while (0)
+    if (glu) VIDI_GM_KS(1, 6, true);                     // 6 operations per step: 5 steps = 20 KB of W per wave in flight
+    else if (mt == 1) VIDI_GM_KS(1, 8, false);           // 4 operations per step: 7 steps = 14 KB
+    else VIDI_GM_KS(2, 6, false);                        // 6 operations per step: 5 steps = 10 KB
+#undef VIDI_GM_KS
+#undef VIDI_GM
+    return (int)hipGetLastError();
+}
+
+int vidi_gemv_mfma_dispatch(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int glu_act, int dtype,
+                            hipStream_t st) {
+    const bool glu = glu_act >= 0;
+    if (!vidi_gemvm_fits(M, N, K, glu) || ldw % 8 || ldx % 8) return VIDI_ERR_SHAPE;
+    if (glu && (N % 32 || (glu_act != ACT_GELU_TANH && glu_act != ACT_SILU))) return VIDI_ERR_ARG;
+    if (((uintptr_t)W & 15) || ((uintptr_t)X & 15)) return VIDI_ERR_ALIGN;
+    GemvmParams p{(const u16*)X, (const u16*)W, (u16*)Y, M, N, K, ldx, ldw, ldy, glu_act == ACT_SILU};
+    if (dtype == VIDI_DT_BF16) return launch_gemvm<BF16>(p, glu, st);
+    if (dtype == VIDI_DT_F16) return launch_gemvm<F16>(p, glu, st);
+    return VIDI_ERR_DTYPE;
+}

@@ -143,6 +143,9 @@ class VidiEngine:
         # decode step: the Gemma2 norm pairs folded into the gate/up and the next layer's q/k/v projections (VIDI_DECODE_NORM_GEMV=0:
         # vidi_resid_norm2 + vidi_gemv[_glu] as separate launches)
         self.decode_norm_gemv = os.environ.get("VIDI_DECODE_NORM_GEMV", "1") != "0"
+        # a BATCH of decode rows (several queries on one video): from this many rows on, the weight-streaming projections run on the matrix
+        # pipe (csrc/gemv_mfma.hip) instead of the VALU GEMV, whose FMAs saturate near 8 rows; 0 = never (the A/B arm)
+        self.gemv_mfma_rows = int(os.environ.get("VIDI_GEMV_MFMA_MIN_ROWS", "5"))
         # decode step: the T2T launch and the merge of the cross-attention partials as one launch (VIDI_DECODE_TAIL=0: two launches)
         self.decode_tail = os.environ.get("VIDI_DECODE_TAIL", "1") != "0"
         # multimodal stream: o_proj over repeat_kv(V) as one GEMM over V with the G column blocks of o_proj summed at load time
@@ -325,6 +328,8 @@ class VidiEngine:
         """bias-free projection: weight-streaming GEMV for M <= 8 (decode), the split-K weight-streaming MFMA kernel for a prompt's
         9..128 rows (VIDI_SKINNY_GEMM=0: the tile GEMM, the A/B arm), the tile / persistent MFMA GEMM otherwise."""
         M = x.shape[0]
+        if self.gemv_mfma_rows and self.gemv_mfma_rows <= M <= 32 and hip.gemv_mfma_fits(M, w.shape[0], x.shape[1]):
+            return hip.gemv_mfma(x, w, out)
         if M <= 8:
             return hip.gemv(x, w, out)
         if M <= 128 and self.skinny_gemm:
@@ -335,6 +340,13 @@ class VidiEngine:
             if need and ((have is not None and have.numel() * 4 >= need) or not torch.cuda.is_current_stream_capturing()):
                 return hip.gemm_skinny(x, w, self._buf("skinny_ws", (need // 4,), torch.float32), out)
         return hip.gemm(x, w, None, out)
+
+    def proj_glu(self, x: torch.Tensor, wgu: torch.Tensor, out: torch.Tensor, act: int) -> torch.Tensor:
+        """gated-MLP front half of a few decode rows (M <= 8): the matrix-pipe kernel from `gemv_mfma_rows` rows on, else the VALU GEMV"""
+        M = x.shape[0]
+        if self.gemv_mfma_rows and M >= self.gemv_mfma_rows and hip.gemv_mfma_fits(M, wgu.shape[0] // 2, x.shape[1], True):
+            return hip.gemv_mfma(x, wgu, out, glu_act=act)
+        return hip.gemv_glu(x, wgu, out, act)
 
     def sample_flag(self, x: torch.Tensor) -> torch.Tensor:
         """int32[1] device flag "the sample holds any non-zero value" (`torch.sum(torch.abs(x)) != 0`, multimodal.py:202, 246) of a
@@ -1003,8 +1015,8 @@ class VidiEngine:
                     hip.add3(tmp, oall[2 * M: 3 * M], None, hidden)
                 hip.norm(hip.NORM_MM, hidden, L["ln_post_attn"], eps=eps, out=hn)
                 if M <= 8:
-                    hip.gemv_glu(hn, L["wgu"], gt, hip.ACT_SILU)
-                    hip.gemv(gt, L["wdown"], dn)
+                    self.proj_glu(hn, L["wgu"], gt, hip.ACT_SILU)
+                    self.proj(gt, L["wdown"], dn)
                     hip.add3(hidden, dn, None, hidden)
                 else:
                     hip.gemm_glu(hn, L["wgu"], gt, act=hip.ACT_SILU)
@@ -1020,7 +1032,7 @@ class VidiEngine:
             else:
                 hip.resid_norm2(oall[:M], o_b, o_c, hidden, L["ln_post_attn"], L["ln_pre_ffn"], hidden, hn, eps=eps)
                 if M <= 8:
-                    hip.gemv_glu(hn, L["wgu"], gt, hip.ACT_GELU_TANH)
+                    self.proj_glu(hn, L["wgu"], gt, hip.ACT_GELU_TANH)
                 else:
                     hip.gemm_geglu(hn, L["wgu"], gt)
             self.proj(gt, L["wdown"], dn)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "vidi_gemv": [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     "vidi_gemm_skinny": [_c_vp] * 5 + [_c_int] * 7 + [_c_vp],
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
+    "vidi_gemv_mfma": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemv_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
     "vidi_gemv_glu_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
@@ -104,6 +105,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.vidi_softcap_argmax_workspace_bytes.argtypes = [_c_int]
     lib.vidi_gemm_skinny_workspace_bytes.restype = ctypes.c_size_t
     lib.vidi_gemm_skinny_workspace_bytes.argtypes = [_c_int] * 3
+    lib.vidi_gemv_mfma_fits.restype = _c_int
+    lib.vidi_gemv_mfma_fits.argtypes = [_c_int] * 4
     lib.vidi_stat_strips.restype = _c_int
     lib.vidi_stat_strips.argtypes = [_c_int]
     for name, args in SIGNATURES.items():
@@ -162,6 +165,8 @@ def _work(name, a):
         return "gemv", float(a[4]) * a[5] * 2, "byte"
     if name == "vidi_gemv_glu":
         return "gemv", 2.0 * a[4] * a[5] * 2, "byte"
+    if name == "vidi_gemv_mfma":
+        return "gemv", (2.0 if a[9] >= 0 else 1.0) * a[4] * a[5] * 2, "byte"
     if name == "vidi_gemv_norm2":
         return "gemv", float(a[12]) * a[13] * 2, "byte"
     if name == "vidi_gemv_glu_norm2":
@@ -412,6 +417,22 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     _check(lib.vidi_gemv(_p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _dt(x), _stream()), "vidi_gemv")
+    return out
+
+
+def gemv_mfma_fits(M: int, N: int, K: int, glu: bool = False) -> bool:
+    return bool(load_library().vidi_gemv_mfma_fits(int(M), int(N), int(K), int(glu)))
+
+
+def gemv_mfma(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, glu_act: int = -1) -> torch.Tensor:
+    """a batch of decode rows on the matrix pipe (csrc/gemv_mfma.hip): out = x @ w.T for 1 <= M <= 32 rows, or with `glu_act` the gated pair
+    act(x Wg^T) * (x Wu^T) on the interleaved gate/up weight (M <= 16)"""
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0] // 2 if glu_act >= 0 else w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _check(lib.vidi_gemv_mfma(_p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), int(glu_act), _dt(x), _stream()), "vidi_gemv_mfma")
     return out
 
 
