@@ -536,7 +536,14 @@ def main():
         h, w = hw if hw[0] != 28 else (cfg.vis_side + 1, cfg.vis_side + 1)
         Nv = T * (h // cfg.mm_image_pool_size) * (w // cfg.mm_image_pool_size)
     Na = audio_token_counts(audio_size, cfg)[1]
-    one = torch.ones(1, dtype=torch.int32, device=dev)         # sample-level "any non-zero input" flag (synthetic: true)
+
+    def whole_sample_flag(x):
+        """the sample-level "any non-zero input" flag (`torch.sum(torch.abs(x)) != 0`, multimodal.py:202, 246), computed INSIDE the timed step as
+        the reference does: one reduction over this rank's frames / windows (vidi_any_nonzero), OR-ed over the ranks when the sample is sharded"""
+        flag = eng.sample_flag(x)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag
 
     from vidi_amd.model import strip_image_token
     idt, mask, pos = strip_image_token(ids, amask)
@@ -551,9 +558,9 @@ def main():
 
     def step(record=False):
         e0 = ev()
-        fi, mi = eng.encode_video_images(pixel, frame_offset=f0, total_frames=T, normalizer=eng.normalizer, sample_flag=one)
+        fi, mi = eng.encode_video_images(pixel, frame_offset=f0, total_frames=T, normalizer=eng.normalizer, sample_flag=whole_sample_flag(pixel))
         e1 = ev()
-        fa, ma = eng.encode_video_audios(mel, audio_size, normalizer=eng.normalizer, chunk_offset=c0, sample_flag=one)
+        fa, ma = eng.encode_video_audios(mel, audio_size, normalizer=eng.normalizer, chunk_offset=c0, sample_flag=whole_sample_flag(mel))
         e2 = ev()
         mm = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
         e3 = ev()
@@ -659,6 +666,13 @@ def main():
                 print(json.dumps({"verify": verify}), file=sys.stderr)
             raise RuntimeError("bench: the HIP path disagrees with the oracle on the sampled rows (see `verify` on stderr)")
 
+    # ---- box-speed reference (untimed): frozen probe kernels, so that records from different boxes can be normalised ----
+    box = None
+    try:
+        box = hip.probe_box(pixel)
+    except Exception as e:
+        box = {"error": repr(e)}
+
     fam = timer.summary() if timer is not None else {}
     roof = None
     if "gemm" in fam:
@@ -707,7 +721,7 @@ def main():
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
         "first_token": first_token, "first_token_logit_abs_sum": logit_checksum, "attn_gain": a.attn_gain, "verify": verify,
         "kernel_families": fams, "kernel_family_steps": timer_steps,
-        "roofline": roof,
+        "roofline": roof, "box_reference": box,
     }
     if world == 1 and not a.no_preproc:
         # SURVEY §8f-2 leg, reported beside the metric and never part of `value`: decoded RGB frames (uint8) and 16 kHz PCM

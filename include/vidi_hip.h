@@ -351,6 +351,13 @@ int vidi_reflect_pad_f32(const float* wave, float* out, int C, int n, int pad, i
 int vidi_power_spectrum_f32(const float* Y, float* P, long long M, int nf, int ldy, int ldp, void* stream);
 int vidi_logmel_finish(float* mel, float* cmax, void* out, int C, int R, int F, int nmel, int out_dtype, void* stream);
 
+/* Box-speed reference (diagnostic, not on the Vidi path; csrc/probe.hip is frozen): bench.py prints these rates beside the metric so that
+ * records from different boxes of a pool can be normalised.  vidi_probe_mfma: a register-operand bf16 MFMA 16x16x32 loop on every SIMD
+ * (operands: 64 KB of bf16 values; out: 2048 * 512 floats; flop = 2048 * 8 * iters * 32 * 16384).  vidi_probe_hbm_read: one non-temporal
+ * sweep over `bytes` (multiple of 16) of buf (out: 2048 * 256 uint32). */
+int vidi_probe_mfma(const void* operands, void* out, int iters, void* stream);
+int vidi_probe_hbm_read(const void* buf, void* out, long long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,8 @@ SIGNATURES = {
     "vidi_gemm_skinny": [_c_vp] * 5 + [_c_int] * 7 + [_c_vp],
     "vidi_gemv_glu": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
     "vidi_gemv_mfma": [_c_vp] * 3 + [_c_int] * 8 + [_c_vp],
+    "vidi_probe_mfma": [_c_vp, _c_vp, _c_int, _c_vp],
+    "vidi_probe_hbm_read": [_c_vp, _c_vp, _c_ll, _c_vp],
     "vidi_gemv_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
     "vidi_gemv_glu_norm2": [_c_vp] * 7 + [_c_ll, _c_f, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
     "vidi_gemm_f32": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
@@ -418,6 +420,33 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     _check(lib.vidi_gemv(_p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _dt(x), _stream()), "vidi_gemv")
     return out
+
+
+def probe_box(buf: torch.Tensor, mfma_ms: float = 250.0) -> dict:
+    """Box-speed reference (csrc/probe.hip, frozen): sustained bf16 MFMA rate of a register-operand loop and the HBM read rate of one sweep
+    over `buf` (a resident tensor of a few GB), each the best of 3 after a warm-up.  Synchronises the device."""
+    lib = load_library()
+    dev = buf.device
+    g = torch.Generator(device="cpu").manual_seed(11)
+    ops = (torch.randn(4096 * 8, generator=g) * 2.0 ** -6).to(torch.bfloat16).to(dev)
+    out = torch.empty(2048 * 512, dtype=torch.float32, device=dev)
+    flop_per_iter = 2048 * 8 * 32 * 16384.0
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1)
+    run = lambda it: _check(lib.vidi_probe_mfma(_p(ops), _p(out), int(it), _stream()), "vidi_probe_mfma")          # noqa: E731
+    ms1 = timed(lambda: run(2000))
+    iters = max(2000, int(2000 * mfma_ms / max(ms1, 1e-3)))
+    mf = max(flop_per_iter * iters / (timed(lambda: run(iters)) * 1e-3) / 1e12 for _ in range(3))
+    flat = buf.contiguous().view(-1)
+    nbytes = (flat.numel() * flat.element_size()) // 16 * 16
+    sweep = lambda: _check(lib.vidi_probe_hbm_read(_p(flat), _p(out), nbytes, _stream()), "vidi_probe_hbm_read")    # noqa: E731
+    timed(sweep)
+    bw = max(nbytes / (timed(sweep) * 1e-3) / 1e9 for _ in range(3))
+    return {"mfma_bf16_16x16x32_TFLOP/s": mf, "hbm_read_GB/s": bw, "hbm_read_bytes": nbytes, "mfma_ms": mfma_ms,
+            "note": "frozen reference kernels (vidi_amd/csrc/probe.hip): divide figures of different boxes by these to compare builds"}
 
 
 def gemv_mfma_fits(M: int, N: int, K: int, glu: bool = False) -> bool:
