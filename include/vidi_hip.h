@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VIDI_ABI_VERSION 5 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny; 4: + vidi_gemm_ln_rows[_heads]; 5: + vidi_gemv_mfma (a batch of decode rows on the matrix pipe) */
+#define VIDI_ABI_VERSION 5 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny; 4: + vidi_gemm_ln_rows[_heads]; 5: + vidi_gemv_mfma (a batch of decode rows on the matrix pipe), vidi_attn_cross_row_tiles_per_block, vidi_probe_* */
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
 #define VIDI_DT_F32 2 /* output type of the preprocessing kernels only */
@@ -191,6 +191,10 @@ int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int 
  * uint8[n_keys] key-padding mask (image/audio_attention_mask).  Writes W = zsplit partials (one per block):
  * Opart:[W][nkv][Rpad][HD] fp32, ML:[W][nkv][Rpad][2] fp32 (base-2 running max, sum). */
 size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD);
+/* 32-row tiles ONE block of the launch covers for a launch of Rpad rows per kv head: 1 (a block = one row tile, its four waves split the
+ * key slice) or 4 (two row tiles and more — a prompt, a batch of prompts: the block's four waves own four row tiles and share one K / V
+ * stream, so the keys are read once per four tiles).  The launch runs nkv x ceil(Rpad / 32 / this) x zsplit blocks: size zsplit with it. */
+int vidi_attn_cross_row_tiles_per_block(int Rpad);
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
                     float scale, float softcap, int zsplit, int dtype, void* stream);

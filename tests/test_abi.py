@@ -36,7 +36,7 @@ def test_every_header_symbol_is_exported(lib_path):
 
 def test_python_binding_covers_the_header(lib_path):
     from vidi_amd import hip
-    bound = set(hip.SIGNATURES) | {"vidi_abi_version", "vidi_build_info", "vidi_attn_cross_workspace_bytes", "vidi_softcap_argmax_workspace_bytes", "vidi_gemm_skinny_workspace_bytes", "vidi_gemv_mfma_fits", "vidi_stat_strips"}
+    bound = set(hip.SIGNATURES) | {"vidi_abi_version", "vidi_build_info", "vidi_attn_cross_workspace_bytes", "vidi_softcap_argmax_workspace_bytes", "vidi_gemm_skinny_workspace_bytes", "vidi_gemv_mfma_fits", "vidi_attn_cross_row_tiles_per_block", "vidi_stat_strips"}
     assert set(header_symbols()) == bound, set(header_symbols()) ^ bound
     lib = hip.load_library()
     assert lib.vidi_attn_cross_workspace_bytes(2, 8, 32, 256) == 2 * 8 * 32 * 258 * 4

@@ -668,6 +668,11 @@ def _cross_ref(q, k, v, mask, scale, softcap, G):
     (256, 2, 2, 5, 333, 64, 50.0, True, 3),        # key mask + ragged tail
     (128, 2, 2, 3, 200, 0, None, True, 1),         # Mistral-style: no softcap, hd=128
     (256, 2, 2, 2, 17, 0, 50.0, False, 4),         # fewer sub-tiles than waves
+    # two row tiles and more: the blocks' four waves own four row tiles and share one K / V stream (attn_cross_rows_kernel)
+    (256, 8, 2, 304, 2000, 64, 50.0, True, 3),     # 8 prompts of 38 tokens (608 rows = 19 row tiles: 5 row blocks, the last with one idle wave), key mask
+    (128, 2, 4, 50, 700, 0, None, False, 2),       # hd = 128, no softcap, 7 row tiles
+    (256, 2, 2, 17, 100, 0, 50.0, False, 5),       # 2 row tiles (two idle waves), more key slices than sub-tiles (an empty slice emits the neutral partial)
+    (256, 8, 2, 39, 90000 // 8, 0, 50.0, False, 16),   # the single-prompt shape at an eighth of the 60-min key count
 ])
 def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
     nq = nkv * G

@@ -197,3 +197,17 @@ def test_split_key_slices_of_the_dual_cross_attention_launch():
     with pytest.raises(ValueError):
         split_key_slices(8, 0, 10)
 
+
+
+def test_dist_plan_reproduces_the_design_figures():
+    """tools/dist_plan.py (the expectation table for the first real multi-GPU run) computes the 8-rank partition of the 60-min configuration
+    with the product's own host logic and must land on the figures DESIGN.md section 6 quotes; other configurations tile without gaps."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dist_plan
+    dist_plan.check_design_figures()
+    for world, frames, fps, q in ((8, 3600, 2.0, 8), (4, 3600, 1.0, 1), (2, 300, 1.0, 1), (8, 301, 1.0, 1), (3, 25, 1.0, 1)):
+        p = dist_plan.plan(world, frames, fps, 39, q)
+        assert p["ranks"][-1]["video_tokens"][1] == p["video_tokens"] and p["ranks"][-1]["audio_tokens"][1] == p["audio_tokens"]
+        assert sum(r["frames"][1] - r["frames"][0] for r in p["ranks"]) == frames

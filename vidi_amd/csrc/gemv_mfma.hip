@@ -17,6 +17,7 @@
 //     the values of gemv.hip's kernels up to the fp32 summation order.
 #include "kernels.h"
 #include "gemv_mfma_api.h"
+#include <stdlib.h>
 
 template <int V> struct GmInt { static constexpr int value = V; };
 
@@ -167,12 +168,33 @@ __global__ __launch_bounds__(KS * 64) void gemvm_kernel(GemvmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's tail (clamped re-loads) must not outlive the wave's registers
 }
 
-// waves per block: the largest of 8, 4, 2, 1 that divides the K steps and leaves every wave >= 4 steps
-static inline int gemvm_ks(int K) {
-    const int steps = K / 64;
-    for (int ks : {8, 4, 2, 1})
-        if (steps % ks == 0 && steps / ks >= 4) return ks;
-    return 1;
+// Launch shape.  The kernel is a latency-bound stream: what matters is that every wave lives long (many 2 KB steps behind one prologue)
+// and that ~1 000-2 000 waves are resident (4-8 per CU x 10-20 KB in flight each covers HBM's latency-bandwidth product several times).
+// Round-5 session 1 measured the first form of this launch (8 waves per block, 7 steps per wave, one feature group per block) at the VALU
+// GEMV's rate: all prologue, no steady state.  Now: the K split is the SMALLEST of 1 / 2 / 4 / 8 that puts >= TARGET waves on the chip
+// (a feature group of 16 rows is one block; fewer waves per block = more steps per wave, fewer partial tiles to add), and at most
+// RESIDENT waves are launched — blocks walk the remaining groups with the ring running across group boundaries.
+#ifndef VIDI_GEMVM_TARGET_WAVES
+#define VIDI_GEMVM_TARGET_WAVES 768
+#endif
+#ifndef VIDI_GEMVM_RESIDENT_WAVES
+#define VIDI_GEMVM_RESIDENT_WAVES 2048
+#endif
+static inline int gemvm_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static inline int gemvm_ks(int N, int K) {
+    static const int forced = gemvm_env("VIDI_GEMVM_KS", 0), target = gemvm_env("VIDI_GEMVM_TARGET_WAVES", VIDI_GEMVM_TARGET_WAVES);
+    const int steps = K / 64, groups = N / 16;
+    if (forced && steps % forced == 0 && (forced == 1 || forced == 2 || forced == 4 || forced == 8)) return forced;
+    int best = 1;
+    for (int ks : {1, 2, 4, 8}) {
+        if (steps % ks) break;
+        best = ks;
+        if (groups * ks >= target) break;
+    }
+    return best;
 }
 
 int vidi_gemvm_fits(int M, int N, int K, int glu) {
@@ -180,16 +202,12 @@ int vidi_gemvm_fits(int M, int N, int K, int glu) {
     return 1;
 }
 
-#ifndef VIDI_GEMVM_BLOCKS_PER_CU
-#define VIDI_GEMVM_BLOCKS_PER_CU 4
-#endif
-
 template <typename T>
 static int launch_gemvm(const GemvmParams& p, bool glu, hipStream_t st) {
-    const int ks = gemvm_ks(p.K);
+    static const int resident = gemvm_env("VIDI_GEMVM_RESIDENT_WAVES", VIDI_GEMVM_RESIDENT_WAVES);
+    const int ks = gemvm_ks(p.N, p.K);
     const int ngroups = p.N / 16;
-    // resident blocks: ~16 waves per CU
-    const int cap = 256 * (ks == 8 ? VIDI_GEMVM_BLOCKS_PER_CU / 2 : VIDI_GEMVM_BLOCKS_PER_CU);
+    const int cap = resident / ks > 0 ? resident / ks : 1;
     const int blocks = ngroups < cap ? ngroups : cap;
     const int mt = (p.M + 15) / 16;
 #define VIDI_GM(MT_, KS_, D_, GLU_) hipLaunchKernelGGL((gemvm_kernel<T, MT_, KS_, D_, GLU_>), dim3(blocks), dim3(KS_ * 64), 0, st, p)
