@@ -37,9 +37,10 @@ def test_two_rank_sharded_prefill_matches_single_rank():
     # arithmetic; in fp32 the partials are summed in another order, which can flip the final bf16 rounding of an output by ONE ulp
     # (2^-8 .. 2^-7 relative; measured: exactly one ulp, 0.78 % of the value): 0.2 % of the spread + 1 % relative
     report("sharded layer-0 merged cross-attention", b["xattn_layer0"], a["xattn_layer0"], 2e-3 * a["xattn_layer0"].std().item(), 1e-2)
-    # ... and after two layers + the final norm those one-ulp flips have been amplified (observed 3 % of the spread)
-    report("sharded prefill hidden", b["prefill"], a["prefill"], 5e-2 * a["prefill"].std().item(), 3e-2)
-    report("sharded decode hidden", b["decode"], a["decode"], 5e-2 * a["decode"].std().item(), 3e-2)
+    # ... and after two layers + the final norm those one-ulp flips have been amplified (observed 2 % of the spread + the relative part:
+    # 0.40 of round 4's 5 % + 3 % bound): 3 % + 2 %
+    report("sharded prefill hidden", b["prefill"], a["prefill"], 3e-2 * a["prefill"].std().item(), 2e-2)
+    report("sharded decode hidden", b["decode"], a["decode"], 3e-2 * a["decode"].std().item(), 2e-2)
     # ONE packed all-gather per decoder layer per forward (numerator + (m, l) of both modalities), none on a single rank
     assert a["collectives_per_forward"] == 0 and b["collectives_per_forward"] == b["layers"]
     # the public API: generate() over the sharded video gives the single-rank tokens; so does a query against the resident shards
@@ -65,8 +66,8 @@ def test_rccl_exchange_on_one_rank_matches_unsharded():
     assert b["collectives_per_forward"] == b["layers"] and a["collectives_per_forward"] == 0
     # one rank holds every key: the only difference is the partial form (fp32 numerator, m, l) taking a trip through the exchange buffer
     report("rccl one-rank layer-0 merged cross-attention", b["xattn_layer0"], a["xattn_layer0"], 2e-3 * a["xattn_layer0"].std().item(), 1e-2)
-    report("rccl one-rank prefill hidden", b["prefill"], a["prefill"], 5e-2 * a["prefill"].std().item(), 3e-2)
-    report("rccl one-rank decode hidden", b["decode"], a["decode"], 5e-2 * a["decode"].std().item(), 3e-2)
+    report("rccl one-rank prefill hidden", b["prefill"], a["prefill"], 3e-2 * a["prefill"].std().item(), 2e-2)
+    report("rccl one-rank decode hidden", b["decode"], a["decode"], 3e-2 * a["decode"].std().item(), 2e-2)
     assert torch.equal(b["tokens"][:, :1], a["tokens"][:, :1]) and torch.equal(b["tokens8"][:, :1], a["tokens8"][:, :1])
     assert torch.equal(b["tokens_cached"], b["tokens"])
     assert b["tokens_graph"] is not None and torch.equal(b["tokens_graph"], b["tokens"])      # 42... layers' exchanges replayed from the graph

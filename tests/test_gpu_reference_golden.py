@@ -1,10 +1,10 @@
 """HIP path vs golden vectors produced by EXECUTING the reference's own model code on CPU/fp32
 (tests/golden/make_golden_dattn.py, make_golden_dattn_7b.py — third-party stand-ins only).  No oracle in between:
 `VidiForCausalLM.forward/generate` on the GPU against what `DattnGemma2ForCausalLM` / `DattnMistralForCausalLM` returned.
-Tolerances: the GPU model computes in bf16/fp16 with the reference's rounding points, the goldens are fp32.  Activations: 5 % of
-the tensor's rms + 3 % relative for bf16 (1 % / 0.6 % fp16).  Logits: max |err| <= LOGIT_TOL x std(logits) with no relative part —
-7 % (bf16) / 1.2 % (fp16), i.e. about 2x what the kernels achieve (3.3 % observed for bf16; audited per call through
-VIDI_TEST_REPORT, tests/util.py).  Masks bit-exact.  Greedy tokens: |err| <= tol on every logit implies the same argmax wherever the
+Tolerances: the GPU model computes in bf16/fp16 with the reference's rounding points, the goldens are fp32.  Activations: 3 % of
+the tensor's rms + 2 % relative for bf16 (0.6 % / 0.4 % fp16).  Logits: max |err| <= LOGIT_TOL x std(logits) with no relative part —
+5 % (bf16) / 1 % (fp16) (3.3 % typical, 4.7 % worst observed for bf16; audited per call through VIDI_TEST_REPORT, tests/util.py);
+`test_a_two_percent_kernel_error_is_caught` plants a 2 % error in one projection and shows which of these checks see it.  Masks bit-exact.  Greedy tokens: |err| <= tol on every logit implies the same argmax wherever the
 reference's top-2 margin exceeds 2 x tol, so free-running generate() must reproduce the reference's tokens up to the first step below
 that margin (and at least 4 of them), and a teacher-forced decode (the reference's tokens fed back) must reproduce EVERY step's scores."""
 import os
@@ -21,7 +21,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def tol(dt, k=1.0):
-    return (5e-2 * k, 3e-2) if dt == torch.bfloat16 else (1e-2 * k, 6e-3)
+    """golden activations: 3 % of the spread + 2 % relative for bf16 (0.6 % + 0.4 % fp16) — the audit's worst use of round 4's 5 % + 3 % was 0.45"""
+    return (3e-2 * k, 2e-2) if dt == torch.bfloat16 else (6e-3 * k, 4e-3)
 
 
 def check_free_running(got, ref_tok, step_logits, atol, min_agree, what):
@@ -227,3 +228,50 @@ def test_vidi7b_generate_against_reference_generate():
             assert int(tf[i].argmax()) == int(D["E_tokens"][0, i])
             agreed += 1
     assert agreed >= 4 and len(set(D["E_tokens"][0].tolist())) >= 4
+
+
+def test_a_two_percent_kernel_error_is_caught():
+    """Negative control for the bounds above (round-4 verdict: "the model-level tests would not catch a 3 % kernel error").  A kernel error is
+    emulated where it would live — every call of one projection is off by 2 %: the output features of `o_proj` alternately x 1.02 and x 0.98 in
+    every decoder layer (a UNIFORM factor would prove nothing: Gemma2's post-attention RMSNorm, gemma.py:237, divides it out exactly — on the
+    CPU oracle a uniform x 1.02 moves the logits by 1e-6 of their spread, the alternating one by 11.5 %) — and case A is re-run on the damaged model:
+      * the teacher-forced step logits / prefill logits against the reference execution must FAIL (the 5 % bound is meant to see this);
+      * for the record, the damage in units of the bound is printed (and logged through VIDI_TEST_REPORT) for 1 %, 2 % and 4 %.
+    What the model-level bound cannot see (a 1 % error) is the per-kernel tests' job: 1 % + 1 % per launch, teacher-forced per layer."""
+    from vidi_amd.config import tiny
+    import vidi_amd.weights as W
+    dt = torch.bfloat16
+    D = np.load(os.path.join(GOLD, "reference_dattn.npz"))
+    cfg = tiny(sliding_window=64)
+    ref = torch.from_numpy(D["A_prefill_logits"])
+    ltol = logit_tol(dt, ref)
+    used = {}
+    real_init = W.init_random_weights
+    for gain in (1.0, 1.01, 1.02, 1.04):
+        def damaged(*a, _g=gain, **kw):
+            w = real_init(*a, **kw)
+            for k in w:
+                if k.endswith("self_attn.o_proj.weight"):
+                    f = torch.ones((w[k].shape[0], 1), dtype=w[k].dtype)
+                    f[::2] = _g
+                    f[1::2] = 2.0 - _g
+                    w[k] = w[k] * f
+            return w
+        W.init_random_weights = damaged
+        try:
+            model = build(cfg, dt)
+        finally:
+            W.init_random_weights = real_init
+        ids = torch.from_numpy(D["A_input_ids"])
+        px, mel = torch.from_numpy(D["A_images"]).to(dt).cuda(), torch.from_numpy(D["A_audios"]).to(dt).cuda()
+        got = model.forward(ids, images=px, audios=mel, audio_sizes=D["A_audio_sizes"].tolist(), logits_to_keep=1).logits[:, -1].float().cpu()
+        used[gain] = float((got - ref).abs().max()) / ltol
+    print("share of the 5 % logit bound in use, by planted o_proj error:", {k: round(v, 2) for k, v in used.items()})
+    log = os.environ.get("VIDI_TEST_REPORT")
+    if log:
+        import json
+        with open(log, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "name": "negative control: planted o_proj error vs share of the logit bound", "used": used}) + "\n")
+    assert used[1.0] < 1.0, "the undamaged model must pass"
+    assert used[1.02] > 1.0, f"a 2 % error in every o_proj call stays inside the logit bound ({used[1.02]:.2f} of it): the bound is too loose to see it"
+    assert used[1.04] > used[1.02] > used[1.0]

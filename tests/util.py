@@ -21,10 +21,12 @@ def seeded(shape, seed, scale=1.0, dtype=torch.float32):
 
 
 def logit_tol(dt, ref):
-    """Absolute tolerance on logits, a fraction of their spread: 7 % (bf16) / 1.2 % (fp16) of std(ref), no relative part — about 2x what
-    the HIP path achieves against fp32 references (3.3 % observed for bf16).  |err| <= tol on every logit implies the same argmax
-    wherever the reference's top-2 margin exceeds 2 x tol."""
-    return (7e-2 if dt == torch.bfloat16 else 1.2e-2) * float(ref.float().std())
+    """Absolute tolerance on logits, a fraction of their spread: 5 % (bf16) / 1 % (fp16) of std(ref), no relative part.  Sized from the audit of
+    what the kernels use (profiles/r4_tolerance_audit.jsonl: worst logit error 4.7 % of the spread for bf16 — Vidi-7B's text-only prompt — and
+    3.3 % typically; 0.6 % for fp16); round 4 allowed 7 % / 1.2 %.  |err| <= tol on every logit implies the same argmax wherever the
+    reference's top-2 margin exceeds 2 x tol.  tests/test_gpu_reference_golden.py::test_a_two_percent_kernel_error_is_caught shows what an
+    error of 2 % in one kernel's output does to the checks built on this bound."""
+    return (5e-2 if dt == torch.bfloat16 else 1e-2) * float(ref.float().std())
 
 
 def report(name, got, ref, atol, rtol):
