@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VIDI_ABI_VERSION 5 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny; 4: + vidi_gemm_ln_rows[_heads]; 5: + vidi_gemv_mfma (a batch of decode rows on the matrix pipe), vidi_attn_cross_row_tiles_per_block, vidi_probe_* */
+#define VIDI_ABI_VERSION 5 /* 2: vidi_softcap_argmax takes a caller-owned workspace (the library holds no device state); 3: + vidi_gemm_skinny; 4: (a lab-only revision: LayerNorm statistics in the consumer's K loop, measured 28 % slower, never shipped); 5: + vidi_gemv_mfma (a batch of decode rows on the matrix pipe), vidi_attn_cross_row_tiles_per_block, vidi_probe_* */
 #define VIDI_DT_BF16 0
 #define VIDI_DT_F16 1
 #define VIDI_DT_F32 2 /* output type of the preprocessing kernels only */
@@ -100,16 +100,6 @@ int vidi_gemm_ln(const void* X, const void* Wf, const float* stats, const float*
  * Y[which][frame][head][token][d] (contiguous, same size as [M, N]). */
 int vidi_gemm_ln_heads(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Y,
                        int M, int N, int K, int ldx, int ldw, int seq, int hd, int tile_cfg, int dtype, void* stream);
-/* The same two projections with the row statistics computed by the call: Y = act(Linear(LayerNorm_eps(X))) from the UN-normalised rows
- * alone.  When the persistent kernel runs (>= 192 tiles of 256 x 256, K % 64 == 0, K >= 192) the (mean, rstd) of a tile's rows are
- * accumulated in its K loop from the X fragments it multiplies anyway (the contraction length IS the LayerNorm width) — no statistics
- * input, no statistics epilogue in the producer of X; otherwise a vidi_row_stats pass fills `stats` (caller-owned scratch, 2 * M floats,
- * always required) and the statistics-input form runs.  Replaces LayerNorm + nn.Linear of the encoder layers like vidi_gemm_ln
- * (HF modeling_siglip.py:310-357, modeling_whisper.py:279-333 through mm_vision/siglip.py:29-34, mm_audio/whisper.py:26-27). */
-int vidi_gemm_ln_rows(const void* X, const void* Wf, float* stats, const float* colsum, const float* shift, void* Y,
-                      int M, int N, int K, int ldx, int ldw, int ldy, float eps, int act, int tile_cfg, int dtype, void* stream);
-int vidi_gemm_ln_rows_heads(const void* X, const void* Wf, float* stats, const float* colsum, const float* shift, void* Y,
-                            int M, int N, int K, int ldx, int ldw, int seq, int hd, float eps, int tile_cfg, int dtype, void* stream);
 int vidi_gemm_qkv_vt_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Yqk, void* Vt,
                         int M, int N, int K, int ldx, int ldw, int ldy,
                         int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream);

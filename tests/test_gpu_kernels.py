@@ -254,55 +254,6 @@ def test_gemm_ln_equals_layernorm_then_linear(hip, dt, act, M, N, K, cfg):
     report(f"gemm_ln act={act}", y, ref, *tol(dt, ref.std().item(), k=2 if act != "none" else 1.5))
 
 
-@pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("act", ["none", "tanh", "erf"])
-@pytest.mark.parametrize("M,N,K,cfg", [(12800, 1152, 1152, -1), (9000, 4352, 1152, 5), (13217, 1280, 1280, -1), (300, 352, 192, 0), (70, 192, 64, -1)])
-def test_gemm_ln_rows_computes_the_statistics_itself(hip, dt, act, M, N, K, cfg, monkeypatch):
-    """vidi_gemm_ln_rows: LayerNorm -> Linear -> act from the un-normalised rows alone.  Large problems: the persistent kernel accumulates the
-    rows' (sum, sum of squares) in its K loop from the X fragments (Epi::lnf == 2; the `stats` scratch stays untouched); small ones: a
-    row_stats pass + the statistics-input form.  Against the fp32 evaluation on the same rounded inputs (the bounds of vidi_gemm_ln), and
-    against vidi_row_stats + vidi_gemm_ln to one output ulp (the same epilogue on statistics that differ in their last fp32 bits)."""
-    from vidi_amd import hip as H
-    x = seeded((M, K), 62, 1.0) + seeded((M, 1), 63, 1.5)
-    x[:, 5] *= 20.0; x[:, K // 2] *= -12.0
-    x = x.to(dt)
-    w = seeded((N, K), 64, 0.05, dtype=dt); b = seeded((N,), 65, 0.3, dtype=dt)
-    gamma = (1.0 + seeded((K,), 66, 0.2)).to(dt); beta = seeded((K,), 67, 0.2, dtype=dt)
-    h = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-6)
-    ref = F.linear(h, w.float(), b.float())
-    ref = {"none": ref, "tanh": O.gelu_tanh(ref), "erf": O.gelu_erf(ref)}[act]
-    wf, cs, sh = _fold_ln(w, b, gamma, beta, dt)
-    a = {"none": H.ACT_NONE, "tanh": H.ACT_GELU_TANH, "erf": H.ACT_GELU_ERF}[act]
-    st = torch.full((2 * M,), float("nan"), dtype=torch.float32).cuda()
-    y = hip.gemm_ln_rows(dev(x), dev(wf), st, dev(cs), dev(sh), eps=1e-6, act=a, tile_cfg=cfg)
-    inloop = cfg in (-1, 5) and ((N + 255) // 256) * ((M + 255) // 256) >= 192 and K % 64 == 0 and K >= 192
-    assert bool(torch.isnan(st).all()) == inloop                         # in-loop: the scratch is not needed
-    report(f"gemm_ln_rows act={act}", y, ref, *tol(dt, ref.std().item(), k=2 if act != "none" else 1.5))
-    st2 = torch.zeros(2 * M, dtype=torch.float32).cuda()
-    hip.row_stats(dev(x), st2, 1e-6)
-    y2 = hip.gemm_ln(dev(x), dev(wf), st2, dev(cs), dev(sh), act=a, tile_cfg=cfg)
-    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-    report("in-loop statistics vs the statistics input", y, y2.float(), 2e-3 * float(ref.abs().max()), 2 * ulp)
-
-
-@pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_ln_rows_heads(hip, dt):
-    """the head-major q | k | v form of vidi_gemm_ln_rows against vidi_row_stats + vidi_gemm_ln_heads (same layout code, statistics from the K loop)"""
-    B, Nt, nh, hd, K = 24, 729, 16, 72, 1152
-    M, N = B * Nt, 3 * nh * hd
-    x = (seeded((M, K), 68, 1.0) + seeded((M, 1), 69, 1.0)).to(dt)
-    w = seeded((N, K), 70, 0.05, dtype=dt); b = seeded((N,), 71, dtype=dt)
-    gamma = (1.0 + seeded((K,), 72, 0.2)).to(dt); beta = seeded((K,), 73, 0.2, dtype=dt)
-    wf, cs, sh = _fold_ln(w, b, gamma, beta, dt)
-    st = torch.zeros(2 * M, dtype=torch.float32).cuda()
-    hip.row_stats(dev(x), st, 1e-6)
-    want = torch.empty(M * N, dtype=dt).cuda(); got = torch.empty(M * N, dtype=dt).cuda()
-    hip.gemm_ln_heads(dev(x), dev(wf), st, dev(cs), dev(sh), want, seq=Nt, hd=hd)
-    scratch = torch.full((2 * M,), float("nan"), dtype=torch.float32).cuda()
-    hip.gemm_ln_rows_heads(dev(x), dev(wf), scratch, dev(cs), dev(sh), got, eps=1e-6, seq=Nt, hd=hd)
-    assert bool(torch.isnan(scratch).all())
-    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-    report("head-major, in-loop statistics", got, want.float(), 2e-3 * float(want.float().abs().max()), 2 * ulp)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -452,19 +452,3 @@ def test_engine_switch_arms_agree(tiny_setup, monkeypatch):
     report("switch arms [prescale off vs all off]: prefill + decode hidden states", c[2], b[2], *tol2(b[2], False))
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_towers_with_the_statistics_in_the_consumers(dt, monkeypatch):
-    """VIDI_LN_INLOOP_ENGINE=1 (csrc/gemm_w4.h Epi::lnf == 2 through vidi_gemm_ln_rows[_heads]; plain bias + residual producers, no
-    ln_finalize): both towers against the fp32 oracle at the tower tolerances, and against the default arm."""
-    from vidi_amd.config import tiny
-    cfg = tiny()
-    eng0, w32 = make(cfg, dt)
-    monkeypatch.setenv("VIDI_LN_INLOOP_ENGINE", "1")
-    eng1, _ = make(cfg, dt)
-    assert eng1.ln_inloop and not eng0.ln_inloop
-    px = seeded((5, 3, cfg.vis_image_size, cfg.vis_image_size), 140, 0.5).clamp(-1, 1).to(dt)
-    mel = seeded((3, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 141, 0.3).to(dt)
-    for name, ref, a, b in (("siglip", O.siglip_forward(px.float(), w32, oracle_cfg(cfg)), eng0.siglip_forward(px.cuda()), eng1.siglip_forward(px.cuda())),
-                            ("whisper", O.whisper_encoder_forward(mel.float(), w32, oracle_cfg(cfg)), eng0.whisper_forward(mel.cuda()), eng1.whisper_forward(mel.cuda()))):
-        report(f"{name}, statistics in the consumers", b, ref, *tol(dt, ref.std().item(), tight=True))
-        report(f"{name}, arms", b, a.float(), *tol(dt, ref.std().item(), tight=True))

@@ -51,20 +51,6 @@ for l in open("gpurun_out/ab_w4n.jsonl"):
     print("VIDI_W4N", d["VIDI_W4N"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "frac", round(d["roofline"]["frac"], 4), "verify", d["verify"]["ok"], round(d["verify"]["embeds_frames_max_err"], 4), "first_token", d["first_token"])
 PY
   ;;
-ablninloop)
-  # same-box ABAB of the prefill: LayerNorm statistics in the consumers' K loops (VIDI_LN_INLOOP_ENGINE=1) against the shipped
-  # producer-side partial sums + ln_finalize (0); `stage_ms_per_step.vision_encode` / `audio_encode` and `verify` are the numbers to read
-  : > $OUT/ab_lninloop.jsonl
-  for r in 1 2; do for sw in 0 1; do
-    VIDI_LN_INLOOP_ENGINE=$sw timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-preproc --decode-steps 4 2> $OUT/ab_lninloop.err | grep '^{' | sed "s/^{/{\"VIDI_LN_INLOOP_ENGINE\": $sw, /" >> $OUT/ab_lninloop.jsonl; echo "ablninloop $sw rc=$?"
-  done; done
-  python - <<'PY'
-import json
-for l in open("gpurun_out/ab_lninloop.jsonl"):
-    d = json.loads(l)
-    print("VIDI_LN_INLOOP_ENGINE", d["VIDI_LN_INLOOP_ENGINE"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "verify", d["verify"]["ok"], round(d["verify"]["embeds_frames_max_err"], 4), "first_token", d["first_token"])
-PY
-  ;;
 abskinny)
   # same-box ABAB of the 5-min config (text prefill is a visible share there): the prompt's projections on vidi_gemm_skinny (default) against
   # the tile GEMM (VIDI_SKINNY_GEMM=0); `stage_ms_per_step.text_prefill` is the number to read

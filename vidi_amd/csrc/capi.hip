@@ -199,56 +199,6 @@ int vidi_gemm_ln_heads(const void* X, const void* Wf, const float* stats, const 
     return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg, dtype, (hipStream_t)stream);
 }
 
-// LayerNorm folded into the projection with the row statistics computed by the call itself: in the persistent kernel's K loop when that kernel
-// runs (>= 192 tiles of 256 x 256, K a multiple of 64, >= 192), otherwise by a vidi_row_stats pass into the caller's `stats` scratch and the
-// statistics-input form.  VIDI_LN_INLOOP=0 forces the second form (the A/B arm).
-static bool ln_inloop_takes(int M, int N, int K, int tile_cfg) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIDI_LN_INLOOP"); on = (e && atoi(e) == 0) ? 0 : 1; }
-    const long long t256 = (long long)((N + 255) / 256) * ((M + 255) / 256);
-    return on && (tile_cfg < 0 || tile_cfg == 5) && t256 >= 192 && K % 64 == 0 && K >= 192;
-}
-
-int vidi_gemm_ln_rows(const void* X, const void* Wf, float* stats, const float* colsum, const float* shift, void* Y,
-                      int M, int N, int K, int ldx, int ldw, int ldy, float eps, int act, int tile_cfg, int dtype, void* stream) {
-    (void)hipGetLastError();
-    if (!X || !Wf || !stats || !colsum || !shift || !Y || !(eps > 0.f)) return VIDI_ERR_ARG;
-    if (((uintptr_t)colsum & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)stats & 7)) return VIDI_ERR_ALIGN;
-    if (act != ACT_NONE && act != ACT_GELU_TANH && act != ACT_GELU_ERF) return VIDI_ERR_ARG;
-    if (tile_cfg == 3) return VIDI_ERR_ARG;
-    GemmParams p = base_params(X, Wf, nullptr, Y, nullptr, M, N, K, ldx, ldw, ldy, 0, 0);
-    p.act = act; p.ln_s = colsum; p.ln_c = shift;
-    if (ln_inloop_takes(M, N, K, tile_cfg)) {
-        p.ln_eps = eps;
-        return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, 5, dtype, (hipStream_t)stream);
-    }
-    const int rc = vidi_row_stats_dispatch(X, stats, M, K, ldx, eps, dtype, (hipStream_t)stream);
-    if (rc != 0) return rc;
-    p.ln_stats = stats;
-    return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg, dtype, (hipStream_t)stream);
-}
-
-int vidi_gemm_ln_rows_heads(const void* X, const void* Wf, float* stats, const float* colsum, const float* shift, void* Y,
-                            int M, int N, int K, int ldx, int ldw, int seq, int hd, float eps, int tile_cfg, int dtype, void* stream) {
-    (void)hipGetLastError();
-    if (!X || !Wf || !stats || !colsum || !shift || !Y || !(eps > 0.f)) return VIDI_ERR_ARG;
-    if (((uintptr_t)colsum & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)stats & 7)) return VIDI_ERR_ALIGN;
-    if (seq <= 0 || hd <= 0 || hd % 8 || M % seq || N % (3 * hd)) return VIDI_ERR_SHAPE;
-    if ((unsigned long long)M * (unsigned)seq >= (1ull << 32)) return VIDI_ERR_SHAPE;
-    if (tile_cfg == 3) return VIDI_ERR_ARG;
-    GemmParams p = base_params(X, Wf, nullptr, Y, nullptr, M, N, K, ldx, ldw, N, 0, 0);
-    p.ln_s = colsum; p.ln_c = shift;
-    p.hm_seq = seq; p.hm_hd = hd; p.hm_heads = N / (3 * hd); p.hm_magic = (unsigned)((1ull << 32) / (unsigned)seq) + 1u;
-    if (ln_inloop_takes(M, N, K, tile_cfg)) {
-        p.ln_eps = eps;
-        return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, 5, dtype, (hipStream_t)stream);
-    }
-    const int rc = vidi_row_stats_dispatch(X, stats, M, K, ldx, eps, dtype, (hipStream_t)stream);
-    if (rc != 0) return rc;
-    p.ln_stats = stats;
-    return vidi_gemm_dispatch(p, 1, MODE_PLAIN, 0, tile_cfg, dtype, (hipStream_t)stream);
-}
-
 int vidi_gemm_qkv_vt_ln(const void* X, const void* Wf, const float* stats, const float* colsum, const float* shift, void* Yqk, void* Vt,
                         int M, int N, int K, int ldx, int ldw, int ldy,
                         int vstart, int hd, int seq, int seqpad, int nheads, int tile_cfg, int dtype, void* stream) {

@@ -176,11 +176,10 @@ static int launch_mode(const GemmParams& p, int batch, int tile_cfg, hipStream_t
         const long long t256 = (long long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
         static int big = -1;                      // VIDI_GEMM_CFG: 4 or 5 (A/B of the two large-tile kernels; same results)
         if (big < 0) { const char* e = getenv("VIDI_GEMM_CFG"); big = e ? atoi(e) : 5; if (big != 4 && big != 5) big = 5; }
-        if (t256 >= 192 && (big == 5 || p.ln_stats || p.ln_eps > 0.f)) {            // persistent 4-wave kernel; the 8-wave kernel covers epilogue combinations it lacks
+        if (t256 >= 192 && (big == 5 || p.ln_stats)) {            // persistent 4-wave kernel; the 8-wave kernel covers epilogue combinations it lacks
             const int rc = launch_w4_any<T, MODE, REPKV>(p, batch, st);
             if (rc != VIDI_W4_UNSUPPORTED) return rc;
         }
-        if (p.ln_eps > 0.f && !p.ln_stats) return VIDI_ERR_ARG;          // in-loop statistics exist in the persistent kernel only (capi.hip checks before it asks)
         tile_cfg = (t256 >= 192 && !p.ln_stats) ? 4 : 0;
     }
     if ((p.ln_stats || p.hm_seq) && tile_cfg != 0 && tile_cfg != 5) return VIDI_ERR_ARG;       // folded LayerNorm: persistent kernel or the 128x128 tile

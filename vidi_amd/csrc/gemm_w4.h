@@ -62,6 +62,8 @@ struct W4Geom {
 // the bias add (c carries the bias).  1 (true): (mean, rstd) of the rows come from GemmParams::ln_stats.  2: they are computed HERE, in the
 // K loop, from the X fragments the wave multiplies anyway (the contraction length is the LayerNorm width, so a tile sees whole rows): both
 // n-waves of a row block read the same X fragments, each accumulates (sum, sum of squares) of its own 128 rows — one v_dot2c per MFMA slot,
+// [LAB ONLY — measured in round 5 (profiles/r5_gemm_lab_lnstats.jsonl): the K loop runs at 941 instead of 1 584 TFLOP/s with the dot
+// products in it, the whole fc1 kernel at 798 instead of 1 103 — no product path instantiates lnf == 2; tools/lab/gemm_lab lnstats does]
 // on registers that are live anyway — and the results land in the lanes the epilogue reads them from: no exchange, no statistics input,
 // no statistics epilogue in the producer.  GemmParams::ln_eps is the LayerNorm's epsilon.
 // STATS: the stored rows' per-strip partial sums go to GemmParams::stat_part (bias + residual producers of a LayerNorm input)

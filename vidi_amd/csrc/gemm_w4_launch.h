@@ -26,7 +26,7 @@ static int launch_w4(const GemmParams& p, int batch, hipStream_t st) {
 // MODE_PLAIN: (bias, act, residual kind) combinations the Vidi engines use; others return VIDI_W4_UNSUPPORTED
 template <typename T>
 static int w4_plain_dispatch(const GemmParams& p, int batch, int repkv, hipStream_t st) {
-    if (p.ln_stats || p.stat_part || p.ln_eps > 0.f) return vidi_w4_lnf(p, batch, MODE_PLAIN, T::id, st);       // LayerNorm folded into the projection (gemm_w4_lnf.hip)
+    if (p.ln_stats || p.stat_part) return vidi_w4_lnf(p, batch, MODE_PLAIN, T::id, st);       // LayerNorm folded into the projection (gemm_w4_lnf.hip)
     const bool bias = p.bias != nullptr;
     const int res = p.R ? (p.rmod < p.M ? 2 : 1) : 0;
     const int act = p.act;

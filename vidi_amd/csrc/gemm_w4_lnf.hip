@@ -10,20 +10,6 @@ static int lnf(const GemmParams& p, int batch, int mode, hipStream_t st) {
     if (batch != 1 || p.R || !p.ln_s || !p.ln_c) return VIDI_ERR_ARG;
     if (mode == MODE_QKV_VT) return launch_w4<T, MODE_QKV_VT, false, Epi<true, ACT_NONE, 0, true>>(p, batch, st);
     if (mode != MODE_PLAIN) return VIDI_ERR_ARG;
-    if (!p.ln_stats) {
-        // the rows' (mean, rstd) computed in the K loop from the X fragments (Epi::lnf == 2; GemmParams::ln_eps)
-        if (p.ln_eps <= 0.f) return VIDI_ERR_ARG;
-        if (p.hm_seq) {
-            if (p.act != ACT_NONE) return VIDI_ERR_ARG;
-            return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 0, 2, false, true>>(p, batch, st);
-        }
-        switch (p.act) {
-            case ACT_NONE: return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 0, 2>>(p, batch, st);
-            case ACT_GELU_TANH: return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_GELU_TANH, 0, 2>>(p, batch, st);
-            case ACT_GELU_ERF: return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_GELU_ERF, 0, 2>>(p, batch, st);
-            default: return VIDI_ERR_ARG;
-        }
-    }
     if (p.hm_seq) {
         if (p.act != ACT_NONE) return VIDI_ERR_ARG;
         return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 0, true, false, true>>(p, batch, st);      // q/k/v projection, head-major

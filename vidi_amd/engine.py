@@ -135,8 +135,6 @@ class VidiEngine:
         self.stream_norm2 = os.environ.get("VIDI_STREAM_NORM2", "1") != "0"
         # decode step: rope + cache append + T2T as one launch (VIDI_DECODE_ATTN=0: rope_cache + attn_text), T2V + T2A partial passes as
         # one launch (VIDI_CROSS_DUAL=0: one launch per modality) — the A/B arms of tools/ab_decode.py
-        # towers: LayerNorm statistics computed by the consuming projection (VIDI_LN_INLOOP_ENGINE=1; off until measured: profiles/r4_notes.md)
-        self.ln_inloop = os.environ.get("VIDI_LN_INLOOP_ENGINE", "0") == "1"
         self.skinny_gemm = os.environ.get("VIDI_SKINNY_GEMM", "1") != "0"      # prompts of 9..128 rows: csrc/gemm_skinny.h instead of the tile GEMM
         self.decode_attn = os.environ.get("VIDI_DECODE_ATTN", "1") != "0"
         self.cross_dual = os.environ.get("VIDI_CROSS_DUAL", "1") != "0"
@@ -368,16 +366,7 @@ class VidiEngine:
         M = x.shape[0]
         st, part, h, yqk, vt, ao, f1 = ws["st"], ws["part"], ws["h"], ws["yqk"], ws["vt"], ws["ao"], ws["f1"]
         Hd = x.shape[1]
-        if self.ln_fold and self.attn_rm and self.ln_inloop:
-            # the consumers compute the row statistics themselves (in their K loops: csrc/gemm_w4.h Epi::lnf == 2): the producers are plain
-            # bias + residual projections, no partial sums, no finalize launch
-            qkv = ws["qkv"]
-            hip.gemm_ln_rows_heads(x, L["wqkv"], st, L["sqkv"], L["cqkv"], qkv, eps=eps, seq=attn_kw["N"], hd=attn_kw["D"])
-            hip.attn_self_rm(qkv, ao[:M], B=attn_kw["B"], N=attn_kw["N"], H=attn_kw["H"], D=attn_kw["D"], scale=attn_kw["scale"], head_major=True)
-            hip.gemm(ao[:M], L["wo"], L["bo"], x, residual=x)
-            hip.gemm_ln_rows(x, L["fc1"], st, L["s1"], L["c1"], f1[:M], eps=eps, act=act)
-            hip.gemm(f1[:M], L["fc2"], L["b2"], x, residual=x)
-        elif self.ln_fold and self.attn_rm:
+        if self.ln_fold and self.attn_rm:
             # q | k | v from ONE plain projection, written head-major ([3][frame][head][token][d]: a head's key rows contiguous -> whole
             # 128-byte lines for the attention's K / V tiles); the attention kernel transposes V on the fly (LDS transpose read), so the
             # GEMM has no scattered V^T stores
@@ -450,7 +439,7 @@ class VidiEngine:
             else:
                 hip.im2col_patch(pixel[c0:c1], A[:M], T=Tc, S=S, P=P, Kpad=V["kpad"])
                 hip.gemm(A[:M], V["patch_w"], V["patch_b"], x, residual=V["pos"], rmod=N)
-            if fold and not self.ln_inloop:
+            if fold:
                 hip.row_stats(x, ws["st"], cfg.vis_ln_eps)
             pr = self.probe if (self.probe is not None and "vis_frames" in self.probe) else None
             grab = (lambda: pr["vis_x"].append(torch.stack([x[(f - c0) * N: (f - c0 + 1) * N].clone() for f in pr["vis_frames"] if c0 <= f < c1]))) \
@@ -565,7 +554,7 @@ class VidiEngine:
             # conv2 (k3,s2,p1): row t reads y1 rows 2t..2t+2; GELU(erf); + embed_positions
             hip.gemm(y1[0], A["conv2_w"], A["conv2_b"], x.view(Cc, N, Da), act=hip.ACT_GELU_ERF, residual=A["pos"], rmod=N,
                      M=N, K=3 * Da, ldx=2 * Da, batch=Cc, bsX=(Lm + 1) * Da, bsY=N * Da, bsR=0)
-            if fold and not self.ln_inloop:
+            if fold:
                 hip.row_stats(x, ws["st"], cfg.aud_ln_eps)
             pr = self.probe if (self.probe is not None and "aud_windows" in self.probe) else None
             grab = (lambda: pr["aud_x"].append(torch.stack([x[(c - c0) * N: (c - c0 + 1) * N].clone() for c in pr["aud_windows"] if c0 <= c < c1]))) \
@@ -579,7 +568,7 @@ class VidiEngine:
                 if self.dtype == torch.float16:                     # TP whisper:409-411 overflow guard
                     cv = torch.finfo(torch.float16).max - 1000
                     x.clamp_(min=-cv, max=cv)
-                    if fold and not self.ln_inloop:                 # the clamp may have changed rows: their statistics again
+                    if fold:                                        # the clamp may have changed rows: their statistics again
                         hip.row_stats(x, ws["st"], cfg.aud_ln_eps)
             if grab is not None:
                 grab()

@@ -49,8 +49,6 @@ SIGNATURES = {
     "vidi_attn_self": [_c_vp] * 3 + [_c_int] * 8 + [_c_f, _c_int, _c_vp],
     "vidi_attn_self_rm": [_c_vp] * 2 + [_c_int] * 5 + [_c_ll] * 4 + [_c_int, _c_f, _c_int, _c_vp],
     "vidi_gemm_ln_heads": [_c_vp] * 6 + [_c_int] * 9 + [_c_vp],
-    "vidi_gemm_ln_rows": [_c_vp] * 6 + [_c_int] * 6 + [_c_f] + [_c_int] * 3 + [_c_vp],
-    "vidi_gemm_ln_rows_heads": [_c_vp] * 6 + [_c_int] * 7 + [_c_f] + [_c_int] * 2 + [_c_vp],
     "vidi_attn_cross": [_c_vp] * 6 + [_c_int] * 9 + [_c_f, _c_f, _c_int, _c_int, _c_vp],
     "vidi_attn_merge": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "vidi_attn_merge2": [_c_vp] * 3 + [_c_int] * 2 + [_c_vp] * 3 + [_c_int] * 2 + [_c_int] * 7 + [_c_vp],
@@ -145,7 +143,7 @@ def _work(name, a):
         return "gemm", 2.0 * a[5] * a[6] * a[7], "flop"
     if name == "vidi_gemm_qkv_vt_ln":
         return "gemm", 2.0 * a[7] * a[8] * a[9], "flop"
-    if name in ("vidi_gemm_ln", "vidi_gemm_res_stats", "vidi_gemm_ln_rows", "vidi_gemm_ln_rows_heads"):
+    if name in ("vidi_gemm_ln", "vidi_gemm_res_stats"):
         return "gemm", 2.0 * a[6] * a[7] * a[8], "flop"
     if name == "vidi_row_stats":
         return "norm", float(a[2]) * a[3] * 2, "byte"
@@ -584,35 +582,6 @@ def gemm_ln_heads(x, wf, stats, colsum, shift, out, *, seq: int, hd: int, tile_c
         raise VidiHipError("gemm_ln_heads: `out` must be a contiguous buffer of M * N elements")
     _check(lib.vidi_gemm_ln_heads(_p(x), _p(wf), _p(stats), _p(colsum), _p(shift), _p(out), M, N, K, x.stride(0), wf.stride(0), seq, hd,
                                   tile_cfg, _dt(x), _stream()), "vidi_gemm_ln_heads")
-    return out
-
-
-def gemm_ln_rows(x, wf, stats, colsum, shift, out=None, *, eps: float, act: int = ACT_NONE, tile_cfg: int = -1):
-    """out = act(Linear(LayerNorm_eps(x))) from the un-normalised rows alone: the row statistics are computed inside the call (in the
-    persistent kernel's K loop, or by a row pass into `stats` — a caller-owned fp32 scratch of 2 * M elements — for small problems)"""
-    lib = load_library()
-    _rowmajor(x, "x"); _rowmajor(wf, "wf")
-    M, K = x.shape
-    N = wf.shape[0]
-    _ln_vecs(stats, colsum, shift, M, N)
-    if out is None:
-        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    _check(lib.vidi_gemm_ln_rows(_p(x), _p(wf), _p(stats), _p(colsum), _p(shift), _p(out), M, N, K, x.stride(0), wf.stride(0), out.stride(0),
-                                 float(eps), act, tile_cfg, _dt(x), _stream()), "vidi_gemm_ln_rows")
-    return out
-
-
-def gemm_ln_rows_heads(x, wf, stats, colsum, shift, out, *, eps: float, seq: int, hd: int, tile_cfg: int = -1):
-    """gemm_ln_rows (no activation) writing the q | k | v projection head-major: out[which][frame][head][token][d]"""
-    lib = load_library()
-    _rowmajor(x, "x"); _rowmajor(wf, "wf")
-    M, K = x.shape
-    N = wf.shape[0]
-    _ln_vecs(stats, colsum, shift, M, N)
-    if not out.is_contiguous() or out.numel() < M * N:
-        raise VidiHipError("gemm_ln_rows_heads: `out` must be a contiguous buffer of M * N elements")
-    _check(lib.vidi_gemm_ln_rows_heads(_p(x), _p(wf), _p(stats), _p(colsum), _p(shift), _p(out), M, N, K, x.stride(0), wf.stride(0), seq, hd,
-                                       float(eps), tile_cfg, _dt(x), _stream()), "vidi_gemm_ln_rows_heads")
     return out
 
 
