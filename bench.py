@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-preproc", action="store_true", help="skip the extra (untimed-in-`value`) GPU preprocessing leg")
     ap.add_argument("--src-hw", type=int, nargs=2, default=[480, 854], help="decoded frame size fed to the preprocessing leg")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of sampled frames / K/V-cache rows after the timed region")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the (untimed-in-`value`) legs that run BASELINE configs[1] and configs[4] on this GPU "
+                    "after the headline workload (default workload, one GPU only)")
     ap.add_argument("--attn-gain", type=float, default=ATTN_GAIN, help="factor on the decoder's random q_proj weights (a power of two is exact in "
                                                                         "bf16/fp16): sharper text->video attention; 1 = SURVEY 8d's plain randn * 0.02")
     return ap.parse_args()
@@ -666,6 +668,69 @@ def main():
                 print(json.dumps({"verify": verify}), file=sys.stderr)
             raise RuntimeError("bench: the HIP path disagrees with the oracle on the sampled rows (see `verify` on stderr)")
 
+    # ---- the other single-GPU BASELINE configurations, measured in the same run (never part of `value`) ----
+    # configs[1]: 5-min video @1 fps, one query; configs[4] on ONE GPU: 30 min @2 fps (3 600 frames), 8 ragged prompts sharing the video, 128
+    # decoded tokens per query.  Same synthetic video (its first frames / windows), same weights, one warm-up + one timed prefill each.
+    other = None
+    if world == 1 and not a.no_other_configs and a.preset == "vidi15_9b" and a.frames == 3600 and a.fps == 1.0 and a.queries == 1:
+        del mm, ts
+        torch.cuda.empty_cache()
+
+        def run_config(T2, fps2, queries2, ragged2, ndec):
+            secs2 = T2 / fps2
+            Cw2, asz2 = math.ceil(secs2 / 30), int(round(secs2 * 100))
+            px2, mel2 = pixel[:T2], mel[:Cw2]
+            pl2 = [a.prompt_len] * queries2 if ragged2 is None else [ragged2[0] + round(i * (ragged2[1] - ragged2[0]) / max(1, queries2 - 1)) for i in range(queries2)]
+            g2 = torch.Generator().manual_seed(2)
+            ids2 = torch.randint(1000, min(200000, cfg.vocab_size), (queries2, max(pl2) + 1), generator=g2)
+            ids2[:, 0] = cfg.bos_token_id
+            ids2[:, 4] = -200
+            am2 = None
+            if len(set(pl2)) > 1:
+                am2 = torch.arange(ids2.shape[1])[None, :] < (torch.tensor(pl2)[:, None] + 1)
+                ids2 = torch.where(am2, ids2, torch.full_like(ids2, cfg.pad_token_id if cfg.pad_token_id is not None else 0))
+            idt2, mask2, pos2 = strip_image_token(ids2, am2)
+            hw2 = token_budget_hw(T2, cfg.vis_side, cfg.mm_image_pool_size, cfg.mm_max_tokens_base)
+            h2, w2 = hw2 if hw2[0] != 28 else (cfg.vis_side + 1, cfg.vis_side + 1)
+            Nv2 = T2 * (h2 // cfg.mm_image_pool_size) * (w2 // cfg.mm_image_pool_size)
+            Na2 = audio_token_counts(asz2, cfg)[1]
+
+            def prefill():
+                e = [ev()]
+                fi, mi = eng.encode_video_images(px2, frame_offset=0, total_frames=T2, normalizer=eng.normalizer, sample_flag=eng.sample_flag(px2)); e.append(ev())
+                fa, ma = eng.encode_video_audios(mel2, asz2, normalizer=eng.normalizer, chunk_offset=0, sample_flag=eng.sample_flag(mel2)); e.append(ev())
+                mm2 = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True); e.append(ev())
+                ts2, last2 = model._prefill(idt2, mask2, pos2, mm2, ndec + 1)
+                _, nx2 = eng.logits_argmax(last2); e.append(ev())
+                return mm2, ts2, nx2, e
+            w = prefill()
+            decode_eager(w[1], w[0], w[2], 2)
+            del w
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mm2, ts2, nx2, e = prefill()
+            torch.cuda.synchronize()
+            t_pre = time.perf_counter() - t0
+            td = time.perf_counter()
+            nx2 = decode_eager(ts2, mm2, nx2, ndec)
+            torch.cuda.synchronize()
+            t_dec = (time.perf_counter() - td) / max(1, ndec)
+            if not bool(torch.isfinite(nx2.float()).all()):
+                raise RuntimeError("non-finite decode output")
+            rec = {"frames": T2, "fps": fps2, "queries": queries2, "prompt_tokens": pl2 if len(set(pl2)) > 1 else pl2[0], "video_tokens": Nv2, "audio_tokens": Na2,
+                   "video_tokens_per_s": Nv2 / t_pre, "prefill_ms": t_pre * 1e3, "decode_ms_per_step": t_dec * 1e3, "decode_tokens": ndec,
+                   "sec_per_query": (t_pre + ndec * t_dec) / queries2,
+                   "stage_ms": dict(zip(("vision_encode", "audio_encode", "mm_stream", "text_prefill"), (e[i].elapsed_time(e[i + 1]) for i in range(4))))}
+            del mm2, ts2
+            torch.cuda.empty_cache()
+            return rec
+        try:
+            other = {"configs[1] 5-min@1fps, 1 query": run_config(300, 1.0, 1, None, a.decode_steps),
+                     "configs[4] on ONE GPU: 30-min@2fps, 8 ragged prompts, 128 tokens": run_config(3600, 2.0, 8, (24, 52), 128),
+                     "note": "same run, same box, after the timed headline steps; one warm-up + one timed prefill each; never part of `value`"}
+        except Exception as e:          # never lose the headline line to an extra leg
+            other = {"error": repr(e)}
+
     # ---- box-speed reference (untimed): frozen probe kernels, so that records from different boxes can be normalised ----
     box = None
     try:
@@ -721,7 +786,7 @@ def main():
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
         "first_token": first_token, "first_token_logit_abs_sum": logit_checksum, "attn_gain": a.attn_gain, "verify": verify,
         "kernel_families": fams, "kernel_family_steps": timer_steps,
-        "roofline": roof, "box_reference": box,
+        "roofline": roof, "box_reference": box, "other_baseline_configs": other,
     }
     if world == 1 and not a.no_preproc:
         # SURVEY §8f-2 leg, reported beside the metric and never part of `value`: decoded RGB frames (uint8) and 16 kHz PCM
