@@ -182,9 +182,11 @@ int vidi_attn_self_rm(const void* QKV, void* O, int B, int N, int H, int D, int 
  * Opart:[W][nkv][Rpad][HD] fp32, ML:[W][nkv][Rpad][2] fp32 (base-2 running max, sum). */
 size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD);
 /* 32-row tiles ONE block of the launch covers for a launch of Rpad rows per kv head: 1 (a block = one row tile, its four waves split the
- * key slice) or 4 (two row tiles and more — a prompt, a batch of prompts: the block's four waves own four row tiles and share one K / V
- * stream, so the keys are read once per four tiles).  The launch runs nkv x ceil(Rpad / 32 / this) x zsplit blocks: size zsplit with it. */
-int vidi_attn_cross_row_tiles_per_block(int Rpad);
+ * key slice) or 4 (two row tiles and more — a prompt, a batch of prompts — with a logit softcap, in bf16: the block's four waves own four
+ * row tiles and share one K / V stream, so the keys are read once per four tiles; the softmax there runs against a fixed reference,
+ * which needs the softcap's bound on the logits and bf16's exponent range).  The launch runs nkv x ceil(Rpad / 32 / this) x zsplit
+ * blocks: size zsplit with it. */
+int vidi_attn_cross_row_tiles_per_block(int Rpad, float softcap, int dtype);
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,
                     float scale, float softcap, int zsplit, int dtype, void* stream);

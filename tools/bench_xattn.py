@@ -47,7 +47,7 @@ def main():
         ms = e0.elapsed_time(e1) / a.iters
         print(json.dumps({"kernel": "attn_cross+merge", "Lq": a.lq, "keys": Nk, "zsplit": zs, "ms": ms,
                           "GBps": Nk * 2 * nkv * HD * 2 / ms / 1e6, "TFLOPs": 4.0 * a.lq * Nk * nkv * G * HD / ms / 1e9,
-                          "row_tiles_per_block": hip.attn_cross_row_tiles_per_block(Rpad)}), flush=True)
+                          "row_tiles_per_block": hip.attn_cross_row_tiles_per_block(Rpad, 50.0, torch.bfloat16)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -324,235 +324,6 @@ __global__ __launch_bounds__(256) void attn_cross2_kernel(AttnCrossParams a, Att
     else attn_cross_body<T, HD>(b, bz - za, (int)gridDim.z - za);
 }
 
-// ---- many query rows (a prompt: 2 x Lq rows per kv head; a batch of prompts: hundreds) ------------------------------------------------
-// attn_cross_body gives every 32-row tile its own blocks, each of which streams its key slice through private per-wave rings: R / 32 row
-// tiles read the whole K / V R / 32 times.  At the 8-prompt prefill of BASELINE configs[4] (608 rows = 19 row tiles) that is 14 GB of
-// L2 -> LDS traffic per layer and modality for 0.74 GB of keys — the launch ran at 0.3 PFLOP/s and 0.5 TB/s of unique bytes, bound by the
-// L2's bandwidth (round-4 verdict item 4; profiles/r5_notes.md).  Here the four waves of a block own FOUR DIFFERENT row tiles and share
-// ONE K / V stream: a 32-key sub-tile (K 32 x HD, Vt HD x 32: 32 KB at HD = 256) is DMA'd into a block-wide ring of three slots once —
-// every wave issues a quarter of its 1 KB pieces — and consumed by all four waves, each with its own register-resident Q fragments,
-// online softmax state and accumulators.  One barrier per sub-tile: at the top of step i every wave has waited for its own pieces of
-// sub-tile i (the barrier makes that "all pieces") and has finished reading sub-tile i - 1, whose slot the DMA of sub-tile i + 2 then
-// overwrites.  A wave writes the partial (O, m, l) of its row tile itself — same partial layout, same merge kernels.  Per sub-tile the
-// arithmetic is attn_cross_body's, instruction for instruction; a (row tile, key slice) partial differs from it only in which keys the
-// slice holds.  K / V traffic per launch drops 4x (and the row blocks of one kv head run on one XCD and share its L2).
-template <typename T, int HD>
-__device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, const int z, const int zsplit) {
-    constexpr int QROW = HD * 2;
-    constexpr int CPR = HD / 8;
-    constexpr int KST = HD / 16;
-    constexpr int DT = HD / 32;
-    constexpr int KBYTES = 32 * QROW;
-    constexpr int VBYTES = HD * 64;
-    constexpr int KLD = KBYTES / 1024, VLD = VBYTES / 1024;      // 1 KB DMA pieces per sub-tile
-    constexpr int KPW = KLD / 4, VPW = VLD / 4;                  // ... per wave
-    constexpr int SLOT = KBYTES + VBYTES, NSLOT = 3;
-    static_assert(KLD % 4 == 0 && VLD % 4 == 0 && (KPW + VPW == 8 || KPW + VPW == 4), "HD must be 128 or 256");
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][K sub-tile | Vt sub-tile]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int kvh = blockIdx.x;
-    const int r0 = (blockIdx.y * 4 + wave) * 32;                 // this wave's row tile
-    const bool active = r0 < p.R;                                // (a block's last waves may have no rows: they only move data)
-
-    // Q fragments straight from global memory (B operand: column = row l31, contraction chunk 2 ks + hi); rows beyond R are zero
-    u32x4 qf[KST];
-    {
-        const int r = r0 + l31;
-        const bool live = r < p.R;
-        const int rc = live ? r : 0;
-        const u16* qrow = p.Q + (size_t)(rc / p.G) * p.ldq + (kvh * p.G + rc % p.G) * HD;
-#pragma unroll
-        for (int ks = 0; ks < KST; ++ks) qf[ks] = live ? *(const u32x4*)(qrow + (2 * ks + hi) * 8) : u32x4{0, 0, 0, 0};
-        // the fragments are consumed HERE as far as the compiler's wait-count bookkeeping goes: their loads are then complete before the first
-        // DMA is issued, and the loop carries no pending ordinary load (with one pending at the loop header the compiler put vmcnt(0) — a
-        // full drain of the K / V ring — in front of the first MFMA of every sub-tile: seen in the ISA)
-#pragma unroll
-        for (int ks = 0; ks < KST; ++ks) asm volatile("" : "+v"(qf[ks]));
-    }
-
-    const int nsub = (p.n_keys + 31) / 32;
-    const int n_mine = z < nsub ? (nsub - z + zsplit - 1) / zsplit : 0;     // sub-tiles z, z + zsplit, ... (interleaved over the slices)
-    const u16* kc_head = p.Kc + (size_t)kvh * p.ntile64 * 64 * HD;
-    const u16* vt_head = p.Vtc + (size_t)kvh * p.ntile64 * HD * 64;
-    auto issue = [&](int i) {                                    // sub-tile i of this block -> slot i % NSLOT; this wave's quarter of the pieces
-        const int st = z + i * zsplit;
-        const int kb = p.key_start + st * 32;
-        char* sK = smem + (i % NSLOT) * SLOT;
-        char* sV = sK + KBYTES;
-        const u16* ksrc = kc_head + (size_t)kb * HD;
-        const u16* vsrc = vt_head + (size_t)(kb >> 5) * HD * 32;
-#pragma unroll
-        for (int jj = 0; jj < KPW; ++jj) {
-            const int j = wave * KPW + jj;
-            const int pidx = j * 64 + lane, row = pidx / CPR, cl = pidx % CPR;
-            glds16(ksrc + row * HD + (cl ^ (row & 15)) * 8, sK + j * 1024);      // (default cache policy: the other row blocks re-read the slice from L2)
-        }
-#pragma unroll
-        for (int jj = 0; jj < VPW; ++jj) {
-            const int j = wave * VPW + jj;
-            const int pidx = j * 64 + lane, d = pidx >> 2, cl = pidx & 3;
-            glds16(vsrc + d * 32 + (cl ^ ((d >> 2) & 3)) * 8, sV + j * 1024);
-        }
-    };
-
-    f32x16 o[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float L2E = 1.4426950408889634f;
-    const bool use_cap = p.softcap > 0.f;
-    const float pre = use_cap ? p.scale / p.softcap : p.scale * L2E;
-    const float capl2 = p.softcap * L2E;
-
-    if (n_mine > 0) issue(0);
-    if (n_mine > 1) issue(1);
-    for (int i = 0; i < n_mine; ++i) {
-        // this wave's pieces of sub-tile i have landed (those of i + 1 may be in flight) ...
-        if (i + 1 < n_mine) wait_vmcnt<KPW + VPW>(); else wait_vmcnt<0>();
-        // ... and after the barrier so have everybody's; every wave is also done reading sub-tile i - 1
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (i + 2 < n_mine) issue(i + 2);
-        if (!active) continue;
-        const char* sK = smem + (i % NSLOT) * SLOT;
-        const char* sV = sK + KBYTES;
-        const int st = z + i * zsplit;
-        // ---- S^T = K Q^T ----
-        f32x16 s;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-        {
-            u32x4 kf[2][4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                kf[0][e] = *(const u32x4*)(sK + l31 * QROW + ((((2 * e + hi)) ^ (l31 & 15)) << 4));
-#pragma unroll
-            for (int kb4 = 0; kb4 < KST / 4; ++kb4) {
-                if (kb4 + 1 < KST / 4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        kf[(kb4 + 1) & 1][e] = *(const u32x4*)(sK + l31 * QROW + (((2 * ((kb4 + 1) * 4 + e) + hi) ^ (l31 & 15)) << 4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s = T::mfma32(kf[kb4 & 1][e], qf[kb4 * 4 + e], s);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- logits: scale, softcap, mask; online softmax in base 2 (attn_cross_body's arithmetic) ----
-        const int kb_local = st * 32;
-        u32x4 pf0, pf1;
-        {
-            float mx = -INFINITY;
-            if (use_cap) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e2 = __expf(2.0f * s[r] * pre);
-                    s[r] = capl2 * (1.0f - 2.0f / (e2 + 1.0f));
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] *= pre;
-            }
-            if (kb_local + 32 > p.n_keys) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kb_local + krow32(r, hi) >= p.n_keys) s[r] = -INFINITY;
-            }
-            if (p.mask) {
-                const unsigned char* mp = p.mask + kb_local + 4 * hi;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned mv = *(const unsigned*)(mp + 8 * j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (((mv >> (8 * e)) & 0xffu) == 0) s[4 * j + e] = -INFINITY;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp2(m_run - m_use);
-            m_run = m_new;
-            float pv[16], psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pv[r] = fast_exp2(s[r] - m_use);
-                psum += pv[r];
-            }
-            l_run = l_run * alpha + psum;
-            pf0 = pack8<T>(pv);
-            pf1 = pack8<T>(pv + 8);
-            if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
-            }
-        }
-        // ---- O^T += Vt P^T ----
-        {
-            u32x4 vf[2][4];
-            auto read_v = [&](int buf, int dt0) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int d = (dt0 + e) * 32 + l31;
-                    const int swz = (d >> 2) & 3;
-                    vf[buf][2 * e] = *(const u32x4*)(sV + d * 64 + (((0 + hi) ^ swz) << 4));
-                    vf[buf][2 * e + 1] = *(const u32x4*)(sV + d * 64 + (((2 + hi) ^ swz) << 4));
-                }
-            };
-            read_v(0, 0);
-#pragma unroll
-            for (int b2 = 0; b2 < DT / 2; ++b2) {
-                if (b2 + 1 < DT / 2) read_v((b2 + 1) & 1, (b2 + 1) * 2);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    o[b2 * 2 + e] = T::mfma32(vf[b2 & 1][2 * e], pf0, o[b2 * 2 + e]);
-                    o[b2 * 2 + e] = T::mfma32(vf[b2 & 1][2 * e + 1], pf1, o[b2 * 2 + e]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // every LDS read of this sub-tile has returned before the wave can reach the next barrier (their consumers are above)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-
-    // ---- this wave's partial: numerator rows, (m, l) — the layout of one attn_cross_body partial ----
-    if (!active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const int r = r0 + l31;
-    if (r < p.R) {
-        const size_t base = ((size_t)z * p.nkv + kvh) * p.Rpad + r;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 ov = {o[dt][4 * j], o[dt][4 * j + 1], o[dt][4 * j + 2], o[dt][4 * j + 3]};
-                *(f32x4*)(p.Opart + base * HD + dt * 32 + 8 * j + 4 * hi) = ov;
-            }
-        if (hi == 0) {
-            p.ML[base * 2] = m_run;
-            p.ML[base * 2 + 1] = l_tot;
-        }
-    }
-}
-
-// one or two modalities' key regions in one launch (b.n_keys <= 0: only a); the first `za` z-slices sweep set a's keys
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_cross_rows_kernel(AttnCrossParams a, AttnCrossParams b, int za) {
-    const int bz = blockIdx.z;
-    if (bz < za) attn_cross_rows_body<T, HD>(a, bz, za);
-    else attn_cross_rows_body<T, HD>(b, bz - za, (int)gridDim.z - za);
-}
-
 // Combine W partials per (row, kv head): O = sum_w 2^(m_w-m) O_w / sum_w 2^(m_w-m) l_w.
 // Optionally emits the merged result in PARTIAL form (numerator, m, l) for a further cross-GPU merge.
 
@@ -686,38 +457,20 @@ int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b
 
 // Row tiles (32 rows) a block of the cross-attention launch covers: 4 — the shared-stream kernel above — from two row tiles on
 // (VIDI_XATTN_ROWS=0: never, the A/B arm), else 1.  Callers size the key split with it (blocks = nkv x ceil(row tiles / this) x slices).
-int vidi_attn_cross_rtpb(int Rpad) {
+int vidi_attn_cross_rtpb(int Rpad, float softcap, int dtype) {
     static const int on = [] { const char* e = getenv("VIDI_XATTN_ROWS"); return (e && atoi(e) == 0) ? 0 : 1; }();
-    return (on && Rpad > 32) ? 4 : 1;
+    // the shared-stream kernel's softmax has no running maximum: it needs the tanh softcap's bound on the logits and bf16's exponent range
+    return (on && Rpad > 32 && softcap > 0.f && dtype == VIDI_DT_BF16) ? 4 : 1;
 }
 
-static int launch_cross_rows(const AttnCrossParams& a, const AttnCrossParams& b, int za, int zb, int HD, int dtype, hipStream_t st) {
-    const dim3 grid(a.nkv, (a.Rpad / 32 + 3) / 4, za + zb);
-    const int lds = 3 * (32 * HD * 2 + HD * 64);
-#define LAUNCH(TT, HH)                                                                        \
-    do {                                                                                      \
-        auto kern = attn_cross_rows_kernel<TT, HH>;                                           \
-        static bool done = false;                                                             \
-        if (!done) {                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            if (e != hipSuccess) return (int)e;                                               \
-            done = true;                                                                      \
-        }                                                                                     \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, b, za);                         \
-    } while (0)
-    if (dtype == VIDI_DT_BF16) { if (HD == 256) LAUNCH(BF16, 256); else LAUNCH(BF16, 128); }
-    else if (dtype == VIDI_DT_F16) { if (HD == 256) LAUNCH(F16, 256); else LAUNCH(F16, 128); }
-    else return VIDI_ERR_DTYPE;
-#undef LAUNCH
-    return (int)hipGetLastError();
-}
+int vidi_attn_cross_rows_launch(const AttnCrossParams& a, const AttnCrossParams& b, int za, int zb, int HD, int dtype, hipStream_t st);      // attn_cross_rows.hip
 
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st) {
     if (p.R <= 0 || p.n_keys <= 0 || p.G <= 0 || p.nkv <= 0 || zsplit <= 0) return VIDI_ERR_SHAPE;
     if (p.key_start % 64 != 0 || p.Rpad % 32 != 0 || p.Rpad < p.R) return VIDI_ERR_SHAPE;
     if ((p.ldq % 8) || ((uintptr_t)p.Q & 15) || ((uintptr_t)p.Kc & 15) || ((uintptr_t)p.Vtc & 15)) return VIDI_ERR_ALIGN;
     if (HD != 256 && HD != 128) return VIDI_ERR_SHAPE;
-    if (vidi_attn_cross_rtpb(p.Rpad) == 4) return launch_cross_rows(p, p, zsplit, 0, HD, dtype, st);
+    if (vidi_attn_cross_rtpb(p.Rpad, p.softcap, dtype) == 4) return vidi_attn_cross_rows_launch(p, p, zsplit, 0, HD, dtype, st);
     const dim3 grid(p.nkv, p.Rpad / 32, zsplit);
     const int lds = 32 * HD * 2 + 4 * (32 * HD * 2 + HD * 64);
 #define LAUNCH(TT, HH)                                                                        \
@@ -743,7 +496,7 @@ int vidi_attn_cross2_dispatch(const AttnCrossParams& a, const AttnCrossParams& b
     if (a.key_start % 64 != 0 || b.key_start % 64 != 0 || a.Rpad % 32 != 0 || a.Rpad < a.R) return VIDI_ERR_SHAPE;
     if ((a.ldq % 8) || ((uintptr_t)a.Q & 15) || ((uintptr_t)a.Kc & 15) || ((uintptr_t)a.Vtc & 15)) return VIDI_ERR_ALIGN;
     if (HD != 256 && HD != 128) return VIDI_ERR_SHAPE;
-    if (vidi_attn_cross_rtpb(a.Rpad) == 4) return launch_cross_rows(a, b, za, zb, HD, dtype, st);
+    if (vidi_attn_cross_rtpb(a.Rpad, a.softcap, dtype) == 4) return vidi_attn_cross_rows_launch(a, b, za, zb, HD, dtype, st);
     const dim3 grid(a.nkv, a.Rpad / 32, za + zb);
     const int lds = 32 * HD * 2 + 4 * (32 * HD * 2 + HD * 64);
 #define LAUNCH(TT, HH)                                                                        \

@@ -296,7 +296,7 @@ size_t vidi_attn_cross_workspace_bytes(int zsplit, int nkv, int Rpad, int HD) {
     return W * nkv * Rpad * (size_t)(HD + 2) * sizeof(float);
 }
 
-int vidi_attn_cross_row_tiles_per_block(int Rpad) { return vidi_attn_cross_rtpb(Rpad); }
+int vidi_attn_cross_row_tiles_per_block(int Rpad, float softcap, int dtype) { return vidi_attn_cross_rtpb(Rpad, softcap, dtype); }
 
 int vidi_attn_cross(const void* Q, const void* Kc, const void* Vtc, const void* mask, float* Opart, float* ML,
                     int R, int Rpad, int G, int nkv, int HD, int ldq, int ntile64, int key_start, int n_keys,

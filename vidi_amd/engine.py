@@ -755,7 +755,7 @@ class VidiEngine:
         mask = mm.img_mask if which == "img" else mm.aud_mask
         Rpad = _round_up(R, 32)
         nsub = (n + 31) // 32
-        row_blocks = -(-(Rpad // 32) // hip.attn_cross_row_tiles_per_block(Rpad))      # blocks along the rows (a block covers 1 or 4 row tiles)
+        row_blocks = -(-(Rpad // 32) // hip.attn_cross_row_tiles_per_block(Rpad, cfg.attn_logit_softcapping, self.dtype))      # blocks along the rows (a block covers 1 or 4 row tiles)
         zsplit = max(1, min(256 // max(1, nkv * row_blocks), (nsub + 7) // 8))
         key = f"xattn_ws_{which}_{zsplit}_{Rpad}"        # one workspace per modality: both partial sets live until the merge
         if key not in self._ws:
@@ -789,7 +789,7 @@ class VidiEngine:
         nkv, hd = cfg.num_key_value_heads, cfg.head_dim
         G = cfg.num_attention_heads // nkv
         Rpad = _round_up(R, 32)
-        Z = 256 // max(1, nkv * -(-(Rpad // 32) // hip.attn_cross_row_tiles_per_block(Rpad)))
+        Z = 256 // max(1, nkv * -(-(Rpad // 32) // hip.attn_cross_row_tiles_per_block(Rpad, cfg.attn_logit_softcapping, self.dtype)))
         if mm.n_img <= 0 or mm.n_aud <= 0 or Z < 2:
             return False
         from .shard import split_key_slices

@@ -106,7 +106,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.vidi_gemm_skinny_workspace_bytes.restype = ctypes.c_size_t
     lib.vidi_gemm_skinny_workspace_bytes.argtypes = [_c_int] * 3
     lib.vidi_attn_cross_row_tiles_per_block.restype = _c_int
-    lib.vidi_attn_cross_row_tiles_per_block.argtypes = [_c_int]
+    lib.vidi_attn_cross_row_tiles_per_block.argtypes = [_c_int, _c_f, _c_int]
     lib.vidi_gemv_mfma_fits.restype = _c_int
     lib.vidi_gemv_mfma_fits.argtypes = [_c_int] * 4
     lib.vidi_stat_strips.restype = _c_int
@@ -449,9 +449,9 @@ def probe_box(buf: torch.Tensor, mfma_ms: float = 250.0) -> dict:
             "note": "frozen reference kernels (vidi_amd/csrc/probe.hip): divide figures of different boxes by these to compare builds"}
 
 
-def attn_cross_row_tiles_per_block(Rpad: int) -> int:
+def attn_cross_row_tiles_per_block(Rpad: int, softcap: Optional[float], dtype: torch.dtype) -> int:
     """32-row tiles one block of vidi_attn_cross / vidi_attn_cross2 covers at Rpad rows per kv head (1 or 4): callers size `zsplit` with it"""
-    return int(load_library().vidi_attn_cross_row_tiles_per_block(int(Rpad)))
+    return int(load_library().vidi_attn_cross_row_tiles_per_block(int(Rpad), float(softcap or 0.0), DT_BF16 if dtype == torch.bfloat16 else DT_F16))
 
 
 def gemv_mfma_fits(M: int, N: int, K: int, glu: bool = False) -> bool:
