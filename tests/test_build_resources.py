@@ -20,6 +20,7 @@ HOT = {
     "attn_self.resources.txt": ["attn_self_kernel"],
     "attn_self_rm.resources.txt": ["attn_self_rm_kernel"],
     "attn_cross.resources.txt": ["attn_cross_kernel", "attn_cross2_kernel", "attn_merge"],
+    "attn_cross_rows.resources.txt": ["attn_cross_rows_kernel"],
     "attn_text.resources.txt": ["attn_text_kernel", "attn_text_decode_kernel", "rope_cache_kernel"],
     "rowops.resources.txt": ["norm_kernel", "resid_norm2_kernel", "resid_norm2_rows_kernel", "row_stats_kernel"],
     "elementwise.resources.txt": ["softcap_argmax_kernel"],
@@ -145,3 +146,44 @@ def test_transpose_read_destinations_untouched_until_the_wait():
                 viol.append((kern, line.strip()))
     assert reads >= 100 and windows >= 10, (reads, windows)            # the asm form is the one that was built
     assert not viol, viol[:5]
+
+
+def test_asm_matrix_instructions_of_the_many_row_cross_attention_keep_their_distances():
+    """vidi_amd/csrc/attn_cross_rows.hip issues its MFMAs from inline asm with pinned register files (the accumulators in AGPRs): the compiler
+    sees opaque statements and inserts none of the wait states gfx940+ needs in software around matrix instructions, nor does it know that a
+    copy of an accumulator into a VGPR reads a matrix result.  The kernel keeps those distances by construction; this test reads them back
+    from the compiled ISA: the main loop must not touch the accumulator file with anything but the MFMAs (no v_accvgpr_* — a copy there means
+    the compiler carries accumulators in VGPRs again: 300 extra VALU instructions per sub-tile and reads of in-flight results), no spills,
+    and no non-matrix instruction may read an MFMA's result within the scanned window behind it."""
+    import subprocess
+    import sys
+    import tempfile
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "vidi_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "x.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", csrc, os.path.join(csrc, "attn_cross_rows.hip"), "-o", out],
+                       check=True, capture_output=True)
+        src = open(out).read()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mfma_hazards as H
+    found = 0
+    for m in re.finditer(r"^(_Z22attn_cross_rows_kernel\w+):[^\n]*\n", src, re.M):
+        body = src[m.end(): src.find(".Lfunc_end", m.end())]
+        lines = body.split("\n")
+        heads = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
+        assert heads, "no loop found"
+        for h in heads:                                        # (the two modalities' bodies are inlined: two loops per kernel)
+            label = lines[h].split(":")[0].strip()
+            ends = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\s*$", l) and i > h]
+            assert ends, f"no back edge to {label}"
+            loop = [l for l in lines[h: ends[-1] + 1] if l.strip() and not l.strip().startswith(";")]
+            assert not [l for l in loop if "v_accvgpr" in l], f"{m.group(1)}: the main loop copies accumulator registers: {[l.strip() for l in loop if 'v_accvgpr' in l][:3]}"
+            assert not [l for l in loop if "scratch_" in l], f"{m.group(1)}: spills inside the main loop"
+            assert sum("v_mfma" in l for l in loop) in (32, 16), "QK^T + PV of one sub-tile"
+        n, _, _, min_reader, worst = H.scan(lines)
+        assert n and min_reader >= 10, f"{m.group(1)}: an instruction reads a matrix result {min_reader} instructions behind its MFMA: {worst}"
+        found += 1
+    assert found == 2, "bf16 kernels of both head dims"

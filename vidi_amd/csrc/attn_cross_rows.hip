@@ -30,9 +30,9 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     constexpr int VBYTES = HD * 64;
     constexpr int KLD = KBYTES / 1024, VLD = VBYTES / 1024;      // 1 KB DMA pieces per sub-tile
     constexpr int KPW = KLD / 4, VPW = VLD / 4;                  // ... per wave
-    constexpr int SLOT = KBYTES + VBYTES, NSLOT = 4;
+    constexpr int KSLOTS = 3, VSLOTS = 5;                        // rings: see the pipeline below
     static_assert(KLD % 4 == 0 && VLD % 4 == 0 && (KPW + VPW == 8 || KPW + VPW == 4), "HD must be 128 or 256");      // (wait_vmcnt<> knows 0, 4, 8, 16)
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][K sub-tile | Vt sub-tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][K sub-tile] [5][Vt sub-tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -60,11 +60,12 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     const int n_mine = z < nsub ? (nsub - z + zsplit - 1) / zsplit : 0;     // sub-tiles z, z + zsplit, ... (interleaved over the slices)
     const u16* kc_head = p.Kc + (size_t)kvh * p.ntile64 * 64 * HD;
     const u16* vt_head = p.Vtc + (size_t)kvh * p.ntile64 * HD * 64;
-    auto issue = [&](int i) {                                    // sub-tile i of this block -> slot i % NSLOT; this wave's quarter of the pieces
+    char* const vring = smem + KSLOTS * KBYTES;
+    auto issue = [&](int i) {                                    // sub-tile i of this block -> K slot i % 3, V slot i % 5; this wave's quarter of the pieces
         const int st = z + i * zsplit;
         const int kb = p.key_start + st * 32;
-        char* sK = smem + (i % NSLOT) * SLOT;
-        char* sV = sK + KBYTES;
+        char* sK = smem + (i % KSLOTS) * KBYTES;
+        char* sV = vring + (i % VSLOTS) * VBYTES;
         const u16* ksrc = kc_head + (size_t)kb * HD;
         const u16* vsrc = vt_head + (size_t)(kb >> 5) * HD * 32;
 #pragma unroll
@@ -100,11 +101,15 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     const float capl2 = p.softcap * L2E;
     const float m_run = capl2 - XSHIFT;                            // the reference every partial of this launch reports
 
-    // Software pipeline over the sub-tiles (the wave is alone on its SIMD: whatever overlaps must overlap inside it): QK^T of sub-tile i + 1
-    // is issued BEFORE the softmax of sub-tile i, so the matrix pipe works through its 16 dependent MFMAs while the VALU runs the tanh
-    // softcap / exponentials of the scores it produced one step earlier; PV of sub-tile i follows.  Sub-tile i + 1's K must then be in LDS at
-    // step i: the ring has FOUR slots (K / V of i and i + 1 being read, i + 2 landing, i + 3 requested) and the barrier at the top of step i
-    // says "everybody's pieces of i + 1 have landed, everybody is done with K(i) and V(i - 1)".
+    // Software pipeline over the sub-tiles, three stages deep (the wave is alone on its SIMD: whatever overlaps must overlap inside it, and a
+    // wave issues in order).  Step i runs, score by score:
+    //     matrix pipe:  one MFMA of QK^T(i + 1)   +   one MFMA of PV(i - 1)          (64 cycles of the pipe)
+    //     VALU:         softcap + exponential of one score of sub-tile i            (~60 cycles: two v_exp, one v_rcp)
+    // so the scores of sub-tile i + 1 and the products of sub-tile i - 1 are on the matrix pipe while the VALU turns sub-tile i's scores
+    // into probabilities (PMC before this form: the wave spent 22 % of its cycles waiting on back-to-back PV instructions).  Data in LDS at
+    // step i: K(i + 1) and V(i - 1) are being read, sub-tile i + 2 is landing, i + 3 is requested -> a K ring of 3 slots (K(i) was last
+    // read in step i - 1) and a V ring of 5 (V(i - 2) was last read in step i - 1).  The barrier at the top of step i says "everybody's
+    // pieces of sub-tile i + 1 have landed, everybody is done with K(i) and V(i - 2)", after which the DMA of i + 3 may overwrite exactly those.
     f32x16 zero16;
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
@@ -113,30 +118,35 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     // fragments — in VGPRs.  Through the builtins the compiler kept the accumulators in VGPRs across the loop and copied all 128 into AGPRs
     // and back around every sub-tile's PV (or, with -amdgpu-mfma-vgpr-form, parked the Q fragments in AGPRs and copied them out per use):
     // 300+ of the loop's VALU instructions either way (ISA + PMC, profiles/r5_notes.md).  To the compiler these are opaque statements: the
-    // wait states gfx940+ needs around matrix instructions are kept BY HAND — a score tile is read in the iteration after the one whose
-    // MFMAs wrote it; VALU-written P fragments sit behind an s_nop; the accumulators are read only after the loop, behind s_nops; no operand
-    // is named in the AGPR file unless it lives there (an "a" operand held in VGPRs is copied in right in front of its MFMA: NaNs).
+    // wait states gfx940+ needs around matrix instructions are kept BY HAND — a score tile is read in the step after the one whose MFMAs
+    // wrote it; the P fragments a PV reads were written a whole step earlier; the accumulators are read only after the loop, behind s_nops;
+    // no operand is named in the AGPR file unless it lives there (an "a" operand held in VGPRs is copied in right in front of its MFMA:
+    // NaNs); every path through the loop issues the same matrix instructions (a path around them makes the compiler carry the accumulators
+    // in VGPRs).  tools/isa_mfma_hazards.py reads the distances back from the ISA.
     auto qk_mfma = [&](f32x16& c, const u32x4& a, const u32x4& b, bool first) __attribute__((always_inline)) {
         if (first) T::mfma32_bV_first(c, a, b); else T::mfma32_bV(c, a, b);
     };
-    auto qk = [&](const char* sK, f32x16& s) {               // the first sub-tile's scores (nothing to overlap with yet)
-        u32x4 kf[KST];
-#pragma unroll
-        for (int ks = 0; ks < KST; ++ks) kf[ks] = *(const u32x4*)(sK + l31 * QROW + (((2 * ks + hi) ^ (l31 & 15)) << 4));
-#pragma unroll
-        for (int ks = 0; ks < KST; ++ks) {
-            qk_mfma(s, kf[ks], qf[ks], ks == 0);
-        }
+    auto k_frag = [&](const char* sK, int ks) __attribute__((always_inline)) {
+        return *(const u32x4*)(sK + l31 * QROW + (((2 * ks + hi) ^ (l31 & 15)) << 4));
+    };
+    auto v_frag = [&](const char* sV, int j) __attribute__((always_inline)) {      // j = half * DT + dt: keys 16 half .. + 15 of d tile dt
+        const int d = (j % DT) * 32 + l31;
+        return *(const u32x4*)(sV + d * 64 + (((2 * (j / DT) + hi) ^ ((d >> 2) & 3)) << 4));
     };
     if (n_mine > 0) issue(0);
     if (n_mine > 1) issue(1);
     if (n_mine > 2) issue(2);
     f32x16 s_cur = zero16;
+    u32x4 pp0 = {0, 0, 0, 0}, pp1 = {0, 0, 0, 0};                  // P fragments of the previous sub-tile (none yet: the first PV adds 0 x V(0))
     if (n_mine > 0) {
         if (n_mine > 2) wait_vmcnt<2 * (KPW + VPW)>(); else if (n_mine > 1) wait_vmcnt<KPW + VPW>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        qk(smem, s_cur);
+        u32x4 kf[KST];
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) kf[ks] = k_frag(smem, ks);
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) qk_mfma(s_cur, kf[ks], qf[ks], ks == 0);
     }
     for (int i = 0; i < n_mine; ++i) {
         const bool more = i + 1 < n_mine;
@@ -146,85 +156,113 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
             asm volatile("" ::: "memory");
             if (i + 3 < n_mine) issue(i + 3);
         }
-        // (a block's waves without rows run the same instructions on zero Q fragments: with a path around the matrix instructions the compiler
-        // carried the accumulators across the loop in VGPRs and copied all of them into AGPRs and back around every sub-tile's PV)
-        const char* sV = smem + (i % NSLOT) * SLOT + KBYTES;
+        // (a block's waves without rows run the same instructions on zero Q fragments, and the last step multiplies whatever the next K slot
+        // holds — its scores are never used — so that every path through the loop issues the same matrix instructions)
+        const char* sKn = smem + ((i + 1) % KSLOTS) * KBYTES;
+        const char* sVp = vring + ((i > 0 ? i - 1 : 0) % VSLOTS) * VBYTES;      // step 0: V(0), landed, times P = 0
         const int st = z + i * zsplit;
+        const int kb_local = st * 32;
         f32x16 s = s_cur;
         f32x16 s_next = zero16;
-        // QK^T of sub-tile i + 1 (past the last one: whatever the slot holds — the scores are never used), ONE matrix instruction in front of
-        // each score's softcap + exponential: the 16 MFMAs form a dependent chain (32 cycles each), a score costs ~60 cycles of VALU (two
-        // v_exp, one v_rcp), and a wave issues in order — side by side in the source, fenced pair by pair, is the only way they overlap
-        const int kb_local = st * 32;
-        u32x4 pf0, pf1;
+        float pv[16];
         {
-            const char* sKn = smem + ((i + 1) % NSLOT) * SLOT;
-            // K fragments four at a time, one batch ahead of the MFMAs that use them; V fragments of the first PV group requested under the
-            // last scores (all 16 + 16 fragments at once took the kernel to 256 + 256 registers and 36 spills)
-            constexpr int NB = KST / 4;
-            u32x4 kf[2][4];
+            // K / V fragments four at a time, one batch ahead of the MFMAs that use them
+            u32x4 kf[2][4], vf[2][4];
             auto load_k = [&](int batch) __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    kf[batch & 1][e] = *(const u32x4*)(sKn + l31 * QROW + (((2 * (batch * 4 + e) + hi) ^ (l31 & 15)) << 4));
+                for (int e = 0; e < 4; ++e) kf[batch & 1][e] = k_frag(sKn, batch * 4 + e);
             };
-            u32x4 vf0[DT], vf1[DT];
-            auto load_v = [&](u32x4 (&vf)[DT], int half) __attribute__((always_inline)) {
+            auto load_v = [&](int batch) __attribute__((always_inline)) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const int d = dt * 32 + l31;
-                    const int swz = (d >> 2) & 3;
-                    vf[dt] = *(const u32x4*)(sV + d * 64 + (((2 * half + hi) ^ swz) << 4));
-                }
+                for (int e = 0; e < 4; ++e) vf[batch & 1][e] = v_frag(sVp, batch * 4 + e);
             };
             load_k(0);
-            float pv[16];
+            load_v(0);
+            // Four scores at a time in lock-step, and ONE matrix instruction in front of every ~32 cycles of VALU work: a wave issues in order,
+            // a 32x32x16 MFMA holds the matrix pipe for 32 cycles, and a second one issued right behind it stalls the wave for that long (PMC of
+            // the forms with two MFMAs back to back: 21-23 % of the wave's cycles waiting on instruction issue).  A group's VALU work — four
+            // multiplies, four v_exp (16 cycles each), four adds, four v_rcp, four fma, four v_exp — is cut into eight slots of about 32
+            // cycles; its eight matrix instructions (QK^T(i + 1) and PV(i - 1) alternating: two links of the dependent QK chain are 64+ cycles
+            // apart) lead the slots.  Fences keep the slots apart; inside a slot the order is free.
+            auto mq = [&](int r) __attribute__((always_inline)) { if (r < KST) qk_mfma(s_next, kf[(r / 4) & 1][r % 4], qf[r], r == 0); };
+            auto mp = [&](int r) __attribute__((always_inline)) { if (r < 2 * DT) T::mfma32_cA(o[r % DT], vf[(r / 4) & 1][r % 4], r < DT ? pp0 : pp1); };
+            auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+            const float c2 = -2.0f * capl2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r < KST && r % 4 == 0 && r / 4 + 1 < NB) load_k(r / 4 + 1);
-                if (r == 12) load_v(vf0, 0);
-                if (r < KST) qk_mfma(s_next, kf[(r / 4) & 1][r % 4], qf[r], r == 0);
-                // logit in base-2 units  cap2 tanh(y) = cap2 - 2 cap2 / (exp(2 y) + 1)  minus the FIXED reference m_ref = cap2 - XSHIFT:
-                //   p = 2^(XSHIFT - 2 cap2 / (exp(2 y) + 1)):  multiply, v_exp, add, v_rcp, fma, v_exp
-                const float e2 = fast_exp2(s[r] * pre2);
-                pv[r] = fast_exp2(__builtin_fmaf(-2.0f * capl2, __builtin_amdgcn_rcpf(e2 + 1.0f), XSHIFT));
-                asm volatile("" : "+v"(pv[r]));                        // (pure arithmetic: LLVM would sink it to its first user, behind the chain)
-                __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = 4 * g;
+                if (r0 + 4 < KST) load_k(g + 1);
+                if (r0 + 4 < 2 * DT) load_v(g + 1);
+                float x[4];
+                mq(r0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = s[r0 + e] * pre2;
+                x[0] = fast_exp2(x[0]);
+                fence();
+                mp(r0);
+                x[1] = fast_exp2(x[1]); x[2] = fast_exp2(x[2]);
+                fence();
+                mq(r0 + 1);
+                x[3] = fast_exp2(x[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = x[e] + 1.0f;
+                fence();
+                mp(r0 + 1);
+                x[0] = __builtin_amdgcn_rcpf(x[0]); x[1] = __builtin_amdgcn_rcpf(x[1]);
+                fence();
+                mq(r0 + 2);
+                x[2] = __builtin_amdgcn_rcpf(x[2]); x[3] = __builtin_amdgcn_rcpf(x[3]);
+                fence();
+                mp(r0 + 2);
+                // logit in base-2 units  cap2 tanh(y) = cap2 - 2 cap2 / (exp(2 y) + 1)  minus the FIXED reference m_ref = cap2 - XSHIFT
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(c2, x[e], XSHIFT);
+                pv[r0] = fast_exp2(x[0]);
+                fence();
+                mq(r0 + 3);
+                pv[r0 + 1] = fast_exp2(x[1]); pv[r0 + 2] = fast_exp2(x[2]);
+                fence();
+                mp(r0 + 3);
+                pv[r0 + 3] = fast_exp2(x[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(pv[r0 + e]));       // (pure arithmetic: LLVM would sink it to its first user)
+                fence();
             }
-            if (kb_local + 32 > p.n_keys) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kb_local + krow32(r, hi) >= p.n_keys) pv[r] = 0.f;
-            }
-            if (p.mask) {
-                const unsigned char* mp = p.mask + kb_local + 4 * hi;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned mv = *(const unsigned*)(mp + 8 * j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (((mv >> (8 * e)) & 0xffu) == 0) pv[4 * j + e] = 0.f;
-                }
-            }
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) psum += pv[r];
-            l_run += psum;
-            pf0 = pack8<T>(pv);
-            pf1 = pack8<T>(pv + 8);
-            asm volatile("s_nop 1" : "+v"(pf0), "+v"(pf1));            // (VALU-written B operands in front of MFMAs the compiler cannot see)
-            // ---- O^T += Vt P^T: pf0's product first, then pf1's, per accumulator (attn_cross_body's order); the second group's V fragments
-            //      are requested once the first group is on the matrix pipe ----
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) T::mfma32_cA(o[dt], vf0[dt], pf0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_v(vf1, 1);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) T::mfma32_cA(o[dt], vf1[dt], pf1);
         }
+        if (kb_local + 32 > p.n_keys) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb_local + krow32(r, hi) >= p.n_keys) pv[r] = 0.f;
+        }
+        if (p.mask) {
+            const unsigned char* mp = p.mask + kb_local + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned mv = *(const unsigned*)(mp + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((mv >> (8 * e)) & 0xffu) == 0) pv[4 * j + e] = 0.f;
+            }
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += pv[r];
+        l_run += psum;
+        pp0 = pack8<T>(pv);
+        pp1 = pack8<T>(pv + 8);
         s_cur = s_next;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every LDS read of this step has returned before the wave can reach the next barrier
     }
+    // PV of the last sub-tile
+    if (n_mine > 0) {
+        const char* sVp = vring + ((n_mine - 1) % VSLOTS) * VBYTES;
+        u32x4 vf[2 * DT];
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) vf[j] = v_frag(sVp, j);
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) T::mfma32_cA(o[j % DT], vf[j], j < DT ? pp0 : pp1);
+    }
+
     // ---- this wave's partial: numerator rows, (m, l) — the layout of one attn_cross_body partial ----
     if (!active) return;
     // the last PV results (8-pass MFMAs, invisible to the hazard recogniser) must have landed before anything reads them; naming the
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_cross_rows_kernel(AttnCrossParams a,
 
 int vidi_attn_cross_rows_launch(const AttnCrossParams& a, const AttnCrossParams& b, int za, int zb, int HD, int dtype, hipStream_t st) {
     const dim3 grid(a.nkv, (a.Rpad / 32 + 3) / 4, za + zb);
-    const int lds = 4 * (32 * HD * 2 + HD * 64);
+    const int lds = 3 * (32 * HD * 2) + 5 * (HD * 64);          // K ring of 3 sub-tiles, V ring of 5
 #define LAUNCH(TT, HH)                                                                        \
     do {                                                                                      \
         auto kern = attn_cross_rows_kernel<TT, HH>;                                           \

@@ -125,24 +125,26 @@ struct BF16 {
     // 32x32x16 forms with operands pinned to a register file (gfx90a+ takes A / B from either file): the B operand read straight from
     // AGPRs (no v_accvgpr_read per use of a resident fragment), the accumulator in AGPRs or VGPRs.
     // (the `_first` forms' result is early-clobber: a matrix instruction's destination must not overlap its A / B operands)
+    // Each carries `s_nop 1` in front: a VALU-written operand needs two wait states before a matrix instruction reads it, and the compiler
+    // puts plain moves right in front of these statements.
     // CAUTION — to the compiler these are opaque asm statements, not MFMAs: it inserts NONE of the wait states gfx940+ needs in software
     // around matrix instructions (XDL result -> VALU / memory reader: passes + 2..3; a register copied into the other file right in front of
     // the MFMA that reads it).  Callers keep readers of a result far behind it (or put s_nop in between) and pick the form whose operands
     // are RESIDENT in the named file — attn_cross.hip's many-row kernel documents its distances.
     static __device__ __forceinline__ void mfma32_bA(f32x16& c, const u32x4& a, const u32x4& b_agpr) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b_agpr));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b_agpr));
     }
     static __device__ __forceinline__ void mfma32_bA_first(f32x16& c, const u32x4& a, const u32x4& b_agpr) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b_agpr));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b_agpr));
     }
     static __device__ __forceinline__ void mfma32_cA(f32x16& c_agpr, const u32x4& a, const u32x4& b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c_agpr) : "v"(a), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c_agpr) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void mfma32_bV(f32x16& c, const u32x4& a, const u32x4& b) {              // everything in VGPRs
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void mfma32_bV_first(f32x16& c, const u32x4& a, const u32x4& b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
     }
 };
 struct F16 {
@@ -162,19 +164,19 @@ struct F16 {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void mfma32_bA(f32x16& c, const u32x4& a, const u32x4& b_agpr) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b_agpr));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b_agpr));
     }
     static __device__ __forceinline__ void mfma32_bA_first(f32x16& c, const u32x4& a, const u32x4& b_agpr) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b_agpr));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b_agpr));
     }
     static __device__ __forceinline__ void mfma32_cA(f32x16& c_agpr, const u32x4& a, const u32x4& b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c_agpr) : "v"(a), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c_agpr) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void mfma32_bV(f32x16& c, const u32x4& a, const u32x4& b) {              // everything in VGPRs
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void mfma32_bV_first(f32x16& c, const u32x4& a, const u32x4& b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
     }
 };
 
