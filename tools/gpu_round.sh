@@ -23,12 +23,12 @@ bench20)
   # the driver's command shape
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; echo "bench20 rc=$?"; python tools/show_bench.py $OUT/bench20.json 2>/dev/null | head -40 ;;
 prof)
-  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r4 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify > $OUT/prof_bench.json 2> $OUT/prof.err)
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r5 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify --no-other-configs > $OUT/prof_bench.json 2> $OUT/prof.err)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
 mfma)
-  CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify"
+  CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify --no-other-configs"
   (cd /tmp && timeout 1200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- $CMD > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err); echo "mfma rc=$?"
   python tools/mfma_busy_from_pmc.py "$(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1)" $OUT/mfma_busy.json
   rm -rf $OUT/pmc_mfma ;;
@@ -132,7 +132,7 @@ dist2)
 chunk)
   timeout 900 python tools/bench_vis_chunk.py 3600 > $OUT/vis_chunk.jsonl 2> $OUT/vis_chunk.err; echo "chunk rc=$?"; cat $OUT/vis_chunk.jsonl ;;
 pmc)
-  CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify"
+  CMD="python $REPO/bench.py --steps 1 --warmup 0 --decode-steps 2 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify --no-other-configs"
   # rocprofv3's counter mode sometimes segfaults within seconds of the first dispatches of this command (round 4: 5 of 7 attempts, either
   # counter, different boxes; the same passes run through when retried): a failed attempt costs ~5 s, so each pass is tried up to 5 times
   for pass in "FETCH_SIZE pmc_fetch f" "WRITE_SIZE pmc_write w"; do
