@@ -51,6 +51,19 @@ for l in open("gpurun_out/ab_w4n.jsonl"):
     print("VIDI_W4N", d["VIDI_W4N"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "frac", round(d["roofline"]["frac"], 4), "verify", d["verify"]["ok"], round(d["verify"]["embeds_frames_max_err"], 4), "first_token", d["first_token"])
 PY
   ;;
+abqkv)
+  # same-box ABAB of the prefill: SigLIP's q | k | v projection on 288 x 224 tiles (default) against the 256-wide kernel (VIDI_W4N_QKV=0), one library
+  : > $OUT/ab_qkv.jsonl
+  for r in 1 2; do for sw in 0 1; do
+    VIDI_W4N_QKV=$sw timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-preproc --no-other-configs --decode-steps 4 2> $OUT/ab_qkv.err | grep '^{' | sed "s/^{/{\"VIDI_W4N_QKV\": $sw, /" >> $OUT/ab_qkv.jsonl; echo "abqkv $sw rc=$?"
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/ab_qkv.jsonl"):
+    d = json.loads(l)
+    print("VIDI_W4N_QKV", d["VIDI_W4N_QKV"], round(d["value"]), {k: round(v) for k, v in d["stage_ms_per_step"].items()}, "gemm TFLOP/s", round(d["kernel_families"]["gemm"]["TFLOP/s"]), "frac", round(d["roofline"]["frac"], 4), "verify", d["verify"]["ok"], round(d["verify"]["embeds_frames_max_err"], 4), "first_token", d["first_token"], "probe", round(d["box_reference"]["mfma_bf16_16x16x32_TFLOP/s"]))
+PY
+  ;;
 abskinny)
   # same-box ABAB of the 5-min config (text prefill is a visible share there): the prompt's projections on vidi_gemm_skinny (default) against
   # the tile GEMM (VIDI_SKINNY_GEMM=0); `stage_ms_per_step.text_prefill` is the number to read

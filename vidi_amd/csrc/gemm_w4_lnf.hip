@@ -12,6 +12,8 @@ static int lnf(const GemmParams& p, int batch, int mode, hipStream_t st) {
     if (mode != MODE_PLAIN) return VIDI_ERR_ARG;
     if (p.hm_seq) {
         if (p.act != ACT_NONE) return VIDI_ERR_ARG;
+        const int rc = vidi_w4n_ln_heads(p, T::id, st);              // widths of the 288 x 224 tile geometry (SigLIP q | k | v: N = 3 456)
+        if (rc != VIDI_W4_UNSUPPORTED) return rc;
         return launch_w4<T, MODE_PLAIN, false, Epi<true, ACT_NONE, 0, true, false, true>>(p, batch, st);      // q/k/v projection, head-major
     }
     switch (p.act) {

@@ -26,7 +26,7 @@ struct W4NGeom {
     static constexpr int WROWS = 112;                                         // rows per wave
     static constexpr int STAGE_BYTES = (BN + BM) * ROWB, RING = 2 * STAGE_BYTES;
     static constexpr int SCR_ROW = 144 * 2 + 16, SCR_BYTES = 16 * SCR_ROW;   // per-wave epilogue scratch: 16 rows x (128 + 16 cols + pad)
-    static constexpr int CST_OFF = RING + 4 * SCR_BYTES, CST_BYTES = 4096;
+    static constexpr int CST_OFF = RING + 4 * SCR_BYTES, CST_BYTES = 6144;   // bias (576 B) | folded LayerNorm: colsum 2 KB, shift 2 KB, (mean, rstd) 2 KB
     static constexpr int LDS_BYTES = CST_OFF + 2 * CST_BYTES;
     static_assert(STAGE_BYTES == 65536 && LDS_BYTES <= 163840, "LDS plan");
 };
@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
     using G = W4NGeom;
     constexpr int BN = G::BN, BM = G::BM, BK = G::BK, NT = G::NT, TN = G::TN, TM = G::TM, ROWB = G::ROWB, STAGE_BYTES = G::STAGE_BYTES;
     constexpr int NPH = TN * TM;                           // 63 MFMAs per phase (k32 step)
-    static_assert(EPI::bias && EPI::act == ACT_NONE && EPI::res == 1 && !EPI::lnf && !EPI::heads, "bias + residual(row m) [+ statistics]");
+    // two epilogue families: bias + residual(row m) [+ statistics] (out_proj / fc2), and the folded LayerNorm with the head-major store
+    // (SigLIP's q | k | v projection: N = 3 456 = 12 x 288, i.e. 13.5 tiles of 256 wide)
+    constexpr bool LNH = EPI::lnf == 1 && EPI::heads;
+    static_assert((EPI::bias && EPI::act == ACT_NONE && EPI::res == 1 && EPI::lnf == 0 && !EPI::heads) ||
+                  (LNH && EPI::act == ACT_NONE && EPI::res == 0 && !EPI::stats), "bias + residual(row m) [+ statistics], or LN-fold + head-major");
     auto swz = [](int row) { return (row >> 1) & 7; };
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -109,13 +113,24 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
 #define VIDI_PIN __builtin_amdgcn_sched_barrier(0)
 
     // ---- epilogue constants: bias[n0 .. n0 + 287] (bf16, 576 B) -> LDS by wave 0 during the tile's first iteration ----
-    __amdgpu_buffer_rsrc_t srdC0 = rsrc_of(p.bias, (unsigned long long)p.N * 2);
+    //      folded LayerNorm: wave 0 colsum[n0 ..] (fp32: columns 0..255 to +0, 256..287 to +1024), wave 1 shift[n0 ..] the same way to +2048,
+    //      waves 2, 3 (mean, rstd) of rows m0 .. m0 + 255 to +4096 (rows and columns out of range read as zeros)
+    __amdgpu_buffer_rsrc_t srdC0;
+    if constexpr (LNH) srdC0 = rsrc_of(wave == 0 ? p.ln_s : (wave == 1 ? p.ln_c : p.ln_stats), wave < 2 ? (unsigned long long)p.N * 4 : (unsigned long long)p.M * 8);
+    else srdC0 = rsrc_of(p.bias, (unsigned long long)p.N * 2);
     int tpar = 0;
     auto issue_cst = [&]() {
         if constexpr (LAB::no_dma) return;
         char* dst = smem + G::CST_OFF + tpar * G::CST_BYTES;
-        if (wave == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)(n0 + 8 * lane) * 2u, 0, 0, 0);
+        if constexpr (LNH) {
+            const unsigned voff = wave < 2 ? (unsigned)(n0 + 4 * lane) * 4u : (unsigned)(m0 + (wave - 2) * 128 + 2 * lane) * 8u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)(dst + (wave < 2 ? wave * 2048 : 4096 + (wave - 2) * 1024)), 16, voff, 0, 0, 0);
+            if (wave < 2)                                           // the 32 tail columns (lanes 8.. read past the tile's columns: never used)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)(dst + wave * 2048 + 1024), 16, (unsigned)(n0 + 256 + 4 * lane) * 4u, 0, 0, 0);
+        } else {
+            if (wave == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC0, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)(n0 + 8 * lane) * 2u, 0, 0, 0);
+        }
     };
 
     // one K iteration: 2 x 63 MFMAs on slice kt (gemm_w4.h's schedule; pieces 0..6 = X, 7..15 = W; fragments 7 X + 9 W per k32 step)
@@ -178,7 +193,91 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
     char* scr = smem + G::RING + wave * G::SCR_BYTES;
     constexpr int SROW = G::SCR_ROW;
     constexpr bool stats_on = EPI::stats;
+    // ---- folded LayerNorm + head-major store (q | k | v): y = rstd_m * (acc - mean_m * s_n) + c_n, rounded once, stored to
+    //      Y[which][frame][head][token][d] (gemm_w4.h's arithmetic and address map; a 288-column tile is four whole heads of d = 72) ----
+    auto epilogue_lnh = [&](int em0, int en0) {
+        const char* cst = smem + G::CST_OFF + tpar * G::CST_BYTES;
+        f32x4 lnS[TN], lnC[TN];
+        float lnMu[TM], lnRs[TM];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int col = (a < 8 ? wn * 128 + a * 16 : 256 + wn * 16) + 4 * hi;          // (columns 0..255 at +0, 256..287 at +1024: contiguous)
+            lnS[a] = *(const f32x4*)(cst + col * 4);
+            lnC[a] = *(const f32x4*)(cst + 2048 + col * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const f32x2_t ms = *(const f32x2_t*)(cst + 4096 + (wm * G::WROWS + b * 16 + l15) * 8);
+            lnMu[b] = ms[0];
+            lnRs[b] = ms[1];
+        }
+        const int rr = lane >> 4, cc = lane & 15;                    // main read-back: 4 rows x 16 chunks of 8 columns per instruction
+        const int tr = (lane >> 1) & 15, tc = lane & 1;              // tail read-back: 16 rows x 2 chunks on lanes 0..31
+        const int nmain = en0 + wn * 128 + cc * 8, ntail = en0 + 256 + wn * 16 + tc * 8;
+        const bool tl = lane < 32;
+        auto head_col = [&](int n) {                                 // (which, head, d) of a column: fixed for the tile
+            const int nc = min(n, p.N - 8), hdim = p.hm_heads * p.hm_hd;
+            const int which = nc / hdim, nh = nc - which * hdim, hh = nh / p.hm_hd;
+            return ((size_t)which * (p.M / p.hm_seq) * p.hm_heads + hh) * p.hm_seq * p.hm_hd + (nh - hh * p.hm_hd);
+        };
+        const size_t hm_main = head_col(nmain), hm_tail = head_col(ntail);
+        const bool ok_main = nmain < p.N && !LAB::no_store, ok_tail = tl && ntail < p.N && !LAB::no_store;
+        auto stage = [&](auto bt) {
+            constexpr int b = decltype(bt)::value;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const float t = -lnRs[b] * lnMu[b];
+            const f32x2 tt = {t, t}, rr2 = {lnRs[b], lnRs[b]};
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = aread(acc[a][b][e]);
+                const f32x2 u0 = __builtin_elementwise_fma(tt, f32x2{lnS[a][0], lnS[a][1]}, f32x2{lnC[a][0], lnC[a][1]});
+                const f32x2 u1 = __builtin_elementwise_fma(tt, f32x2{lnS[a][2], lnS[a][3]}, f32x2{lnC[a][2], lnC[a][3]});
+                const f32x2 y0 = __builtin_elementwise_fma(rr2, f32x2{v[0], v[1]}, u0);
+                const f32x2 y1 = __builtin_elementwise_fma(rr2, f32x2{v[2], v[3]}, u1);
+                const u32x2 o = {pack2<T>(y0[0], y0[1]), pack2<T>(y1[0], y1[1])};
+                *(u32x2*)(scr + l15 * SROW + (a < 8 ? a * 32 : 256) + 4 * hi * 2) = o;
+            }
+        };
+        u32x4 val[4], valt;
+        auto fetch = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[j] = *(const u32x4*)(scr + (j * 4 + rr) * SROW + cc * 16);
+            valt = *(const u32x4*)(scr + tr * SROW + 256 + tc * 16);
+        };
+        auto store = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = em0 + wm * G::WROWS + b * 16 + j * 4 + rr;
+                if (ok_main && m < p.M) {
+                    const int fr = (int)__umulhi((unsigned)m, p.hm_magic), tok = m - fr * p.hm_seq;      // m / seq, m % seq
+                    *(u32x4*)(p.Y + hm_main + ((size_t)fr * p.hm_heads * p.hm_seq + tok) * p.hm_hd) = val[j];
+                }
+            }
+            const int mt = em0 + wm * G::WROWS + b * 16 + tr;
+            if (ok_tail && mt < p.M) {
+                const int fr = (int)__umulhi((unsigned)mt, p.hm_magic), tok = mt - fr * p.hm_seq;
+                *(u32x4*)(p.Y + hm_tail + ((size_t)fr * p.hm_heads * p.hm_seq + tok) * p.hm_hd) = valt;
+            }
+        };
+        auto step = [&](auto bt) {
+            constexpr int b = decltype(bt)::value;
+            VIDI_PIN;
+            fetch();
+            VIDI_PIN;
+            if constexpr (b + 1 < TM) stage(std::integral_constant<int, b + 1>{});
+            VIDI_PIN;
+            store(b);
+            VIDI_PIN;
+        };
+        stage(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+    };
     auto epilogue = [&](int em0, int en0) {
+        if constexpr (LNH) { epilogue_lnh(em0, en0); return; } else {
         const char* cst = smem + G::CST_OFF + tpar * G::CST_BYTES;
         u32x2 bq[TN];
 #pragma unroll
@@ -302,6 +401,7 @@ __global__ __launch_bounds__(256) void gemm_w4n_kernel(GemmParams p) {
         step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
         step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
         step(std::integral_constant<int, 6>{});
+        }
     };
 
     // =========================================== tile loop ===========================================

@@ -147,6 +147,7 @@ int vidi_norm_dispatch(const NormParams& p, int mode, int dtype, hipStream_t st)
 int vidi_ln_finalize_dispatch(const float* part, float* stats, long long rows, int nstr, int H, float eps, hipStream_t st);
 int vidi_row_partials_dispatch(const void* Y, float* part, long long rows, int N, long long ldy, int nstr, int dtype, hipStream_t st);
 int vidi_w4n_stat_strips(int N);                                              // (sum, sum^2) entries per row of GemmParams::stat_part for an output width N
+int vidi_w4n_ln_heads(const GemmParams& p, int dtype, hipStream_t st);       // ... its LN-fold + head-major epilogue (q | k | v at N = 12 x 288)
 int vidi_w4n_bias_res(const GemmParams& p, int dtype, hipStream_t st);       // 288 x 224 tile geometry (gemm_w4n.h); VIDI_W4_UNSUPPORTED (-100) when it does not apply
 int vidi_row_stats_dispatch(const void* X, float* stats, long long rows, int H, long long ldx, float eps, int dtype, hipStream_t st);
 int vidi_ew_dispatch(int op, void** a, const long long* i, const float* f, int dtype, hipStream_t st);
