@@ -330,7 +330,7 @@ class VidiEngine:
             return hip.gemv_mfma(x, w, out)
         if M <= 8:
             return hip.gemv(x, w, out)
-        if M <= 128 and self.skinny_gemm:
+        if M <= 128 and self.skinny_gemm and w.shape[0] <= 65536:         # (lm_head's 256 000 rows run unsplit: an fp32 round trip of M x N for nothing)
             need = hip.gemm_skinny_workspace_bytes(M, w.shape[0], x.shape[1])
             have = self._ws.get("skinny_ws")
             # (a workspace that would have to be allocated in the middle of a graph capture — a decode step of 9+ rows whose prefill ran on

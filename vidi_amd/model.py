@@ -542,6 +542,10 @@ class VidiForCausalLM:
         kw_procs, kw_crits = generation_kwargs_processors(kwargs, eos_list, eng.dev)
         processors = kw_procs + list(kwargs.get("logits_processor") or [])
         criteria = kw_crits + list(kwargs.get("stopping_criteria") or [])
+        if eng.world > 1 and criteria:
+            # the greedy loop broadcasts rank 0's stop decisions; beam search evaluates its criteria inside vidi_amd/beam.py on every rank, and a
+            # wall-clock (`max_time`) or caller-supplied criterion may differ between ranks: one rank would leave the per-layer all-gathers early
+            raise NotImplementedError("beam search over a sharded video takes no `max_time` / `stopping_criteria` (the ranks could stop at different steps)")
         do_sample = bool(kwargs.get("do_sample", False))
         if do_sample:
             # beam-search multinomial sampling: HF appends the warpers to the processors (they see the log-probabilities)
