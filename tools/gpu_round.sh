@@ -137,7 +137,7 @@ dist2)
   # two ranks sharing the one GPU of the box (gloo transport; RCCL refuses two ranks on one device): the torchrun / sharded code path
   # of bench.py end to end, on a 10-minute video so both ranks fit
   # (bench.py launches its own ranks: no torchrun on the command line)
-  VIDI_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --frames 600 --steps 1 --warmup 1 --no-preproc > $OUT/bench_dist2.json 2> $OUT/bench_dist2.err; echo "dist2 rc=$?"
+  VIDI_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --frames 600 --steps 1 --warmup 1 --no-preproc --no-other-configs > $OUT/bench_dist2.json 2> $OUT/bench_dist2.err; echo "dist2 rc=$?"
   VIDI_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --frames 600 --fps 2 --queries 8 --ragged-prompts 24 52 --decode-steps 64 --steps 1 --warmup 1 --no-preproc \
       > $OUT/bench_dist2_q8.json 2> $OUT/bench_dist2_q8.err; echo "dist2 q8 rc=$?"
   timeout 600 python bench.py --frames 600 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
