@@ -415,7 +415,8 @@ def test_gemv(hip, dt, M):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(8, 8192, 3584), (24, 3584, 4096), (8, 3584, 14336), (1, 16, 64), (2, 48, 128), (5, 1008, 3584), (16, 256, 512),
-                                   (17, 64, 192), (32, 3584, 4096), (8, 4000, 3584), (3, 32, 320), (8, 6144, 4096)])
+                                   (17, 64, 192), (32, 3584, 4096), (8, 4000, 3584), (3, 32, 320), (8, 6144, 4096),
+                                   (8, 67200, 256), (3, 40016, 128), (20, 36000, 192)])      # more feature groups than resident blocks: blocks walk groups
 def test_gemv_mfma(hip, dt, M, N, K):
     """vidi_gemv_mfma (a batch of decode rows on the matrix pipe; every K split 1 / 2 / 4 / 8, one and two 16-row groups, blocks that walk
     several feature groups): against the fp32 product of the same operands to the output rounding, and against vidi_gemv (M <= 8: both
@@ -437,7 +438,7 @@ def test_gemv_mfma(hip, dt, M, N, K):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,I,K,act", [(8, 14336, 3584, "gelu"), (5, 512, 256, "gelu"), (1, 96, 64, "silu"), (8, 64, 128, "silu"), (16, 1024, 4096, "silu"),
-                                       (2, 14336, 4096, "silu")])
+                                       (2, 14336, 4096, "silu"), (8, 40000, 128, "gelu")])
 def test_gemv_mfma_glu(hip, dt, M, I, K, act):
     """the gated pair on the interleaved gate/up weight: against the oracle's rounding points (T(act(T(g))) * T(u), gemma.py:116-123 via HF
     Gemma2MLP / mistral.py:131-137) from fp32 dot products, and against vidi_gemv_glu for M <= 8 (same rounding points, other summation
