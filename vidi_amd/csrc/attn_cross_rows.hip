@@ -8,6 +8,10 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+#ifndef VIDI_XROWS_AHEAD
+#define VIDI_XROWS_AHEAD 3            // sub-tiles in flight ahead of the scores being formed (3: 128 KB of LDS at HD = 256; 4: 160 KB, all of it)
+#endif
+
 // ---- many query rows (a prompt: 2 x Lq rows per kv head; a batch of prompts: hundreds) ------------------------------------------------
 // attn_cross_body gives every 32-row tile its own blocks, each of which streams its key slice through private per-wave rings: R / 32 row
 // tiles read the whole K / V R / 32 times.  At the 8-prompt prefill of BASELINE configs[4] (608 rows = 19 row tiles) that is 14 GB of
@@ -30,7 +34,8 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     constexpr int VBYTES = HD * 64;
     constexpr int KLD = KBYTES / 1024, VLD = VBYTES / 1024;      // 1 KB DMA pieces per sub-tile
     constexpr int KPW = KLD / 4, VPW = VLD / 4;                  // ... per wave
-    constexpr int KSLOTS = 3, VSLOTS = 5;                        // rings: see the pipeline below
+    constexpr int AHEAD = VIDI_XROWS_AHEAD;                      // sub-tiles requested ahead of the one whose scores are being formed
+    constexpr int KSLOTS = AHEAD, VSLOTS = AHEAD + 2;            // rings: see the pipeline below
     static_assert(KLD % 4 == 0 && VLD % 4 == 0 && (KPW + VPW == 8 || KPW + VPW == 4), "HD must be 128 or 256");      // (wait_vmcnt<> knows 0, 4, 8, 16)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][K sub-tile] [5][Vt sub-tile]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -136,10 +141,13 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     if (n_mine > 0) issue(0);
     if (n_mine > 1) issue(1);
     if (n_mine > 2) issue(2);
+    if constexpr (AHEAD > 3) { if (n_mine > 3) issue(3); }
     f32x16 s_cur = zero16;
     u32x4 pp0 = {0, 0, 0, 0}, pp1 = {0, 0, 0, 0};                  // P fragments of the previous sub-tile (none yet: the first PV adds 0 x V(0))
     if (n_mine > 0) {
-        if (n_mine > 2) wait_vmcnt<2 * (KPW + VPW)>(); else if (n_mine > 1) wait_vmcnt<KPW + VPW>(); else wait_vmcnt<0>();
+        // (sub-tile 0 has landed; up to AHEAD - 1 younger ones may be in flight)
+        if (AHEAD > 3 && n_mine > 3) wait_vmcnt<(AHEAD > 3 ? 3 : 2) * (KPW + VPW)>();
+        else if (n_mine > 2) wait_vmcnt<2 * (KPW + VPW)>(); else if (n_mine > 1) wait_vmcnt<KPW + VPW>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         u32x4 kf[KST];
@@ -151,10 +159,12 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     for (int i = 0; i < n_mine; ++i) {
         const bool more = i + 1 < n_mine;
         if (more) {
-            if (i + 2 < n_mine) wait_vmcnt<KPW + VPW>(); else wait_vmcnt<0>();
+            // sub-tile i + 1 has landed; i + 2 (.. i + AHEAD - 1) may be in flight
+            if (AHEAD > 3 && i + 3 < n_mine) wait_vmcnt<(AHEAD > 3 ? 2 : 1) * (KPW + VPW)>();
+            else if (i + 2 < n_mine) wait_vmcnt<KPW + VPW>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (i + 3 < n_mine) issue(i + 3);
+            if (i + AHEAD < n_mine) issue(i + AHEAD);
         }
         // (a block's waves without rows run the same instructions on zero Q fragments, and the last step multiplies whatever the next K slot
         // holds — its scores are never used — so that every path through the loop issues the same matrix instructions)
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_cross_rows_kernel(AttnCrossParams a,
 
 int vidi_attn_cross_rows_launch(const AttnCrossParams& a, const AttnCrossParams& b, int za, int zb, int HD, int dtype, hipStream_t st) {
     const dim3 grid(a.nkv, (a.Rpad / 32 + 3) / 4, za + zb);
-    const int lds = 3 * (32 * HD * 2) + 5 * (HD * 64);          // K ring of 3 sub-tiles, V ring of 5
+    const int lds = VIDI_XROWS_AHEAD * (32 * HD * 2) + (VIDI_XROWS_AHEAD + 2) * (HD * 64);          // K ring of AHEAD sub-tiles, V ring of AHEAD + 2
 #define LAUNCH(TT, HH)                                                                        \
     do {                                                                                      \
         auto kern = attn_cross_rows_kernel<TT, HH>;                                           \
