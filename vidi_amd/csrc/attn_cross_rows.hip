@@ -1,10 +1,9 @@
 // Text -> multimodal cross-attention for MANY query rows (a prompt, a batch of prompts): see attn_cross.hip for the path, the cache layout
 // and the one-row-tile kernel (decode).  Replaces the same call sites (flash_attn_func / flash_attn_varlen_func, lmm/dattn/xattn.py:123,253
-// via gemma.py:81-91) when a launch has two row tiles and more, a logit softcap and bf16 operands.
-// Compiled WITHOUT -amdgpu-mfma-vgpr-form (attn_cross.hip has it): here the output accumulators are never touched by the VALU inside the
-// loop, so the compiler's default — MFMA results in AGPRs — is exactly right for them (128 registers at HD = 256 that do not compete with
-// the fragments), and the 16 score registers cost one v_accvgpr_read each per sub-tile.  (An asm-MFMA form with hand-pinned files was
-// built first: it needs every hazard distance kept by hand and the allocator still shuffled accumulators through VGPRs; round-5 notes.)
+// via gemma.py:81-91) when a launch has two row tiles and more, a logit softcap and bf16 operands (vidi_attn_cross_row_tiles_per_block).
+// A translation unit of its own, compiled WITHOUT -amdgpu-mfma-vgpr-form (attn_cross.hip has it): the matrix instructions here are asm
+// statements with pinned register files (accumulators in AGPRs, everything else in VGPRs) — see the comment at qk_mfma below for why and
+// for the wait states that are kept by hand; tools/isa_mfma_hazards.py and tests/test_build_resources.py read them back from the ISA.
 #include "kernels.h"
 #include <stdlib.h>
 
@@ -16,14 +15,18 @@
 // attn_cross_body gives every 32-row tile its own blocks, each of which streams its key slice through private per-wave rings: R / 32 row
 // tiles read the whole K / V R / 32 times.  At the 8-prompt prefill of BASELINE configs[4] (608 rows = 19 row tiles) that is 14 GB of
 // L2 -> LDS traffic per layer and modality for 0.74 GB of keys — the launch ran at 0.3 PFLOP/s and 0.5 TB/s of unique bytes, bound by the
-// L2's bandwidth (round-4 verdict item 4; profiles/r5_notes.md).  Here the four waves of a block own FOUR DIFFERENT row tiles and share
-// ONE K / V stream: a 32-key sub-tile (K 32 x HD, Vt HD x 32: 32 KB at HD = 256) is DMA'd into a block-wide ring of three slots once —
-// every wave issues a quarter of its 1 KB pieces — and consumed by all four waves, each with its own register-resident Q fragments,
-// online softmax state and accumulators.  One barrier per sub-tile: at the top of step i every wave has waited for its own pieces of
-// sub-tile i (the barrier makes that "all pieces") and has finished reading sub-tile i - 1, whose slot the DMA of sub-tile i + 2 then
-// overwrites.  A wave writes the partial (O, m, l) of its row tile itself — same partial layout, same merge kernels.  Per sub-tile the
-// arithmetic is attn_cross_body's, instruction for instruction; a (row tile, key slice) partial differs from it only in which keys the
-// slice holds.  K / V traffic per launch drops 4x (and the row blocks of one kv head run on one XCD and share its L2).
+// L2's bandwidth (round-4 verdict item 4; profiles/r5_notes.md section 3 has every step with its measurement).  Here:
+//   * the four waves of a block own FOUR DIFFERENT row tiles and share ONE K / V stream: a 32-key sub-tile (K 32 x HD, Vt HD x 32: 32 KB at
+//     HD = 256) is DMA'd into block-wide rings once — every wave issues a quarter of its 1 KB pieces — and consumed by all four waves, each
+//     with its own register-resident Q fragments, row sums and accumulators; one barrier per sub-tile; K / V traffic per launch drops 4x
+//     (and the row blocks of one kv head run on one XCD and share its L2);
+//   * the softmax has NO running maximum: the tanh softcap bounds every logit, so one fixed reference serves all rows (see XSHIFT below) — no
+//     cross-lane maximum, no rescale of the accumulators, and the accumulators are never touched by the VALU inside the loop;
+//   * a three-stage software pipeline inside the wave: QK^T of sub-tile i + 1 and PV of sub-tile i - 1 are on the matrix pipe while the VALU
+//     turns the scores of sub-tile i into probabilities, one matrix instruction per ~32 cycles of lock-stepped VALU work.
+// A wave writes the partial (numerator, reference, sum) of its row tile itself — the partial layout and the merge kernels of attn_cross.hip.
+// Values: the one-row-tile kernel's up to the softmax's reference (a power-of-two-free shift of the exponent: the probabilities differ in
+// their last bits) and the tanh's division (v_rcp here, IEEE there).
 template <typename T, int HD>
 __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, const int z, const int zsplit) {
     constexpr int QROW = HD * 2;
@@ -37,13 +40,13 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     constexpr int AHEAD = VIDI_XROWS_AHEAD;                      // sub-tiles requested ahead of the one whose scores are being formed
     constexpr int KSLOTS = AHEAD, VSLOTS = AHEAD + 2;            // rings: see the pipeline below
     static_assert(KLD % 4 == 0 && VLD % 4 == 0 && (KPW + VPW == 8 || KPW + VPW == 4), "HD must be 128 or 256");      // (wait_vmcnt<> knows 0, 4, 8, 16)
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][K sub-tile] [5][Vt sub-tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [KSLOTS][K sub-tile] [VSLOTS][Vt sub-tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int kvh = blockIdx.x;
     const int r0 = (blockIdx.y * 4 + wave) * 32;                 // this wave's row tile
-    const bool active = r0 < p.R;                                // (a block's last waves may have no rows: they only move data)
+    const bool active = r0 < p.R;                                // (a block's last waves may have no rows: they run on zero Q fragments and store nothing)
 
     // Q fragments straight from global memory (B operand: column = row l31, contraction chunk 2 ks + hi); rows beyond R are zero
     u32x4 qf[KST];
