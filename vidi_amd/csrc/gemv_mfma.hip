@@ -5,12 +5,13 @@
 // ~100 VALU operations per 16 B, i.e. the whole VALU rate of the chip at 6 TB/s: the 8-row step ran at 16.0 ms against an 8.9 ms floor
 // (round-4 verdict, item 5).  Why not gemm_skinny.h: split-K through an fp32 workspace + a reduce launch, sized for 39..128 rows.
 // Here (HBM-bound, algorithmic bytes = N K 2, one pass over W, no workspace):
-//   * a block owns 16 output features (GLU: 16 gate rows + their 16 up rows) and ALL of K; its KS waves take the 64-wide k steps
-//     round-robin (wave w: steps w, w + KS, ... — at any moment the block reads KS adjacent 128-byte lines of each of its rows) and
+//   * a block owns 16 output features (GLU: 16 gate rows + their 16 up rows; wide outputs: 32 features = two 16-row groups against one X
+//     fragment) and ALL of K; its KS waves (1 for most shapes: see the launch-shape comment below) take the 64-wide k steps round-robin and
 //     their partial accumulators are added in LDS once per feature group;
-//   * W goes HBM -> registers, 32 contiguous bytes per lane (lane (row l15, hi): k = 64 s + 16 hi .. + 15), non-temporal, D - 1 steps
-//     ahead in a register ring; the X rows (<= 32, L2-resident) are loaded the same way — lane (m = l15, hi) takes the same k bytes of its
-//     row, which IS the B fragment of MFMA 16x16x32 under the k permutation the W fragment uses ({16 hi + 0..7} then {16 hi + 8..15});
+//   * W goes HBM -> registers, 32 contiguous bytes per lane (lane (row l15, hi): k = 64 s + 16 hi .. + 15), D - 1 steps ahead in a
+//     register ring (default cache policy: the non-temporal hint measured 9-19 % slower here); the X rows (<= 32, L2-resident) are loaded
+//     the same way by the lanes of real rows — lane (m = l15, hi) takes the same k bytes of its row, which IS the B fragment of MFMA
+//     16x16x32 under the k permutation the W fragment uses ({16 hi + 0..7} then {16 hi + 8..15});
 //   * the ring runs over the flattened (feature group, step) sequence of a block (grid-stride over the groups), so the pipe never
 //     drains between groups; loads are asm with counted vmcnt waits (ordinary loads get a vmcnt(0) at the loop header: gemm_skinny.h).
 //   * C[i = 4 hi + r][j = l15] = feature n0 + 4 hi + r, X row 16 g + l15.  Output rounding: T(sum); GLU: T( T(act(T(g))) * T(u) ) —
