@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--queries", type=int, default=1, help="prompts batched against the one encoded video (BASELINE config 5: 8)")
     ap.add_argument("--decode-graph", action="store_true", help="replay decode steps from a hipGraph (opt-in: capture costs ~126 ms)")
     ap.add_argument("--preset", default="vidi15_9b")
+    ap.add_argument("--dist-mode", default=os.environ.get("VIDI_DIST_MODE", "sharded_stream"), choices=["sharded_stream", "gather_tokens"],
+                    help="N > 1: 'sharded_stream' keeps every rank's tokens local through the decoder (K/V shards + per-layer LSE-merged cross-attention, "
+                         "scales the whole prefill); 'gather_tokens' is BASELINE configs[3] as worded: frame-sharded towers + RCCL all-gather of the "
+                         "visual / audio tokens, decoder replicated (scales the towers only)")
     ap.add_argument("--vis-chunk", type=int, default=0, help="override cfg.vis_frames_per_chunk (activation chunking only)")
     ap.add_argument("--aud-chunk", type=int, default=0, help="override cfg.aud_chunks_per_batch")
     ap.add_argument("--no-preproc", action="store_true", help="skip the extra (untimed-in-`value`) GPU preprocessing leg")
@@ -322,7 +326,7 @@ def _cache_rows(mm, li, rows, nkv, hd):
 
 
 def verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, rank, pixel, mel, f0, f1, T, c0, c1, audio_size, Nv, Na,
-                          fi, fa, mi_mask, ma_mask, mm, idt, mask, pos, lg0):
+                          fi, fa, mi_mask, ma_mask, mm, idt, mask, pos, lg0, ff0=None, fc0=None):
     """Untimed check of what the timed kernels produced, against the CPU oracle (oracle/vidi_oracle.py — the checker, never the thing
     measured) evaluated in the model dtype with the reference's eager rounding points:
       * FREE-RUNNING: the token embeddings of three frames (first / middle / last: SigLIP x26 -> pool -> projector -> norms -> positions)
@@ -332,7 +336,11 @@ def verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, r
         row-wise, so the oracle evaluates each layer on exactly those rows and must reproduce that layer's K / V cache rows and the
         next layer's input within one layer's bf16 roundings — and the probed pass must equal the timed pass's caches bit for bit;
       * how much the first-token logits move when every video key is masked (the multimodal path must matter to the answer).
-    Every rank checks the sampled rows / frames it owns (global indices, so the sample is the same for every N); results are MAX-reduced."""
+    Every rank checks the sampled rows / frames it owns (global indices, so the sample is the same for every N); results are MAX-reduced.
+    `ff0` / `fc0`: the frame / window that row 0 of `fi` / `fa` belongs to — this rank's first (sharded stream: its own tokens) or 0 (dist
+    mode gather_tokens: after the all-gather every rank holds all tokens; the frames it can re-encode are still its own)."""
+    ff0 = f0 if ff0 is None else ff0
+    fc0 = c0 if fc0 is None else fc0
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dataclasses
     import numpy as np
@@ -356,7 +364,7 @@ def verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, r
     rs = np.random.RandomState(7)
     g_img = sorted(set([0, 1, tpf - 1, tpf, Nv // 2, Nv - 1] + rs.randint(0, Nv, 42).tolist()))
     g_aud = sorted(set([0, Na // 2, Na - 1] + rs.randint(0, Na, 13).tolist())) if Na > 0 else []
-    img0, aud0 = f0 * tpf, c0 * per
+    img0, aud0 = ff0 * tpf, fc0 * per
     n_il, n_al = (0 if fi is None else fi.shape[0]), (0 if fa is None else fa.shape[0])
     li_rows = [r - img0 for r in g_img if img0 <= r < img0 + n_il]
     la_rows = [r - aud0 for r in g_aud if aud0 <= r < aud0 + n_al]
@@ -383,7 +391,7 @@ def verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, r
         mine = [t for t in sorted({0, T // 2, T - 1}) if f0 <= t < f1]
         if mine and fi is not None and fi.shape[0]:
             ref = _oracle_frame_embeds(O, pixel[[t - f0 for t in mine]].cpu(), mine, T, w, ocfg, dtype)
-            got = torch.stack([fi[(t - f0) * tpf: (t - f0 + 1) * tpf] for t in mine]).cpu()
+            got = torch.stack([fi[(t - ff0) * tpf: (t - ff0 + 1) * tpf] for t in mine]).cpu()
             errs["embeds_frames"] = spread(got, ref)
             counts["frames"] = len(mine)
         if c0 == 0 and c1 > 0 and fa is not None and fa.shape[0] >= per and Na >= per:
@@ -495,7 +503,8 @@ def main():
     del weights
     eng = model.engine
     if world > 1:
-        eng.set_dist(None)
+        eng.set_dist(None, mode=a.dist_mode)
+    gather_mode = world > 1 and a.dist_mode == "gather_tokens"
 
     # ---- synthetic workload: resident in HBM before the timed region ----
     T = a.frames
@@ -504,6 +513,9 @@ def main():
     audio_size = int(round(secs * 100))                       # mel frames (100 per second)
     f0, f1 = shard(T, world, rank)
     c0, c1 = shard(Cw, world, rank)
+    from vidi_amd.shard import video_shard
+    vshard = video_shard(T, Cw, world, rank)
+    assert (vshard.f0, vshard.f1, vshard.c0, vshard.c1) == (f0, f1, c0, c1)
     # the synthetic video is a function of the GLOBAL element index (a counter-based generator: splitmix64 of the index -> two uniforms ->
     # Box-Muller), so an N-rank run encodes exactly the video the 1-rank run does and `first_token` / `verify` are comparable across N;
     # generated in chunks of 64 frames by a few large elementwise launches (one generator call per frame was 14 400 tiny launches, which
@@ -564,6 +576,9 @@ def main():
         e1 = ev()
         fa, ma = eng.encode_video_audios(mel, audio_size, normalizer=eng.normalizer, chunk_offset=c0, sample_flag=whole_sample_flag(mel))
         e2 = ev()
+        if gather_mode:      # the all-gather of visual / audio tokens (the product's own helper: model.encode_mm_state calls the same)
+            fi, mi, fa, ma = model._gather_tokens(fi, mi, fa, ma, vshard, audio_size)
+        e2b = ev()
         mm = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
         e3 = ev()
         ts, last = model._prefill(idt, mask, pos, mm, a.decode_steps + 1)
@@ -573,7 +588,7 @@ def main():
         last_feats[:] = [fi, fa, mi, ma]
         if record:
             torch.cuda.synchronize()
-            for k, (x, y) in {"vision_encode": (e0, e1), "audio_encode": (e1, e2), "mm_stream": (e2, e3), "text_prefill": (e3, e4)}.items():
+            for k, (x, y) in {"vision_encode": (e0, e1), "audio_encode": (e1, e2), "token_all_gather": (e2, e2b), "mm_stream": (e2b, e3), "text_prefill": (e3, e4)}.items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + x.elapsed_time(y)
         return mm, ts, nxt
 
@@ -662,7 +677,8 @@ def main():
     verify = None
     if not a.no_verify:
         verify = verify_against_oracle(a, cfg, eng, model, make_weights, dtype, dev, world, rank, pixel, mel, f0, f1, T, c0, c1, audio_size, Nv, Na,
-                                       last_feats[0], last_feats[1], last_feats[2], last_feats[3], mm, idt, mask, pos, lg0)
+                                       last_feats[0], last_feats[1], last_feats[2], last_feats[3], mm, idt, mask, pos, lg0,
+                                       ff0=0 if gather_mode else None, fc0=0 if gather_mode else None)
         if not verify["ok"]:
             if rank == 0:
                 print(json.dumps({"verify": verify}), file=sys.stderr)
@@ -777,7 +793,9 @@ def main():
         "config": {"workload": f"{'Vidi-7B' if cfg.arch == 'mistral' else 'Vidi1.5-9B'} prefill, {T} frames@{a.fps:g}fps 384px (+{Cw} audio windows, "
                                + (f"{a.prompt_len}-token prompt)" if len(set(plens)) == 1 and a.queries == 1 else f"{a.queries} prompts of {min(plens)}..{max(plens)} tokens sharing the video)"),
                    "frames": T, "fps": a.fps, "video_tokens": Nv, "audio_tokens": Na, "prompt_tokens": plens[0] if len(set(plens)) == 1 else plens,
-                   "parallelism": f"frame-shard x{world} (K/V shards resident, LSE-merged cross-attention)" if world > 1 else "single GPU"},
+                   "parallelism": ("single GPU" if world == 1 else f"frame-shard x{world} (towers sharded, RCCL all-gather of visual / audio tokens, decoder replicated)"
+                                   if gather_mode else f"frame-shard x{world} (K/V shards resident, LSE-merged cross-attention)")},
+        "dist_mode": a.dist_mode if world > 1 else None,
         # one video, `queries` prompts answered together: the encode + stream prefill is shared
         "sec_per_query": (ms_per_step / 1e3 + a.decode_steps * t_decode) / a.queries, "decode_ms_per_token": t_decode * 1e3,
         "sec_per_query_cached": (stage_ms.get("text_prefill", 0.0) / a.steps / 1e3 + a.decode_steps * t_decode) / a.queries,

@@ -36,6 +36,10 @@ def main(out_path):
     ids = torch.tensor([[2, 21, 22, -200, 23, 24, 25]], dtype=torch.int64)
     # the PRODUCT entry point shards the video (every rank is handed all of it, vidi_amd/model.py:encode_mm_state)
     mm = model.encode_mm_state([px], [mel], [audio_size])
+    # the inner seam (multimodal.py:254-265): under set_dist (either mode) the ranks' shards are all-gathered into the reference-order tensors
+    g0 = getattr(eng, "n_token_gathers", 0)
+    enc = [None if t is None else t.cpu() for t in model.encode_videos([px], [mel], [audio_size])]
+    token_gathers = getattr(eng, "n_token_gathers", 0) - g0
     idt, mask, pos = strip_image_token(ids)
     ts = eng.new_text_state(1, 16)
     n0 = eng.n_collectives
@@ -81,7 +85,7 @@ def main(out_path):
         toks_graph = model.generate(ids, mm_state=mm, max_new_tokens=6, do_sample=False).cpu()
         os.environ["VIDI_DECODE_GRAPH"] = "0"
     if rank == 0:
-        torch.save({"xattn_layer0": xo.float().cpu(), "tokens8": toks8.cpu(), "collectives8": coll8, "tokens_graph": toks_graph, "sharded": bool(eng.sharded),
+        torch.save({"enc": enc, "token_gathers": token_gathers, "dist_mode": getattr(eng, "dist_mode", None), "xattn_layer0": xo.float().cpu(), "tokens8": toks8.cpu(), "collectives8": coll8, "tokens_graph": toks_graph, "sharded": bool(eng.sharded),
                     "prefill": hn.float().cpu(), "decode": hn2.float().cpu(), "g_img": int(mm.g_img), "g_aud": int(mm.g_aud),
                     "n_img_local": int(mm.n_img), "n_aud_local": int(mm.n_aud), "tokens": toks.cpu(), "tokens_cached": toks_cached.cpu(),
                     "collectives_per_forward": per_forward, "layers": cfg.num_hidden_layers}, out_path)

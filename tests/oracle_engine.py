@@ -32,13 +32,21 @@ class OracleEngine:
         self.mistral = cfg.arch == "mistral"
         self.normalizer = 1.0
         self.world, self.rank, self.pg = 1, 0, None
+        self.dist_mode, self.shard_encode = "sharded_stream", False
+        # per_unit: frames / audio windows are encoded ONE AT A TIME (every matmul sees the same operand shapes whatever the shard cut), so
+        # that "the all-gathered shards equal the single-rank encode" can be asserted BIT FOR BIT on the CPU as well (a batched fp32 GEMM
+        # may round a row differently when the row count changes: a property of the BLAS blocking, not of the path under test)
+        self.per_unit = False
 
     # ---- multi-rank test mode (tests/test_shard.py): the product class (vidi_amd/model.py) shards the video; this engine checks
     #      that the shards tile it with the right global offsets, reassembles them over the process group (the north-star's literal
     #      "all-gather of visual tokens") and runs the oracle on the whole — so every rank must reproduce the single-rank answer ----
-    def set_dist(self, group=None):
+    def set_dist(self, group=None, mode=None):
+        import os
         import torch.distributed as dist
         self.pg, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        self.dist_mode = mode or os.environ.get("VIDI_DIST_MODE", "sharded_stream")
+        self.shard_encode = self.world > 1
 
     def sample_flag(self, x):
         return torch.tensor([int(bool((x != 0).any()))], dtype=torch.int32)
@@ -50,7 +58,71 @@ class OracleEngine:
         return allr
 
     # ---- multimodal encode ----
+    def _local(self):
+        return self.per_unit or (self.world > 1 and self.dist_mode == "gather_tokens")
+
+    def _images_local(self, pixel, frame_offset, total_frames, flag, budget_frames):
+        """the rows of frames [frame_offset, frame_offset + T) of a `total_frames`-frame video, frame by frame, with the GLOBAL
+        positions / budget (multimodal.py:156-208 restated through the oracle's pieces for ONE frame at a time)"""
+        w, cfg, m = self.w, self.ocfg, "model."
+        T = int(pixel.shape[0])
+        Ttot = T if total_frames is None else int(total_frames)
+        d, side, pool = cfg.hidden_size, cfg.vis_side, cfg.mm_image_pool_size
+        hw = None if cfg.arch == "mistral" else O.token_budget_hw(Ttot if budget_frames is None else int(budget_frames), side, pool, cfg.mm_max_tokens_base)
+        pt_all = O.mm_rms_norm(O.learnable_pos_embd(Ttot, cfg.mm_time_interval, d, w, m + "mm_rand_pos_t.", torch.float32))
+        rows = []
+        for t in range(T):
+            f = O.siglip_forward(pixel[t: t + 1].float(), w, cfg)
+            f = f.reshape(1, side, side, -1).permute(0, 3, 1, 2)
+            f = O.learned_conv2d_pool(f, w[m + "mm_rand_img_pool.conv.weight"], pool) if cfg.arch == "mistral" else O.conv2d_pool(f, hw, pool)
+            f = f.permute(0, 2, 3, 1)
+            f = O.mm_RMSNorm(O.projector_mlp(f, w, m + "mm_rand_img_projector."), w[m + "mm_rand_img_norm.weight"])
+            ph = O.learnable_pos_embd(f.shape[1], pool, d, w, m + "mm_rand_pos_h.", f.dtype)
+            f = f + O.mm_rms_norm(ph.reshape(1, -1, 1, d))
+            pw = O.learnable_pos_embd(f.shape[2], pool, d, w, m + "mm_rand_pos_w.", f.dtype)
+            f = f + O.mm_rms_norm(pw.reshape(1, 1, -1, d))
+            f = f + pt_all[frame_offset + t].reshape(1, 1, 1, d)
+            rows.append(f.flatten(0, 2))
+        if not rows:
+            return torch.empty((0, d)), torch.empty((0,), dtype=torch.uint8)
+        feats = torch.cat(rows, dim=0)
+        mask = (torch.sum(torch.abs(feats), dim=-1) != 0) & bool(flag)
+        feats = O.mm_RMSNorm(feats, w[m + "mm_rand_llm_norm.weight"]) * mask.unsqueeze(-1)
+        return feats, mask.to(torch.uint8)
+
+    def _audios_local(self, mel, audio_size, chunk_offset, flag):
+        """the audio tokens of 30-s windows [chunk_offset, chunk_offset + C), window by window, clipped by the GLOBAL floors
+        (multimodal.py:210-252 for one window at a time; the Conv1d has kernel == stride == pool, so it never straddles windows)"""
+        import torch.nn.functional as F
+        from vidi_amd.shard import audio_shard_tokens
+        w, cfg, m = self.w, self.ocfg, "model."
+        d, pool = cfg.hidden_size, cfg.mm_audio_pool_size
+        s1, s2 = O.audio_token_counts([int(audio_size)], cfg)
+        s1, s2_total = int(s1[0]), int(s2[0])
+        assert s2_total > 1
+        pt_all = O.mm_rms_norm(O.learnable_pos_embd(s2_total, cfg.mm_time_interval, d, w, m + "mm_rand_pos_t.", torch.float32))
+        rows_per = cfg.aud_max_source_positions
+        rows = []
+        for c in range(int(mel.shape[0])):
+            tok0, n = audio_shard_tokens(chunk_offset + c, 1, rows_per, pool, s2_total)
+            if n <= 0:
+                continue
+            f = O.whisper_encoder_forward(mel[c: c + 1].float(), w, cfg)[0]               # [rows_per, Da]
+            f = F.conv1d(f[: n * pool].t()[None], w[m + "mm_rand_aud_pool.weight"], None, stride=pool)[0].t()
+            f = O.mm_RMSNorm(O.projector_mlp(f, w, m + "mm_rand_aud_projector."), w[m + "mm_rand_aud_norm.weight"])
+            rows.append(f + pt_all[tok0: tok0 + n])
+        if not rows:
+            return torch.empty((0, d)), torch.empty((0,), dtype=torch.uint8)
+        feats = torch.cat(rows, dim=0)
+        mask = (torch.sum(torch.abs(feats), dim=-1) != 0) & bool(flag)
+        feats = O.mm_RMSNorm(feats, w[m + "mm_rand_llm_norm.weight"]) * mask.unsqueeze(-1)
+        return feats, mask.to(torch.uint8)
+
     def encode_video_images(self, pixel, normalizer=None, frame_offset=0, total_frames=None, sample_flag=None, **kw):
+        if self._local():
+            flag = int(sample_flag[0]) if sample_flag is not None else int(bool((pixel != 0).any()))
+            self.last_shard = dict(kind="img", local=int(pixel.shape[0]), off=int(frame_offset), total=int(pixel.shape[0] if total_frames is None else total_frames))
+            return self._images_local(pixel.float().cpu(), int(frame_offset), total_frames, flag, kw.get("budget_frames"))
         if self.world > 1:
             allr = self._gather_shards(dict(x=pixel.float().cpu(), off=int(frame_offset), tot=total_frames, flag=int(sample_flag[0])))
             full = torch.cat([r["x"] for r in allr], dim=0)
@@ -66,6 +138,9 @@ class OracleEngine:
         return f[0], m[0].to(torch.uint8)
 
     def encode_video_audios(self, mel, audio_size, normalizer=None, chunk_offset=0, sample_flag=None, **kw):
+        if self._local():
+            flag = int(sample_flag[0]) if sample_flag is not None else int(bool((mel != 0).any()))
+            return self._audios_local(mel.float().cpu(), int(audio_size), int(chunk_offset), flag)
         if self.world > 1:
             allr = self._gather_shards(dict(x=mel.float().cpu(), off=int(chunk_offset), size=int(audio_size), flag=int(sample_flag[0])))
             full = torch.cat([r["x"] for r in allr], dim=0)

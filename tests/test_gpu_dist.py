@@ -71,3 +71,57 @@ def test_rccl_exchange_on_one_rank_matches_unsharded():
     assert torch.equal(b["tokens"][:, :1], a["tokens"][:, :1]) and torch.equal(b["tokens8"][:, :1], a["tokens8"][:, :1])
     assert torch.equal(b["tokens_cached"], b["tokens"])
     assert b["tokens_graph"] is not None and torch.equal(b["tokens_graph"], b["tokens"])      # 42... layers' exchanges replayed from the graph
+
+
+def test_gather_tokens_mode_two_ranks_is_bit_identical_to_single_rank():
+    """dist mode "gather_tokens" — BASELINE configs[3] as worded: frame-axis vision-encoder shard + all-gather of the visual (and audio) tokens,
+    decoder replicated.  Two ranks on the one GPU of the box (gloo transport, every kernel on the GPU): `encode_videos` must return the
+    single-rank tensors BIT FOR BIT on rank 0 (per-token math + data movement; 4 frames -> 2 + 2, 2 windows -> 1 + 1 with the second one
+    clipped by the global floors), and since every rank then runs the single-GPU decoder on identical inputs, the text hidden states and
+    the greedy tokens are bit-identical too; no per-layer collective is issued in that mode."""
+    env = {"VIDI_DIST_MODE": "gather_tokens"}
+    with tempfile.TemporaryDirectory() as d:
+        a = _launch(1, os.path.join(d, "w1.pt"))
+        b = _launch(2, os.path.join(d, "w2.pt"), env=env)
+    assert b["dist_mode"] == "gather_tokens" and not b["sharded"]
+    assert a["token_gathers"] == 0 and b["token_gathers"] == 4               # features + mask bytes, per modality
+    for x, y in zip(a["enc"], b["enc"]):
+        assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y)
+    assert (b["g_img"], b["g_aud"]) == (a["g_img"], a["g_aud"]) and b["n_img_local"] == a["n_img_local"] and b["n_aud_local"] == a["n_aud_local"]
+    assert b["collectives_per_forward"] == 0 and b["collectives8"] == 0
+    for k in ("prefill", "decode", "xattn_layer0"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("tokens", "tokens_cached", "tokens8"):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_gather_tokens_through_rccl_on_one_rank():
+    """the `nccl` (= RCCL) branch of the token all-gather on the one GPU of the box: a one-rank group with VIDI_FORCE_SHARDED=1 shards (1 x
+    everything), all-gathers through RCCL and must hand back the unsharded tensors bit for bit; graph-captured decode still works."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _launch(1, os.path.join(d, "w1.pt"))
+        b = _launch(1, os.path.join(d, "w1g.pt"), env={"VIDI_FORCE_SHARDED": "1", "VIDI_DIST_BACKEND": "nccl", "VIDI_DIST_MODE": "gather_tokens", "RANK": "0",
+                                                       "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29535"})
+    assert b["dist_mode"] == "gather_tokens" and b["token_gathers"] == 4 and not b["sharded"]
+    for x, y in zip(a["enc"], b["enc"]):
+        assert torch.equal(x, y)
+    for k in ("prefill", "decode", "tokens", "tokens8", "tokens_graph"):
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("transport", ["gloo_two_ranks", "rccl_one_rank"])
+def test_overlapped_exchange_has_the_bits_of_the_serial_one(transport):
+    """sharded stream: the per-layer all-gather of the packed partials is issued (asynchronously, on the backend's stream) BEFORE the T2T
+    launch and waited for after it (VIDI_DIST_OVERLAP=1, the default) — same launches, same operands as the serial order (=0): the
+    hidden states, the merged cross-attention and the tokens must agree bit for bit, eagerly and (RCCL) replayed from the decode graph."""
+    base = {} if transport == "gloo_two_ranks" else {"VIDI_FORCE_SHARDED": "1", "VIDI_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1",
+                                                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29536"}
+    world = 2 if transport == "gloo_two_ranks" else 1
+    with tempfile.TemporaryDirectory() as d:
+        a = _launch(world, os.path.join(d, "serial.pt"), env={**base, "VIDI_DIST_OVERLAP": "0"})
+        b = _launch(world, os.path.join(d, "overlap.pt"), env={**base, "VIDI_DIST_OVERLAP": "1"})
+    assert a["sharded"] and b["sharded"] and a["collectives_per_forward"] == b["collectives_per_forward"] == a["layers"]
+    for k in ("prefill", "decode", "xattn_layer0", "tokens", "tokens8"):
+        assert torch.equal(a[k], b[k]), k
+    if transport == "rccl_one_rank":
+        assert torch.equal(a["tokens_graph"], b["tokens_graph"]) and torch.equal(b["tokens_graph"], b["tokens"])

@@ -174,6 +174,147 @@ def test_batch_of_eight_ragged_queries_under_set_dist():
     assert got[0][2] == got[1][2], (got[0][2], got[1][2])
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# dist mode "gather_tokens": the north-star's literal collective (BASELINE configs[3]) — frame-sharded encode + all-gather of the tokens
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _gather_worker(rank, world, port, frames, windows, audio_size, ret, two_videos):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from oracle_engine import OracleEngine
+    from util import seeded
+    from vidi_amd.config import tiny
+    from vidi_amd.model import VidiForCausalLM
+    from vidi_amd.weights import init_random_weights
+    torch.set_num_threads(1)
+    cfg = tiny()
+    w = init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu")
+    eng = OracleEngine(cfg, w)
+    eng.per_unit = True                      # frames / windows one at a time on every world size: bit-comparable (see OracleEngine)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        eng.set_dist(None, mode="gather_tokens")
+    model = VidiForCausalLM(cfg, w, dtype=torch.float32, device="cpu", engine=eng)
+    px = seeded((frames, 3, cfg.vis_image_size, cfg.vis_image_size), 200, 0.5).clamp(-1, 1)
+    mel = seeded((windows, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 201, 0.3)
+    ids = torch.tensor([[2, 21, 22, -200, 23, 24, 25]], dtype=torch.int64)
+    fi, mi, fa, ma = model.encode_videos([px], [mel], [audio_size])
+    rec = dict(rank=rank, fi=fi.numpy(), mi=mi.numpy(), fa=fa.numpy(), ma=ma.numpy(), gathers=getattr(eng, "n_token_gathers", 0))
+    rec["tokens"] = model.generate(ids, images=[px], audios=[mel], audio_sizes=[audio_size], max_new_tokens=4, do_sample=False).tolist()
+    if two_videos:
+        # a batch of two videos of different lengths (one prompt each): every video is sharded on its own, the token budget is the batch's
+        px2 = seeded((3, 3, cfg.vis_image_size, cfg.vis_image_size), 202, 0.5).clamp(-1, 1)
+        mel2 = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 203, 0.3)
+        b = model.encode_videos([px, px2], [mel, mel2], [audio_size, 90])
+        rec["batch"] = [t.numpy() for t in b]
+    ret.put(rec)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_gather(world, frames, windows, audio_size, two_videos=False, timeout=300):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, frames, windows, audio_size, ret, two_videos)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((ret.get(timeout=timeout) for _ in range(world)), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("world,frames,windows,audio_size,two", [(2, 5, 2, 173, True), (3, 2, 2, 173, False), (8, 11, 3, 273, False)],
+                         ids=["world2_ragged+batch", "world3_empty_shards", "world8_ragged_clipped"])
+def test_gather_tokens_mode_reproduces_single_rank_encode_videos_bit_for_bit(world, frames, windows, audio_size, two):
+    """`encode_videos` under `set_dist(mode="gather_tokens")`: every rank encodes its frame / window range with the global positions, the
+    tokens + masks are all-gathered (ragged shards padded for the collective, narrowed after) and EVERY rank must hold the single-rank
+    tensors bit for bit — features and masks of both modalities, reference order (multimodal.py:254-265).  world 3 with 2 frames / 2
+    windows leaves rank 2 with empty shards; world 8 with 11 frames is ragged (2,2,2,1,...) and 3 windows leave five ranks without audio,
+    the last window clipped by the global floors.  generate() in that mode returns the single-rank tokens (decoder replicated)."""
+    ref = _run_gather(1, frames, windows, audio_size, two)[0]
+    got = _run_gather(world, frames, windows, audio_size, two)
+    assert len(got) == world
+    for r in got:
+        for k in ("fi", "mi", "fa", "ma"):
+            assert r[k].shape == ref[k].shape and r[k].dtype == ref[k].dtype, (k, r[k].shape, ref[k].shape)
+            assert np.array_equal(r[k], ref[k]), f"rank {r['rank']}: {k} differs from the single-rank encode"
+        assert r["tokens"] == ref["tokens"]
+        assert r["gathers"] >= 4                                      # features + mask per modality, per encode
+        if two:
+            for a, b in zip(r["batch"], ref["batch"]):
+                assert np.array_equal(a, b)
+    assert ref["gathers"] == 0
+    # ... and the per-unit evaluation those bits come from IS the oracle's encode (the batched restatement of multimodal.py:156-252)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import vidi_oracle as O
+    from oracle_engine import oracle_config
+    from util import seeded
+    from vidi_amd.config import tiny
+    from vidi_amd.weights import init_random_weights
+    cfg = tiny()
+    w = {k: v.float() for k, v in init_random_weights(cfg, seed=3, dtype=torch.float32, device="cpu").items()}
+    px = seeded((frames, 3, cfg.vis_image_size, cfg.vis_image_size), 200, 0.5).clamp(-1, 1)
+    mel = seeded((windows, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 201, 0.3)
+    f, m = O.encode_video_images([px], w, oracle_config(cfg))
+    fa, ma = O.encode_video_audios([mel], [audio_size], w, oracle_config(cfg))
+    assert np.array_equal(m.numpy(), ref["mi"]) and np.array_equal(ma.numpy(), ref["ma"])
+    np.testing.assert_allclose(ref["fi"], f.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ref["fa"], fa.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_all_gather_rows_ragged_and_even():
+    """vidi_amd/dist.py on gloo, world 3: ragged row counts incl. an empty shard, 1-D masks, and the even fast path"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, 3, port, ret)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = [ret.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(got)
+
+
+def _rows_worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    from vidi_amd.dist import all_gather_rows
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for counts in ([3, 0, 2], [2, 2, 2], [0, 0, 0], [1, 4, 4]):
+        full = torch.arange(sum(counts) * 5, dtype=torch.float32).view(sum(counts), 5)
+        offs = [sum(counts[:r]) for r in range(world)]
+        out = all_gather_rows(full[offs[rank]: offs[rank] + counts[rank]].clone(), counts, None)
+        ok &= torch.equal(out, full)
+        m = (torch.arange(sum(counts)) % 3).to(torch.uint8)
+        ok &= torch.equal(all_gather_rows(m[offs[rank]: offs[rank] + counts[rank]].clone(), counts, None), m)
+    try:
+        all_gather_rows(torch.zeros(2, 5), [1, 1, 1], None)                 # a rank whose piece disagrees with the partition
+        ok = False
+    except ValueError:
+        pass
+    ret.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_split_key_slices_of_the_dual_cross_attention_launch():
     """host logic of engine._cross_dual: slices in proportion to the keys, never empty, never more than the launch has, short modalities
     capped at one slice per 8 sub-tiles"""

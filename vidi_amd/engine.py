@@ -42,26 +42,7 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def token_budget_hw(T: int, side: int, pool: int, base: int) -> Tuple[int, int]:
-    """Token-budget rule (multimodal.py:175-180 + vidi/utils.py:152-171), integer/float host math.
-    Returns the `hw` the reference hands to Conv2DPool; (28,28) is its "no resize" sentinel."""
-    n_tokens = T * (side + 1) * (side + 1)
-    max_tokens = base * pool * pool
-    if n_tokens > max_tokens:
-        H = W = side + 1
-        ratio = math.sqrt(max_tokens / (T * H * W))
-        th, tw = int(H * ratio), int(W * ratio)
-        return max(10, th - th % 2), max(10, tw - tw % 2)
-    return 28, 28
-
-
-def audio_token_counts(audio_size: int, cfg: VidiConfig) -> Tuple[int, int]:
-    """floor(size*1500/3000), then floor(/pool) — multimodal.py:226-227, 234-235 (same numpy float64 ops)."""
-    import numpy as np
-    pool_ratio = cfg.aud_max_source_positions / cfg.aud_nb_max_frames
-    s1 = int(np.floor(np.array([audio_size]) * pool_ratio).astype(int)[0])
-    s2 = int(np.floor(np.array([s1]) / cfg.mm_audio_pool_size).astype(int)[0])
-    return s1, s2
+from .shard import audio_token_counts, token_budget_hw  # noqa: E402,F401  (host integer rules; re-exported: bench.py and the tests import them from here)
 
 
 @dataclass
@@ -157,6 +138,11 @@ class VidiEngine:
         self._ws: Dict[str, torch.Tensor] = {}
         self.pg, self.world, self.rank = None, 1, 0
         self.sharded = False                            # set_dist(): the key-sharded cross-attention path (world > 1, or forced for a one-rank RCCL test)
+        self.shard_encode = False                       # set_dist(): every rank encodes its own frame / window range (both dist modes)
+        self.dist_mode = "sharded_stream"
+        # sharded stream: the per-layer all-gather is issued asynchronously (it runs on the backend's stream) BEFORE the T2T launch and
+        # waited for after it, so the text self-attention hides it (VIDI_DIST_OVERLAP=0: T2T, then the exchange, strictly serial)
+        self.dist_overlap = os.environ.get("VIDI_DIST_OVERLAP", "1") != "0"
         self.n_collectives = 0                          # data-path all-gathers issued (one per decoder layer per forward when sharded)
 
     # -----------------------------------------------------------------------------------------
@@ -813,11 +799,11 @@ class VidiEngine:
         hip.attn_merge2(*merge[0], *merge[1], nkv=nkv, R=R, Rpad=Rpad, G=G, HD=hd)
         return True
 
-    def _cross_sharded(self, q: torch.Tensor, li: int, mm: MMState, outs: Dict[str, torch.Tensor], R: int):
-        """T2V + T2A of one layer with the keys sharded over ranks.  Per rank: split-KV partials over the local keys ->
-        ONE launch folds them into the partial form (numerator, m, l) of both modalities, written straight into a packed send
-        buffer -> ONE all-gather (RCCL) per layer -> ONE launch merges the world's partials of both modalities (exact: the tanh
-        softcap is per logit, the merge is the LSE identity flash-attn itself uses between key blocks).
+    def _cross_sharded_begin(self, q: torch.Tensor, li: int, mm: MMState, outs: Dict[str, torch.Tensor], R: int, async_op: bool = False):
+        """T2V + T2A of one layer with the keys sharded over ranks, first half.  Per rank: split-KV partials over the local
+        keys -> ONE launch folds them into the partial form (numerator, m, l) of both modalities, written straight into a packed send
+        buffer -> ONE all-gather (RCCL) per layer, issued here.  `async_op`: the collective runs on the backend's stream and the caller
+        goes on launching (the T2T attention) before `_cross_sharded_finish` waits for it.
         `outs`: {"img": [M, nq*hd] slice, "aud": ...} for the modalities the SAMPLE has (a global property)."""
         from .shard import packed_offsets, packed_partial_floats
         cfg = self.cfg
@@ -847,32 +833,50 @@ class VidiEngine:
             ldo = outs[which].stride(0)
         dt = hip._dt(outs[mods[0]])
         hip.attn_merge2_sharded(local_sets, nkv=nkv, R=R, Rpad=Rpad, rpo=R, G=G, HD=hd, ldo=ldo, dtype=dt)
-        self._all_gather(recv, send)
+        work = self._all_gather(recv, send, async_op=async_op)
         self.n_collectives += 1
-        hip.attn_merge2_sharded(final_sets, nkv=nkv, R=R, Rpad=R, rpo=R, G=G, HD=hd, ldo=ldo, dtype=dt)
+        return work, final_sets, dict(nkv=nkv, R=R, Rpad=R, rpo=R, G=G, HD=hd, ldo=ldo, dtype=dt)
+
+    def _cross_sharded_finish(self, pending) -> None:
+        """second half: wait for the layer's all-gather (a stream dependency, no host block under RCCL), then ONE launch merges the
+        world's partials of both modalities (exact: the tanh softcap is per logit, the merge is the LSE identity flash-attn itself uses
+        between key blocks)."""
+        work, final_sets, kw = pending
+        work.wait()
+        hip.attn_merge2_sharded(final_sets, **kw)
+
+    def _cross_sharded(self, q: torch.Tensor, li: int, mm: MMState, outs: Dict[str, torch.Tensor], R: int):
+        self._cross_sharded_finish(self._cross_sharded_begin(q, li, mm, outs, R))
 
     # -----------------------------------------------------------------------------------------
     # multi-GPU (one process per GPU, RCCL): frame/chunk-sharded keys, replicated text stream
     # -----------------------------------------------------------------------------------------
-    def set_dist(self, group=None):
+    def set_dist(self, group=None, mode: Optional[str] = None):
+        """One process per GPU: every rank is handed the SAME video and encodes its contiguous range of frames / 30-s windows with the
+        global positions (vidi_amd/shard.py).  What happens next is `mode` (default: $VIDI_DIST_MODE or "sharded_stream"):
+
+        "gather_tokens"   the north-star's literal collective (BASELINE configs[3]): RCCL all-gather of the visual and audio tokens
+                          (645 MB + 258 MB at 60 min) -> reference-order `[Nv, H]` on every rank, then the decoder replicated: the
+                          diagonal stream, the K/V caches and the cross-attention are those of a single GPU.  Scales the towers only
+                          (Amdahl: the 1.9 PFLOP stream stays on every rank).
+        "sharded_stream"  the shard stays resident through the decoder: each rank streams ITS tokens through the 42 layers and keeps its
+                          K/V shard; per layer one all-gather of packed cross-attention partials + exact LSE merge."""
         import torch.distributed as dist
+        mode = mode or os.environ.get("VIDI_DIST_MODE", "sharded_stream")
+        if mode not in ("gather_tokens", "sharded_stream"):
+            raise ValueError(f"dist mode {mode!r}: expected 'gather_tokens' or 'sharded_stream'")
         self.pg = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        # VIDI_FORCE_SHARDED=1: a one-rank group still goes through shard -> partial form -> all-gather -> merge, so the RCCL branch of
-        # the exchange can be exercised on a one-GPU box (tests/test_gpu_dist.py)
-        self.sharded = self.world > 1 or os.environ.get("VIDI_FORCE_SHARDED", "0") == "1"
+        self.dist_mode = mode
+        # VIDI_FORCE_SHARDED=1: a one-rank group still goes through shard -> (token all-gather | partial form -> all-gather -> merge), so
+        # the RCCL branch of either exchange can be exercised on a one-GPU box (tests/test_gpu_dist.py)
+        self.shard_encode = self.world > 1 or os.environ.get("VIDI_FORCE_SHARDED", "0") == "1"
+        self.sharded = self.shard_encode and mode == "sharded_stream"
 
-    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
-        import torch.distributed as dist
-        # `out` is [world, *inp.shape]; pass it in the concatenated-along-dim-0 form both backends accept
-        cat_shape = (out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:])
-        if dist.get_backend(self.pg) == "gloo":              # CPU-transport test mode (2 ranks on one GPU)
-            o, i = out.cpu().view(cat_shape), inp.cpu().contiguous()
-            dist.all_gather_into_tensor(o, i, group=self.pg)
-            out.copy_(o.view(out.shape))
-        else:
-            dist.all_gather_into_tensor(out.view(cat_shape), inp, group=self.pg)
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        from .dist import all_gather_packed
+        return all_gather_packed(out, inp, self.pg, async_op=async_op)
 
     def text_forward(self, hidden: torch.Tensor, positions: torch.Tensor, ts: TextState, mm: Optional[MMState],
                      Lq: int, new_mask: Optional[torch.Tensor] = None, dyn: bool = False) -> torch.Tensor:
@@ -939,6 +943,19 @@ class VidiEngine:
             # cross-attention partials (vidi_attn_text_decode_merge2) after the T2V + T2A partial pass
             t2t_with_merge = (t2t_fused and self.decode_tail and self.cross_dual and not self.sharded and hd in (128, 256)
                               and mm is not None and mm.g_img > 0 and mm.g_aud > 0)
+            k = 1
+            pending = outs = None
+            if self.sharded:
+                outs = {}
+                if has_img:
+                    outs["img"] = att[k * M: (k + 1) * M]; k += 1
+                if has_aud:
+                    outs["aud"] = att[k * M: (k + 1) * M]; k += 1
+                if outs and self.dist_overlap:
+                    # local partials + pack + the layer's all-gather go out FIRST (they need only the raw q of the projection); the
+                    # collective then runs on RCCL's stream while the T2T launches below execute — same launches, same operands,
+                    # same bits as the serial order
+                    pending = self._cross_sharded_begin(qkv[:, :nqd], li, mm, outs, R=M * (nq // nkv), async_op=True)
             if t2t_with_merge:
                 pass
             elif t2t_fused:
@@ -953,16 +970,12 @@ class VidiEngine:
                 hip.rope_cache(qkv, qr, ts.kc[li], ts.vc[li], cos, sin, B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd, pos0=p0)
                 hip.attn_text(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
                               past_len=p0, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
-            k = 1
             qraw = qkv[:, :nqd]
             G = nq // nkv
             if self.sharded:
-                outs = {}
-                if has_img:
-                    outs["img"] = att[k * M: (k + 1) * M]; k += 1
-                if has_aud:
-                    outs["aud"] = att[k * M: (k + 1) * M]; k += 1
-                if outs:
+                if pending is not None:
+                    self._cross_sharded_finish(pending)
+                elif outs:
                     self._cross_sharded(qraw, li, mm, outs, R=M * G)
             else:
                 both = has_img and has_aud

@@ -188,7 +188,7 @@ class VidiForCausalLM:
         eng = self.engine
         B = self._n_videos(images, audios)
         vis = aud = None
-        if not hasattr(eng, "siglip_forward") or getattr(eng, "sharded", eng.world > 1):
+        if not hasattr(eng, "siglip_forward") or self._shard_on():
             return vis, aud
         if images is not None and all(int(images[i].shape[0]) > 0 for i in range(B)):
             f = eng.siglip_forward(torch.cat([images[i].to(eng.dev) for i in range(B)], dim=0))
@@ -204,11 +204,55 @@ class VidiForCausalLM:
             return None
         return int(sum(int(images[i].shape[0]) for i in range(self._n_videos(images, None))))
 
+    def _shard_on(self) -> bool:
+        """True once `engine.set_dist()` made this process one rank of a frame-sharded group (either dist mode)"""
+        eng = self.engine
+        return bool(getattr(eng, "shard_encode", eng.world > 1))
+
+    def _encode_shard(self, img, aud, audio_size, normalizer=None, budget_frames=None):
+        """This rank's share of ONE video (every rank is handed all of it): its contiguous range of frames and of 30-s audio windows
+        (vidi_amd/shard.py), encoded with the GLOBAL positions (`frame_offset` / `total_frames` for pos_t and the token budget,
+        `chunk_offset` + the global `audio_size` for the audio floors) and the WHOLE sample's "any non-zero input" flags
+        (`images.sum() != 0`, multimodal.py:203-206, 247-250).  -> (fi, mi, fa, ma) of the local tokens, the shard."""
+        from .shard import video_shard
+        eng = self.engine
+        sh = video_shard(0 if img is None else int(img.shape[0]), 0 if aud is None else int(aud.shape[0]), eng.world, eng.rank)
+        fi = mi = fa = ma = None
+        kw = {} if normalizer is None else dict(normalizer=normalizer)
+        if img is not None:
+            kw_i = dict(kw, frame_offset=sh.f0, total_frames=sh.total_frames, sample_flag=eng.sample_flag(img))
+            if budget_frames is not None:
+                kw_i["budget_frames"] = int(budget_frames)
+            fi, mi = eng.encode_video_images(img[sh.f0: sh.f1].to(eng.dev), **kw_i)
+        if aud is not None:
+            fa, ma = eng.encode_video_audios(aud[sh.c0: sh.c1].to(eng.dev), int(audio_size), chunk_offset=sh.c0, sample_flag=eng.sample_flag(aud), **kw)
+        return fi, mi, fa, ma, sh
+
+    def _gather_tokens(self, fi, mi, fa, ma, sh, audio_size, budget_frames=None):
+        """The north-star's collective (BASELINE configs[3]): all-gather of the visual (and audio) tokens the ranks encoded, so that every
+        rank holds the reference-order rows `encode_videos` returns on one GPU (multimodal.py:254-265; the reference's own sequence-
+        parallel path gathers the same way: sequence_parallel/all_to_all.py:361 `Gather.forward`, split.py:73-93 `merge_data`).  The
+        row counts of all ranks follow from host integers (shard.gather_counts); ragged shards are padded for the collective and
+        narrowed after it.  Per-token math + data movement: bit-identical to the single-rank encode."""
+        from .dist import all_gather_rows
+        from .shard import gather_counts
+        eng = self.engine
+        n_img, n_aud = gather_counts(self.config, sh.total_frames if fi is not None else 0, sh.total_windows if fa is not None else 0,
+                                     audio_size, eng.world, budget_frames)
+        if fi is not None:
+            fi, mi = all_gather_rows(fi, n_img, eng.pg), all_gather_rows(mi, n_img, eng.pg)
+        if fa is not None:
+            fa, ma = all_gather_rows(fa, n_aud, eng.pg), all_gather_rows(ma, n_aud, eng.pg)
+        eng.n_token_gathers = getattr(eng, "n_token_gathers", 0) + 2 * (int(fi is not None) + int(fa is not None))
+        return fi, mi, fa, ma
+
     def encode_videos(self, images, audios, audio_sizes):
         """-> (image_features[B,Nv,H], image_mask[B,Nv] bool, audio_features[B,Na,H], audio_mask[B,Na] bool),
         un-normalised like the reference (the normaliser is applied inside the decoder, gemma.py:353-356).  A batch of videos goes
         through each tower in ONE pass and shares the token budget (the reference pools by the batch's total frame count), then
-        every video is finished on its own (positions, norms, masks) and the rows are padded like multimodal.py:199, 243."""
+        every video is finished on its own (positions, norms, masks) and the rows are padded like multimodal.py:199, 243.
+        Under `engine.set_dist()` (one process per GPU, either dist mode) every rank encodes its frame / window range of each video and
+        the tokens are all-gathered: the SAME reference-order tensors on every rank, bit-identical to the single-rank call."""
         eng = self.engine
         B = self._n_videos(images, audios)
         vis, aud = self._tower_batch(images, audios) if B > 1 else (None, None)
@@ -218,6 +262,12 @@ class VidiForCausalLM:
             img = self._single(self._row(images, i) if B > 1 else images, "images")
             au = self._single(self._row(audios, i) if B > 1 else audios, "audios")
             fi = mi = fa = ma = None
+            if self._shard_on():
+                asz = None if au is None else int(audio_sizes[i])
+                fi, mi, fa, ma, sh = self._encode_shard(img, au, asz, budget_frames=budget)
+                fi, mi, fa, ma = self._gather_tokens(fi, mi, fa, ma, sh, asz, budget_frames=budget)
+                per.append((fi, None if mi is None else mi.bool(), fa, None if ma is None else ma.bool()))
+                continue
             if img is not None:
                 kw = {} if budget is None else dict(budget_frames=budget)
                 if vis is not None:
@@ -245,27 +295,24 @@ class VidiForCausalLM:
         aud = self._single(audios, "audios")
         fi = mi = fa = ma = None
         nz = eng.normalizer
-        kw_i, kw_a = {}, {}
-        if budget_frames is not None:
-            kw_i["budget_frames"] = int(budget_frames)
-        if getattr(eng, "sharded", eng.world > 1):
-            from .shard import video_shard
-            sh = video_shard(0 if img is None else int(img.shape[0]), 0 if aud is None else int(aud.shape[0]), eng.world, eng.rank)
-            if img is not None:
-                kw_i.update(frame_offset=sh.f0, total_frames=sh.total_frames, sample_flag=eng.sample_flag(img))
-                img = img[sh.f0: sh.f1]
-            if aud is not None:
-                kw_a = dict(chunk_offset=sh.c0, sample_flag=eng.sample_flag(aud))
-                aud = aud[sh.c0: sh.c1]
+        if self._shard_on():
+            asz = None if aud is None else int(audio_sizes[0])
+            fi, mi, fa, ma, sh = self._encode_shard(img, aud, asz, normalizer=nz, budget_frames=budget_frames)
+            if getattr(eng, "dist_mode", "sharded_stream") == "gather_tokens":
+                # the all-gather of visual / audio tokens; from here on the decoder is replicated (stream, caches, cross-attention of one GPU)
+                fi, mi, fa, ma = self._gather_tokens(fi, mi, fa, ma, sh, asz, budget_frames=budget_frames)
         else:
+            kw_i, kw_a = {}, {}
+            if budget_frames is not None:
+                kw_i["budget_frames"] = int(budget_frames)
             if vis_features is not None:
                 kw_i["vis_features"] = vis_features
             if aud_features is not None:
                 kw_a["aud_features"] = aud_features
-        if img is not None:
-            fi, mi = eng.encode_video_images(img.to(eng.dev), normalizer=nz, **kw_i)
-        if aud is not None:
-            fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]), normalizer=nz, **kw_a)
+            if img is not None:
+                fi, mi = eng.encode_video_images(img.to(eng.dev), normalizer=nz, **kw_i)
+            if aud is not None:
+                fa, ma = eng.encode_video_audios(aud.to(eng.dev), int(audio_sizes[0]), normalizer=nz, **kw_a)
         st = eng.mm_stream_prefill(fi, mi, fa, ma, pre_normalized=True)
         st.image_attention_mask, st.audio_attention_mask = mi, ma
         return st
@@ -277,15 +324,8 @@ class VidiForCausalLM:
 
     def _bcast0(self, t: torch.Tensor) -> torch.Tensor:
         """rank 0's value of a small tensor on every rank of the engine's group"""
-        import torch.distributed as dist
-        pg = self.engine.pg
-        src = dist.get_global_rank(pg, 0) if pg is not None else 0
-        if self._backend() == "gloo" and t.is_cuda:                 # CPU-transport test mode
-            c = t.cpu()
-            dist.broadcast(c, src=src, group=pg)
-            return c.to(t.device)
-        dist.broadcast(t, src=src, group=pg)
-        return t
+        from .dist import broadcast0
+        return broadcast0(t, self.engine.pg)
 
     def _stack_rows(self, rows, pad, kwargs):
         """answers of a batch decoded row by row ([k, n_i] each; k = num_return_sequences under beam search, else 1) -> [sum k, max n_i],

@@ -8,8 +8,31 @@ frames and of 30-s audio windows, encodes them with the GLOBAL positions (`frame
 Pure host integer logic: importable without a GPU (tests/test_shard.py drives it under gloo)."""
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
-from typing import Tuple
+from typing import List, Optional, Tuple
+
+
+def token_budget_hw(T: int, side: int, pool: int, base: int) -> Tuple[int, int]:
+    """Token-budget rule (multimodal.py:175-180 + vidi/utils.py:152-171), integer/float host math.
+    Returns the `hw` the reference hands to Conv2DPool; (28,28) is its "no resize" sentinel."""
+    n_tokens = T * (side + 1) * (side + 1)
+    max_tokens = base * pool * pool
+    if n_tokens > max_tokens:
+        H = W = side + 1
+        ratio = math.sqrt(max_tokens / (T * H * W))
+        th, tw = int(H * ratio), int(W * ratio)
+        return max(10, th - th % 2), max(10, tw - tw % 2)
+    return 28, 28
+
+
+def audio_token_counts(audio_size: int, cfg) -> Tuple[int, int]:
+    """floor(size*1500/3000), then floor(/pool) — multimodal.py:226-227, 234-235 (same numpy float64 ops)."""
+    import numpy as np
+    pool_ratio = cfg.aud_max_source_positions / cfg.aud_nb_max_frames
+    s1 = int(np.floor(np.array([audio_size]) * pool_ratio).astype(int)[0])
+    s2 = int(np.floor(np.array([s1]) / cfg.mm_audio_pool_size).astype(int)[0])
+    return s1, s2
 
 
 def shard(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -56,6 +79,33 @@ def audio_shard_tokens(chunk_offset: int, windows_local: int, rows_per_window: i
     per = rows_per_window // pool
     tok0 = chunk_offset * per
     return tok0, max(0, min(tokens_total - tok0, windows_local * per))
+
+
+def image_tokens_per_frame(cfg, budget_frames: int) -> int:
+    """video tokens one frame contributes: (h / pool) * (w / pool) under the token-budget rule (Vidi1.5, `budget_frames` = the frames the
+    rule counts: the whole batch's, multimodal.py:157-158, 175-180), pool * pool for Vidi-7B's learned Conv2DPool."""
+    pool = cfg.mm_image_pool_size
+    if cfg.arch == "mistral":
+        return pool * pool
+    hw = token_budget_hw(budget_frames, cfg.vis_side, pool, cfg.mm_max_tokens_base)
+    h, w = hw if hw[0] != 28 else (cfg.vis_side + 1, cfg.vis_side + 1)
+    return (h // pool) * (w // pool)
+
+
+def gather_counts(cfg, total_frames: int, total_windows: int, audio_size: Optional[int], world: int,
+                  budget_frames: Optional[int] = None) -> Tuple[List[int], List[int]]:
+    """Rows every rank contributes to the all-gather of visual / audio tokens (`dist_mode = "gather_tokens"`), from host integers alone —
+    no rank has to ask another how much it encoded: -> (video tokens per rank, audio tokens per rank), both in rank (= reference) order."""
+    per = image_tokens_per_frame(cfg, total_frames if budget_frames is None else budget_frames) if total_frames else 0
+    img = [(shard(total_frames, world, r)[1] - shard(total_frames, world, r)[0]) * per for r in range(world)]
+    aud = [0] * world
+    if total_windows and audio_size is not None:
+        s2_total = audio_token_counts(int(audio_size), cfg)[1]
+        rows = cfg.aud_max_source_positions                     # encoder rows per 30-s window
+        for r in range(world):
+            c0, c1 = shard(total_windows, world, r)
+            aud[r] = audio_shard_tokens(c0, c1 - c0, rows, cfg.mm_audio_pool_size, s2_total)[1]
+    return img, aud
 
 
 def packed_partial_floats(n_modalities: int, nkv: int, rows: int, hd: int) -> int:
