@@ -169,3 +169,64 @@ def test_reference_ask_drives_the_hip_engine(arch, compat, drop, preset, tmp_pat
         sys.path.pop(0)
         for k in [k for k in sys.modules if k == drop or k.startswith(drop + ".")]:
             del sys.modules[k]
+
+
+@pytest.mark.parametrize("arch,compat,drop,preset", [("vidi15", "compat", "vidi", "tiny"), ("vidi7b", "compat_7b", "model", "tiny_7b")])
+def test_reference_ask_on_the_dummy_clip_with_nothing_stubbed(arch, compat, drop, preset, tmp_path, monkeypatch):
+    """BASELINE `configs[0]` ("inference.py on dummy.mp4") on the HIP engine with NO loader monkeypatched: the reference's unmodified
+    `ask()` is handed the PATH of a clip and goes through its own `load_video` (decord), `load_audio` (ffmpeg), `process_audio`,
+    `get_length` / `get_media_length` (ffprobe) — resolved through vidi_amd/compat* to vidi_amd/processors.py — with the three decoders
+    the image lacks served by tests/fakes/ (a synthetic clip with dummy.mp4's parameters: 394 frames @16 fps, 24.625 s; the loaders
+    themselves are pinned on the reference's in tests/test_media_plumbing.py).  25 frames and audio_size 2462 must reach `generate()`,
+    and vidi_amd/inference.py must return the same string from the same path."""
+    import importlib.util
+    import sys
+    path = _reference_script(arch)
+    assert path is not None, "the reference's inference.py is neither checked out nor staged: run __graft_entry__.build() in the build container"
+    fakes = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fakes")
+    monkeypatch.syspath_prepend(fakes)
+    for k in [k for k in sys.modules if k == "decord" or k.startswith("decord.")]:
+        monkeypatch.delitem(sys.modules, k)
+    import fake_clip
+    monkeypatch.setenv("PATH", fake_clip.install_executables(str(tmp_path / "bin")) + os.pathsep + os.environ["PATH"])
+    clip = str(tmp_path / "dummy.mp4")
+    meta = fake_clip.write_clip(clip)
+    from vidi_amd import config as C, inference as OURS
+    from vidi_amd.weights import init_random_weights
+    cfg = getattr(C, preset)(sliding_window=64) if arch == "vidi15" else getattr(C, preset)()
+    w = init_random_weights(cfg, seed=9, dtype=torch.float16)
+    ckpt = str(tmp_path / "ckpt")
+    write_checkpoint(ckpt, cfg, w)
+    write_tokenizer(ckpt, cfg.vocab_size, mistral=arch == "vidi7b")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vidi_amd", compat))
+    for k in [k for k in sys.modules if k == drop or k.startswith(drop + ".")]:
+        del sys.modules[k]
+    try:
+        spec = importlib.util.spec_from_file_location("ref_inference_gpu_clip_" + compat, path)
+        INF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(INF)                                              # <- the reference's file, unmodified
+        model, tok, ip, ap = INF.load_pretrained_model(ckpt)
+        assert model.engine.__class__.__name__ == "VidiEngine"
+        model.config.mm_splits = 32
+        seen = {}
+        gen = model.generate
+
+        def spy(*a, **k):
+            seen["images"], seen["audios"], seen["audio_sizes"] = k["images"], k["audios"], k["audio_sizes"]
+            seen["out"] = gen(*a, **dict(k, max_new_tokens=24))
+            return seen["out"]
+        monkeypatch.setattr(model, "generate", spy)
+        ref = INF.ask("a dog running.", clip, model, tok, ip, ap)                 # the reference's own function, from the clip's path
+        assert seen["images"].shape[:2] == (1, 25) and seen["images"].is_cuda     # frames 0, 16, ..., 384
+        assert seen["audio_sizes"] == [2462]                                       # 394 000 samples // 160
+        ref_tokens = seen["out"].cpu().tolist()
+        ours = OURS.ask("a dog running.", clip, model, tok, ip, ap, arch=arch)
+        assert seen["out"].cpu().tolist() == ref_tokens and ref == ours and len(ref) > 0, (ref, ours)
+        last = max(float(x) for seg in ref.split(", ") for x in [seg.split("-")[1].split(":")[2]])
+        assert last <= meta["duration"] + 1                                         # percentages x ffprobe's 24.625 s: inside the clip
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("decord", None)
+        for k in [k for k in sys.modules if k == drop or k.startswith(drop + ".")]:
+            del sys.modules[k]

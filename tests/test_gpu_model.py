@@ -273,6 +273,7 @@ def test_batch_of_videos_one_tower_pass_and_the_batch_token_budget():
             assert int(got[b, 0]) == int(ref_ids[b, 0])
 
 
+@pytest.mark.hipgraph
 def test_graph_decode_equals_eager(tiny_setup, monkeypatch):
     """The hipGraph-replayed decode (device-side cache position, vidi_attn_text_dyn) must emit exactly the
     tokens of the eager per-launch loop, for a batch of two prompts of different lengths sharing one video."""

@@ -1,0 +1,137 @@
+"""Parity AT THE REAL DIMENSIONS against outputs of the reference's own code (tests/golden/make_golden_realdims.py ->
+reference_realdims.npz: `DattnGemma2ForCausalLM.forward` executed on CPU / fp32 at hidden 3584, 16 / 8 heads x 256, GeGLU 14 336,
+SigLIP 1152 / 16 x 72 / 4 304 over 729 tokens, Whisper 1 280 / 20 x 64 / 5 120 over 1 500 rows; depth cut to 2 decoder / 2 + 2 tower layers).
+
+* CPU (`-m "not gpu"`): the oracle — fp32 on both sides — must reproduce the reference's tower rows, token embeddings, K / V cache rows
+  of both decoder layers, last hidden states and logits: this pins oracle/vidi_oracle.py at the dims the big GPU tests
+  (test_gpu_full_depth.py, test_gpu_baseline_scale.py) hold the kernels to.
+* GPU (`-m gpu`): the HIP path against the same vectors DIRECTLY, no oracle in between:
+  - free-running: frames / mel -> `VidiForCausalLM.forward` -> logits at every prompt position, last hidden states, embeddings;
+  - teacher-forced: the reference's own token embeddings fed to `mm_stream_prefill` -> layer-0 K / V rows carry exactly one projection's
+    rounding, layer-1 rows one decoder layer's; the towers' sampled output rows (26-layer drift excluded: two layers deep).
+Weights and inputs are regenerated from the seeds stored in the golden (0.66 G parameters: ~20 s on the host)."""
+import dataclasses
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+GOLD = os.path.join(HERE, "golden", "reference_realdims.npz")
+
+
+def _setup():
+    import make_golden_realdims as MR
+    from vidi_amd.weights import init_random_weights
+    D = np.load(GOLD)
+    assert int(D["weight_seed"][0]) == MR.WEIGHT_SEED and int(D["input_seed"][0]) == MR.INPUT_SEED
+    cfg = MR.realdims_config()
+    px, mel, ids = MR.make_inputs(cfg)
+    assert torch.equal(ids, torch.from_numpy(D["input_ids"]))          # the generator reproduces what the golden was made with
+    w = init_random_weights(cfg, seed=MR.WEIGHT_SEED, dtype=torch.float32, device="cpu")
+    return D, cfg, px, mel, ids, w
+
+
+def t(D, name):
+    return torch.from_numpy(D[name].astype(np.float32) if D[name].dtype == np.float16 else D[name])
+
+
+def test_oracle_reproduces_the_reference_at_real_dims():
+    """fp32 oracle vs the reference's fp32 execution, stored in fp16: |err| <= 1e-3 of the tensor's spread + one fp16 ulp relative"""
+    import vidi_oracle as O
+    from util import report
+    D, cfg, px, mel, ids, w = _setup()
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    ocfg = O.OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in names}, vis_select_layer=cfg.mm_vision_select_layer)
+    torch.set_num_threads(8)
+    close = lambda name, got, ref: report(name, got, ref, 1e-3 * float(ref.float().std()), 1.5e-3)      # noqa: E731
+    with torch.no_grad():
+        vis = O.siglip_forward(px[0], w, ocfg)
+        close("SigLIP tower rows", vis[:, torch.from_numpy(D["vis_rows"])], t(D, "vis_tower_rows"))
+        aud = O.whisper_encoder_forward(mel[0], w, ocfg)
+        close("Whisper tower rows", aud[:, torch.from_numpy(D["aud_rows"])], t(D, "aud_tower_rows"))
+        toks, dbg = O.generate_greedy(ids, list(px), list(mel), D["audio_sizes"].tolist(), w, ocfg, 1, return_debug=True)
+    assert bool(dbg["image_mask"].all()) and bool(dbg["audio_mask"].all())
+    close("image embeds", dbg["image_embeds"][0], t(D, "image_embeds"))
+    close("audio embeds", dbg["audio_embeds"][0], t(D, "audio_embeds"))
+    for li in range(cfg.num_hidden_layers):
+        for mod, cache, rows in (("img", dbg["caches"].image, D["img_tok"]), ("aud", dbg["caches"].audio, D["aud_tok"])):
+            idx = torch.from_numpy(rows)
+            k, v = cache[li]
+            close(f"{mod} K layer {li}", k[0][idx], t(D, f"{mod}_k_{li}"))                     # [B, N, nkv * hd] (gemma.py:59-65)
+            close(f"{mod} V layer {li}", v[0][idx], t(D, f"{mod}_v_{li}"))
+    close("last hidden", dbg["prefill_hidden"][0], t(D, "prefill_hidden_last"))
+    ref_logits = t(D, "prefill_logits_all")
+    got = O.lm_logits(dbg["prefill_hidden"], w, ocfg)[0]
+    report("logits at every prompt position", got, ref_logits, 2e-4 * float(ref_logits.std()), 2e-4)
+
+
+def _cache_rows(mm, li, keys, nkv, hd):
+    """rows `keys` of layer li's K and V in token-major [n, nkv * hd] form, out of the kernels' tile layouts"""
+    from util import perm_positions
+    kc = mm.kc[li].reshape(nkv, -1, hd)                                      # [nkv, ntile64 * 64, hd]
+    idx = torch.as_tensor(keys, dtype=torch.int64, device=kc.device)
+    k = kc[:, idx].permute(1, 0, 2).reshape(len(keys), nkv * hd)
+    vt = mm.vtc[li]                                                         # [nkv, 2 * ntile64, hd, 32 (perm16)]
+    tile = idx >> 5
+    pos = torch.from_numpy(perm_positions(32)[(np.asarray(keys) & 31)]).to(kc.device)
+    v = vt[:, tile, :, pos]                                                 # [n, nkv, hd]
+    return k.float().cpu(), v.reshape(len(keys), nkv * hd).float().cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_path_vs_reference_execution_at_real_dims(dt):
+    from util import logit_tol, report
+    from vidi_amd.model import VidiForCausalLM
+    D, cfg, px, mel, ids, w = _setup()
+    wt = {k: (v if ".mm_rand_pos_" in k else v.to(dt)) for k, v in w.items()}
+    del w
+    model = VidiForCausalLM(cfg, wt, dtype=dt, device="cuda")
+    eng = model.engine
+    nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+    # activation bound: 3 % of the spread + 2 % relative for bf16, 0.6 % + 0.4 % fp16 (tests/test_gpu_reference_golden.py:tol); one-projection
+    # K / V rows on the reference's own inputs: 1 % + 1.2 % (the per-kernel bound of test_gpu_full_depth.py), 0.2 % + 0.25 % fp16
+    a_act, r_act = (3e-2, 2e-2) if dt == torch.bfloat16 else (6e-3, 4e-3)
+    a_kv, r_kv = (1e-2, 1.2e-2) if dt == torch.bfloat16 else (2e-3, 2.5e-3)
+    sp = lambda x: float(x.float().std())       # noqa: E731
+
+    # ---- towers, two layers deep at d = 72 / N = 729 and d = 64 / N = 1500 ----
+    vis = eng.siglip_forward(px[0].to(dt).cuda())
+    ref = t(D, "vis_tower_rows")
+    report("SigLIP rows (1152 / 16 x 72 / 4304, N = 729)", vis[:, torch.from_numpy(D["vis_rows"]).cuda()], ref, a_act * sp(ref), r_act)
+    aud = eng.whisper_forward(mel[0].to(dt).cuda())
+    ref = t(D, "aud_tower_rows")
+    report("Whisper rows (1280 / 20 x 64 / 5120, N = 1500)", aud[:, torch.from_numpy(D["aud_rows"]).cuda()], ref, a_act * sp(ref), r_act)
+
+    # ---- teacher-forced decoder: the reference's own token embeddings in, K / V rows of both layers out ----
+    img, au = t(D, "image_embeds").to(dt).cuda(), t(D, "audio_embeds").to(dt).cuda()
+    ones = lambda n: torch.ones(n, dtype=torch.uint8, device="cuda")       # noqa: E731
+    mm = eng.mm_stream_prefill(img, ones(img.shape[0]), au, ones(au.shape[0]), pre_normalized=False)
+    for li in range(cfg.num_hidden_layers):
+        for mod, rows, start in (("img", D["img_tok"], 0), ("aud", D["aud_tok"], mm.aud_start)):
+            k, v = _cache_rows(mm, li, (rows + start).tolist(), nkv, hd)
+            # layer 1's rows sit behind layer 0's o_proj + two norm pairs + GeGLU MLP: the activation bound
+            a, r = (a_kv, r_kv) if li == 0 else (a_act, r_act)
+            report(f"teacher-forced {mod} K layer {li} (3584 -> 8 x 256)", k, t(D, f"{mod}_k_{li}"), a * sp(t(D, f"{mod}_k_{li}")), r)
+            report(f"teacher-forced {mod} V layer {li}", v, t(D, f"{mod}_v_{li}"), a * sp(t(D, f"{mod}_v_{li}")), r)
+    del mm
+
+    # ---- free-running: frames / mel / prompt -> logits at every prompt position (the reference's forward, gemma.py:484-601) ----
+    out = model.forward(ids, images=px.to(dt).cuda(), audios=mel.to(dt).cuda(), audio_sizes=D["audio_sizes"].tolist(), logits_to_keep=0)
+    st = out.past_image_key_values
+    ref = t(D, "prefill_logits_all")
+    report("logits at all 39 prompt positions", out.logits[0], ref, logit_tol(dt, ref), 0.0)
+    fi, mi, fa, ma = model.encode_videos(px.to(dt).cuda(), mel.to(dt).cuda(), D["audio_sizes"].tolist())
+    assert bool(mi.all()) and bool(ma.all()) and fi.shape[1] == 392 and fa.shape[1] == 100
+    ref = t(D, "image_embeds")
+    report("video token embeddings (2 x 196 tokens)", fi[0], ref, a_act * sp(ref), r_act)
+    ref = t(D, "audio_embeds")
+    report("audio token embeddings (100 tokens)", fa[0], ref, a_act * sp(ref), r_act)
+    for li in range(cfg.num_hidden_layers):
+        k, v = _cache_rows(st, li, D["img_tok"].tolist(), nkv, hd)
+        report(f"free-running img K layer {li}", k, t(D, f"img_k_{li}"), a_act * sp(t(D, f"img_k_{li}")), r_act)
+        report(f"free-running img V layer {li}", v, t(D, f"img_v_{li}"), a_act * sp(t(D, f"img_v_{li}")), r_act)

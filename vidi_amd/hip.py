@@ -125,6 +125,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
 # optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
 # ---------------------------------------------------------------------------------------------
 TIMER = None      # set to a KernelTimer to time every C-ABI launch
+AFTER_CALL = None  # test hook (tests/conftest.py under VIDI_CANARY=2): callable(name) run after every C-ABI launch — the guard-zone check
 
 
 def _work(name, a):
@@ -213,9 +214,10 @@ class _Timed:
 
     def __call__(self, *a):
         t = TIMER
-        if t is None:
-            return self.fn(*a)
-        return t.run(self.name, a, self.fn)
+        rc = self.fn(*a) if t is None else t.run(self.name, a, self.fn)
+        if AFTER_CALL is not None:
+            AFTER_CALL(self.name)
+        return rc
 
 
 class KernelTimer:

@@ -114,7 +114,10 @@ def process_images_gpu(images, image_processor, model_cfg, dtype=torch.bfloat16,
 # ------------------------------------------------------------------------------------------------
 # video / audio  (vid_utils.py:10-64) — decord + ffmpeg on the host, like the reference
 # ------------------------------------------------------------------------------------------------
-def load_video(file, fps: float = 1.0, time_range=None, num_threads: int = 0):
+def load_video(file, fps: float = 1.0, time_range=None, num_threads: int = 0, clamp_last: bool = True):
+    """Vidi1.5_9B/vidi/dataset/vid_utils.py:10-23: every `round(avg_fps / fps)`-th frame, or `round(seconds * fps)` frames spread evenly over
+    `time_range` (seconds) with the last index clamped to the clip.  `clamp_last=False` is Vidi-7B's variant (Vidi_7B/model/vid_utils.py:7-19:
+    no clamp — a range that ends past the clip makes decord raise, as there)."""
     from decord import VideoReader, cpu
     from PIL import Image
     vr = VideoReader(str(file), ctx=cpu(0), num_threads=num_threads)
@@ -123,10 +126,17 @@ def load_video(file, fps: float = 1.0, time_range=None, num_threads: int = 0):
         idx = list(range(0, len(vr), step))
     else:
         first = round(time_range[0] * vr.get_avg_fps())
-        last = min(round(time_range[1] * vr.get_avg_fps()), len(vr) - 1)
+        last = round(time_range[1] * vr.get_avg_fps())
+        if clamp_last:
+            last = min(last, len(vr) - 1)
         idx = np.linspace(first, last, round((time_range[1] - time_range[0]) * fps), dtype=int)
     frames = vr.get_batch(idx).asnumpy()
     return [Image.fromarray(f).convert("RGB") for f in frames]
+
+
+def load_video_7b(file, fps: float = 1.0, time_range=None, num_threads: int = 0):
+    """Vidi_7B/model/vid_utils.py:7-19 (what `model.vid_utils.load_video` resolves to through vidi_amd/compat_7b)"""
+    return load_video(file, fps, time_range, num_threads, clamp_last=False)
 
 
 def load_audio(file, sample_rate: int = 16000, time_range=None):
@@ -165,6 +175,7 @@ def process_audio_gpu(audio: np.ndarray, audio_processor, dtype=torch.bfloat16, 
 
 
 def get_media_length(file) -> float:
+    """Vidi1.5_9B/vidi/dataset/vid_utils.py:67-80 (ffprobe, container duration in seconds)"""
     from subprocess import run
     cmd = ["ffprobe", "-i", str(file), "-show_entries", "format=duration", "-v", "quiet", "-of", "csv=p=0"]
     return float(run(cmd, capture_output=True, check=True).stdout.strip())
