@@ -15,6 +15,31 @@ tests)
   # under oracle/_ref/) and of vidi_amd/inference.py, both driving the HIP engine
   VIDI_CLI_RECORD=$OUT/reference_cli.jsonl VIDI_TEST_REPORT=$OUT/tol_audit.jsonl timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 --durations=15 > $OUT/pytest.log 2>&1
   echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
+canary)
+  # the WHOLE GPU suite once under the guard-zone device allocator (tests/canary/): every tensor its own hipMalloc with poisoned zones
+  VIDI_CANARY=1 timeout 3000 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider --deselect tests/test_gpu_canary.py::test_kernel_and_model_suites_under_the_guard_zone_allocator > $OUT/canary.log 2>&1
+  echo "canary rc=$?"; tail -5 $OUT/canary.log ;;
+probe)
+  # what the GPU box has of the media decoders BASELINE configs[0] needs (recorded in DESIGN.md section 9)
+  { echo "ffmpeg: $(which ffmpeg 2>&1 || echo absent)"; echo "ffprobe: $(which ffprobe 2>&1 || echo absent)"; python -c "import decord; print('decord', decord.__version__)" 2>&1 | tail -1;
+    python -c "import cv2; print('cv2', cv2.__version__)" 2>&1 | tail -1; python -c "import av; print('av', av.__version__)" 2>&1 | tail -1; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; nproc; } > $OUT/probe_media.txt 2>&1
+  cat $OUT/probe_media.txt ;;
+dist2g)
+  # dist mode gather_tokens (BASELINE configs[3] as worded) next to the sharded stream, two ranks on the one GPU (gloo transport), 10-minute video
+  for m in gather_tokens sharded_stream; do
+    VIDI_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --dist-mode $m --frames 600 --steps 1 --warmup 1 --no-preproc --no-other-configs > $OUT/bench_dist2_$m.json 2> $OUT/bench_dist2_$m.err; echo "dist2 $m rc=$?"
+  done
+  timeout 600 python bench.py --frames 600 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
+  python - <<'PY'
+import json
+for n in ("dist2_gather_tokens", "dist2_sharded_stream", "dist1"):
+    try:
+        d = json.loads([l for l in open(f"gpurun_out/bench_{n}.json") if l.startswith("{")][-1])
+        print(n, "value", round(d["value"]), "dist_mode", d.get("dist_mode"), {k: round(v, 1) for k, v in d["stage_ms_per_step"].items()}, "first_token", d["first_token"], "sha", d.get("first_token_logits_sha256", "")[:12], "verify", d["verify"]["ok"])
+    except Exception as e:
+        print(n, "failed:", e)
+PY
+  ;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $OUT/smoke.log ;;
 bench)
