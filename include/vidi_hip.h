@@ -128,7 +128,7 @@ int vidi_gemm_skinny(const void* X, const void* W, const void* bias, void* Y, vo
 /* The same projections for a BATCH of decode rows (several queries sharing one video, BASELINE configs[4]: 8 rows; their o_proj over the
  * three attention streams: 24 rows) on the matrix pipe — vidi_gemv's FMAs are VALU work that saturates near M = 8.  One pass over W, no
  * workspace, 1 <= M <= 32: Y[M,N] = X W^T;  with glu_act = VIDI_ACT_GELU_TANH / VIDI_ACT_SILU (M <= 16): vidi_gemv_glu's gated pair on the
- * interleaved gate/up weight (N = I features).  glu_act < 0: plain.  vidi_gemv_mfma_fits: 1 when (M, N, K) is taken (N % 16, K % 64),
+ * interleaved gate/up weight (N = I features).  glu_act < 0: plain.  vidi_gemv_mfma_fits: 1 when (M, N, K) is taken (N % 16 — % 32 for the gated pair —, K % 64),
  * otherwise call vidi_gemv / vidi_gemm.  Values: vidi_gemv's up to the fp32 summation order. */
 int vidi_gemv_mfma_fits(int M, int N, int K, int glu);
 int vidi_gemv_mfma(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int glu_act, int dtype,

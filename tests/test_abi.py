@@ -71,11 +71,34 @@ def test_no_oracle_import_in_product():
             assert "vidi_oracle" not in open(os.path.join(pkg, fn)).read(), fn
 
 
-def test_driver_build_entry_runs_end_to_end():
-    """`__graft_entry__.build()` is what the driver calls each round: it must exit cleanly on the current library (round 4 shipped an
-    assertion on a stale ABI literal that nothing exercised) and leave the reference's two CLI scripts staged for tests/test_gpu_cli.py."""
+def test_header_abi_literal_matches_the_library():
+    """the check `__graft_entry__.build()` makes after compiling (round 4 shipped an assertion on a stale ABI literal that nothing exercised)"""
     import __graft_entry__ as GE
-    GE.build()
+    from vidi_amd import hip
+    assert GE.header_abi_version() == hip.load_library().vidi_abi_version()
+
+
+def test_driver_build_entry_runs_end_to_end(tmp_path):
+    """`__graft_entry__.build()` is what the driver calls each round: it must exit cleanly on the current sources and leave the reference's
+    two CLI scripts staged for tests/test_gpu_cli.py.  Run in a CHILD process into a scratch directory (VIDI_BUILD_OUT; the tree's objects are
+    copied there first, so sources that did not change are not recompiled): the library this test session has loaded is never relinked
+    underneath it, and the tree is not touched except for the staged scripts."""
+    import shutil
+    import subprocess
+    import sys
+    out = tmp_path / "build"
+    (out / "obj").mkdir(parents=True)
+    src_obj = os.path.join(ROOT, "vidi_amd", "csrc", "build")
+    if os.path.isdir(src_obj):
+        for fn in os.listdir(src_obj):
+            if fn.endswith((".o", ".sha")):
+                shutil.copy2(os.path.join(src_obj, fn), out / "obj" / fn)
+    env = dict(os.environ, VIDI_BUILD_OUT=str(out), VIDI_HIP_LIB=str(out / "libvidi_hip.so"))
+    env.pop("VIDI_BUILD_FORCE", None)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "build ok:" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert (out / "libvidi_hip.so").exists()
     if os.path.isdir("/root/reference"):
+        import __graft_entry__ as GE
         for arch in GE.REFERENCE_CLI:
             assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "reference_cli", arch, "inference.py")), arch

@@ -183,6 +183,12 @@ def test_asm_matrix_instructions_of_the_many_row_cross_attention_keep_their_dist
             assert not [l for l in loop if "v_accvgpr" in l], f"{m.group(1)}: the main loop copies accumulator registers: {[l.strip() for l in loop if 'v_accvgpr' in l][:3]}"
             assert not [l for l in loop if "scratch_" in l], f"{m.group(1)}: spills inside the main loop"
             assert sum("v_mfma" in l for l in loop) in (32, 16), "QK^T + PV of one sub-tile"
+            # the key-padding mask rides in SGPRs (one s_load per sub-tile, a step ahead): an ordinary global load in the loop makes the compiler
+            # drain the hand-counted K / V DMA ring with `s_waitcnt vmcnt(0)` in front of its use (the form up to round 5, on every product launch)
+            plain_loads = [l.strip() for l in loop if re.search(r"\b(global|buffer|flat)_load_", l) and "lds" not in l]
+            assert not plain_loads, f"{m.group(1)}: ordinary vector loads inside the main loop: {plain_loads[:3]}"
+            assert not [l for l in loop if "vmcnt(0)" in l and "lgkmcnt" not in l] or sum("vmcnt(" in l for l in loop) > 1, "a lone full drain of the DMA ring inside the loop"
+            assert sum("s_load_dwordx8" in l for l in loop) == 1, "one scalar mask load per sub-tile"
         n, _, _, min_reader, worst = H.scan(lines)
         assert n and min_reader >= 10, f"{m.group(1)}: an instruction reads a matrix result {min_reader} instructions behind its MFMA: {worst}"
         found += 1

@@ -462,6 +462,7 @@ def test_gemv_mfma_glu(hip, dt, M, I, K, act):
 def test_gemv_mfma_shapes_it_does_not_take(hip):
     assert not hip.gemv_mfma_fits(33, 4096, 3584) and not hip.gemv_mfma_fits(17, 4096, 3584, True)
     assert not hip.gemv_mfma_fits(8, 4096 + 8, 3584) and not hip.gemv_mfma_fits(8, 4096, 3584 + 32)
+    assert hip.gemv_mfma_fits(8, 4096 + 16, 3584) and not hip.gemv_mfma_fits(8, 14336 + 16, 3584, True)      # the gated pair needs I % 32: fits() is the dispatcher's exact predicate
     x = torch.zeros((8, 96), dtype=torch.bfloat16).cuda(); w = torch.zeros((64, 96), dtype=torch.bfloat16).cuda()
     with pytest.raises(Exception, match="vidi_gemv_mfma"):
         hip.gemv_mfma(x, w)
@@ -646,6 +647,42 @@ def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
     out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
     hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
     report("attn_cross", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
+
+
+@pytest.mark.parametrize("softcap,expect_tiles", [(50.0, 4), (66.0, 4), (67.0, 1), (80.0, 1), (200.0, 1)])
+def test_attn_cross_fixed_reference_is_gated_on_the_cap_value(hip, softcap, expect_tiles):
+    """The many-row kernel's softmax has no running maximum: it is exact only while 2^(+-softcap log2 e) stays inside the number range around its
+    fixed reference, i.e. softcap log2 e <= 96 (softcap <= 66.5; Gemma2: 50).  The dispatcher must test the VALUE (a `softcap > 0` test sent a cap
+    of 80 there, where rows whose logits all sit at the low end underflow to l = 0 and the merge writes zeros).  The inputs PIN rows at both ends:
+    queries 20 x and -20 x a common key direction saturate every logit at +cap / -cap, plus ordinary rows; both kernels must match the oracle."""
+    dt = torch.bfloat16
+    HD, nkv, G, Lq, N, zsplit = 256, 2, 2, 48, 1500, 3            # 96 rows = 3 row tiles
+    nq = nkv * G
+    assert hip.attn_cross_row_tiles_per_block(96, softcap, dt) == expect_tiles
+    g = torch.Generator().manual_seed(77)
+    base = torch.randn(HD, generator=g)
+    base = base / base.norm() * HD ** 0.5
+    k = (base[None, None, :] + 0.1 * torch.randn((N, nkv, HD), generator=g)).to(dt)                   # every key close to one direction
+    v = torch.randn((N, nkv, HD), generator=g).to(dt)
+    q = torch.randn((Lq, nq, HD), generator=g)
+    q[:12] = 20.0 * base            # all logits of these rows at +cap
+    q[12:24] = -20.0 * base         # ... at -cap: the rows a too-large cap underflows
+    q = q.to(dt)
+    mask = torch.ones(N, dtype=torch.bool)
+    mask[::7] = False
+    scale = HD ** -0.5
+    ref = _cross_ref(q, k, v, mask, scale, softcap, G)
+    ntile = (N + 63) // 64
+    kc, vtc = pack_kv_cache(k, v, ntile, 0)
+    R, Rpad = Lq * G, 96
+    opart, ml = hip.attn_cross_workspace(zsplit, nkv, Rpad, HD, "cuda")
+    mpad = torch.zeros(ntile * 64, dtype=torch.uint8); mpad[:N] = mask.to(torch.uint8)
+    hip.attn_cross(dev(q.reshape(Lq, nq * HD).contiguous()), dev(kc), dev(vtc), dev(mpad), opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD,
+                   ntile64=ntile, key_start=0, n_keys=N, scale=scale, softcap=softcap, zsplit=zsplit)
+    out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
+    hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+    assert float(out[12:24].float().abs().max()) > 0, "saturated-low rows came back as zeros (l underflowed)"
+    report(f"attn_cross softcap {softcap}", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
 
 
 def test_attn_cross_split_invariance(hip):

@@ -10,8 +10,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "libvidi_hip.so")
+# VIDI_BUILD_OUT: objects and the library go to that directory instead of the tree (tests/test_abi.py exercises the driver's build entry that way,
+# without relinking the library underneath the handles the test session has open)
+_OUT = os.environ.get("VIDI_BUILD_OUT")
+OBJ = os.path.join(_OUT, "obj") if _OUT else os.path.join(CSRC, "build")
+LIB = os.path.join(_OUT, "libvidi_hip.so") if _OUT else os.path.join(HERE, "libvidi_hip.so")
 SOURCES = ["gemm.hip", "gemv.hip", "gemm_w4_bf16.hip", "gemm_w4_f16.hip", "gemm_w4_modes.hip", "gemm_w4_lnf.hip", "gemm_w4_patch.hip", "gemm_w4n.hip", "gemm_skinny.hip", "gemv_mfma.hip", "attn_self.hip", "attn_self_rm.hip", "attn_cross.hip", "attn_cross_rows.hip", "attn_text.hip", "rowops.hip", "elementwise.hip", "preproc.hip", "probe.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "gemm_w4.h", "gemm_w4n.h", "gemm_w4_launch.h", "gemm_skinny.h", "gemm_skinny_api.h", "gemv_mfma_api.h", "attn_text_decode.h", os.path.join("..", "..", "include", "vidi_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]      # (+ the resource-usage remark, see _compile)

@@ -7,6 +7,8 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+typedef __attribute__((ext_vector_type(8))) unsigned int u32x8;
+
 #ifndef VIDI_XROWS_AHEAD
 #define VIDI_XROWS_AHEAD 3            // sub-tiles in flight ahead of the scores being formed (3: 128 KB of LDS at HD = 256; 4: 160 KB, all of it)
 #endif
@@ -20,7 +22,7 @@
 //     HD = 256) is DMA'd into block-wide rings once — every wave issues a quarter of its 1 KB pieces — and consumed by all four waves, each
 //     with its own register-resident Q fragments, row sums and accumulators; one barrier per sub-tile; K / V traffic per launch drops 4x
 //     (and the row blocks of one kv head run on one XCD and share its L2);
-//   * the softmax has NO running maximum: the tanh softcap bounds every logit, so one fixed reference serves all rows (see XSHIFT below) — no
+//   * the softmax has NO running maximum: the tanh softcap bounds every logit, so one fixed reference serves all rows (see m_ref below) — no
 //     cross-lane maximum, no rescale of the accumulators, and the accumulators are never touched by the VALU inside the loop;
 //   * a three-stage software pipeline inside the wave: QK^T of sub-tile i + 1 and PV of sub-tile i - 1 are on the matrix pipe while the VALU
 //     turns the scores of sub-tile i into probabilities, one matrix instruction per ~32 cycles of lock-stepped VALU work.
@@ -95,19 +97,19 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
-    // Softmax WITHOUT a running maximum.  With the tanh softcap every logit lies in [-cap2, cap2] (cap2 = softcap log2 e = 72.1 for Gemma2's
-    // 50), so one fixed reference  m_ref = cap2 - XSHIFT  serves every row of every launch:  p = 2^(logit - m_ref)  lies in
-    // [2^(XSHIFT - 2 cap2), 2^XSHIFT] = [2^-48, 2^96] — no overflow, no underflow, no rescaling of the accumulators, no cross-lane maximum.
-    // (row sums stay below 10^5 keys x 2^96 = 8e33; the probabilities keep their relative precision when rounded to T — bf16 has fp32's
-    // exponent range, fp16 does not: see the dispatch).  The partial is (numerator, m_ref, l): the merge kernels take any reference.
-    // The dispatcher sends launches without a softcap (Vidi-7B) to the per-tile kernel, which keeps the running maximum.
+    // Softmax WITHOUT a running maximum.  With the tanh softcap every logit (base-2 units) lies in [-cap2, cap2], cap2 = softcap log2 e (72.1 for
+    // Gemma2's 50), so ONE fixed reference serves every row of every launch: m_ref = 0, p = 2^logit in [2^-cap2, 2^cap2] — no overflow, no
+    // underflow, no rescaling of the accumulators, no cross-lane maximum.  The margins are symmetric and the dispatcher admits the kernel only
+    // while they hold (vidi_attn_cross_rtpb: cap2 <= VIDI_XROWS_MAX_CAP2 = 96): a row sum stays below 2^17 keys x 2^96 = 2^113 and a numerator
+    // below that times |v|; the smallest probability, 2^-96, is a normal bf16 / fp32 number (bf16 has fp32's exponent range, fp16 does not:
+    // see the dispatch).  The partial is (numerator, m_ref, l): the merge kernels take any reference.  Launches without a softcap (Vidi-7B),
+    // with a larger one, or in fp16 go to the per-tile kernel, which keeps the running maximum.
     static_assert(T::id == VIDI_DT_BF16, "the fixed-reference softmax needs T's exponent range to be fp32's");
-    constexpr float XSHIFT = 96.0f;
     float l_run = 0.f;
     const float L2E = 1.4426950408889634f;
     const float pre2 = 2.0f * (p.scale / p.softcap) * L2E;        // exp(2 y) = 2^(score * pre2), y = score * scale / cap
     const float capl2 = p.softcap * L2E;
-    const float m_run = capl2 - XSHIFT;                            // the reference every partial of this launch reports
+    const float m_run = 0.f;                                       // the reference every partial of this launch reports
 
     // Software pipeline over the sub-tiles, three stages deep (the wave is alone on its SIMD: whatever overlaps must overlap inside it, and a
     // wave issues in order).  Step i runs, score by score:
@@ -147,6 +149,17 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     if constexpr (AHEAD > 3) { if (n_mine > 3) issue(3); }
     f32x16 s_cur = zero16;
     u32x4 pp0 = {0, 0, 0, 0}, pp1 = {0, 0, 0, 0};                  // P fragments of the previous sub-tile (none yet: the first PV adds 0 x V(0))
+    // A sub-tile's key-padding mask is 32 bytes that are the SAME for every lane: ONE scalar load into SGPRs per sub-tile, issued a whole
+    // step ahead (at the end of step i - 1, behind that step's last LDS wait, so the next lgkmcnt wait — after the barrier and the first
+    // fragment reads of step i — finds it long returned) and read after step i's matrix work.  (As ordinary global loads behind the MFMAs —
+    // the form up to round 5 — the compiler put `s_waitcnt vmcnt(0)` in front of their use: a full drain of the hand-counted K / V DMA
+    // ring once per sub-tile, on every launch of the product, which always passes a mask.  Scalar loads count in lgkmcnt, not vmcnt.)
+    u32x8 mk = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mask_prefetch = [&](int i) __attribute__((always_inline)) {
+        const unsigned char* mp = p.mask + (size_t)(z + i * zsplit) * 32;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(mk) : "s"(mp));
+    };
+    if (p.mask && n_mine > 0) mask_prefetch(0);
     if (n_mine > 0) {
         // (sub-tile 0 has landed; up to AHEAD - 1 younger ones may be in flight)
         if (AHEAD > 3 && n_mine > 3) wait_vmcnt<(AHEAD > 3 ? 3 : 2) * (KPW + VPW)>();
@@ -227,9 +240,9 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
                 x[2] = __builtin_amdgcn_rcpf(x[2]); x[3] = __builtin_amdgcn_rcpf(x[3]);
                 fence();
                 mp(r0 + 2);
-                // logit in base-2 units  cap2 tanh(y) = cap2 - 2 cap2 / (exp(2 y) + 1)  minus the FIXED reference m_ref = cap2 - XSHIFT
+                // logit in base-2 units  cap2 tanh(y) = cap2 - 2 cap2 / (exp(2 y) + 1)  (the FIXED reference is m_ref = 0)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(c2, x[e], XSHIFT);
+                for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(c2, x[e], capl2);
                 pv[r0] = fast_exp2(x[0]);
                 fence();
                 mq(r0 + 3);
@@ -248,10 +261,10 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
                 if (kb_local + krow32(r, hi) >= p.n_keys) pv[r] = 0.f;
         }
         if (p.mask) {
-            const unsigned char* mp = p.mask + kb_local + 4 * hi;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk));        // the scalar load issued a step ago (every ds_read of this step has been consumed by now)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned mv = *(const unsigned*)(mp + 8 * j);
+                const unsigned mv = hi ? mk[2 * j + 1] : mk[2 * j];  // keys 8 j + 4 hi .. + 3 of the sub-tile: register 4 j + e holds key krow32(4 j + e, hi)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (((mv >> (8 * e)) & 0xffu) == 0) pv[4 * j + e] = 0.f;
@@ -265,6 +278,7 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
         pp1 = pack8<T>(pv + 8);
         s_cur = s_next;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every LDS read of this step has returned before the wave can reach the next barrier
+        if (p.mask && more) mask_prefetch(i + 1);
     }
     // PV of the last sub-tile
     if (n_mine > 0) {

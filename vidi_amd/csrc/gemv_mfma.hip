@@ -249,8 +249,10 @@ static inline int gemvm_ks(int groups, int K, int target) {
     return best;
 }
 
+// the EXACT shape predicate of vidi_gemv_mfma_dispatch (callers treat "fits" as "will run": engine.proj / proj_glu pick their kernel with it):
+// the gated pair walks 32-row blocks of the interleaved gate / up weight, so its N (= I) must be a multiple of 32, plain projections of 16
 int vidi_gemvm_fits(int M, int N, int K, int glu) {
-    if (M < 1 || M > (glu ? 16 : 32) || N <= 0 || N % 16 || K <= 0 || K % 64) return 0;
+    if (M < 1 || M > (glu ? 16 : 32) || N <= 0 || N % (glu ? 32 : 16) || K <= 0 || K % 64) return 0;
     return 1;
 }
 
@@ -288,7 +290,7 @@ int vidi_gemv_mfma_dispatch(const void* X, const void* W, void* Y, int M, int N,
                             hipStream_t st) {
     const bool glu = glu_act >= 0;
     if (!vidi_gemvm_fits(M, N, K, glu) || ldw % 8 || ldx % 8) return VIDI_ERR_SHAPE;
-    if (glu && (N % 32 || (glu_act != ACT_GELU_TANH && glu_act != ACT_SILU))) return VIDI_ERR_ARG;
+    if (glu && glu_act != ACT_GELU_TANH && glu_act != ACT_SILU) return VIDI_ERR_ARG;
     if (((uintptr_t)W & 15) || ((uintptr_t)X & 15)) return VIDI_ERR_ALIGN;
     GemvmParams p{(const u16*)X, (const u16*)W, (u16*)Y, M, N, K, ldx, ldw, ldy, glu_act == ACT_SILU};
     if (dtype == VIDI_DT_BF16) return launch_gemvm<BF16>(p, glu, st);

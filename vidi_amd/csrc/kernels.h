@@ -128,6 +128,7 @@ int vidi_w4_patch(const GemmParams& p, int dtype, hipStream_t st);            //
 int vidi_w4_window(const GemmParams& p, int dtype, hipStream_t st);           // gemm_w4_patch.hip
 int vidi_attn_self_dispatch(const AttnSelfParams& p, int D, int dtype, hipStream_t st);
 int vidi_attn_self_rm_dispatch(const AttnSelfRmParams& p, int D, int dtype, hipStream_t st);
+#define VIDI_XROWS_MAX_CAP2 96.0f      // largest softcap x log2(e) the fixed-reference softmax of attn_cross_rows.hip is exact for (see there)
 int vidi_attn_cross_rtpb(int Rpad, float softcap, int dtype);     // row tiles a block of the cross-attention launch covers (1 or 4)
 int vidi_attn_cross_dispatch(const AttnCrossParams& p, int HD, int zsplit, int dtype, hipStream_t st);
 int vidi_attn_cross2_dispatch(const AttnCrossParams& a, const AttnCrossParams& b, int HD, int za, int zb, int dtype, hipStream_t st);

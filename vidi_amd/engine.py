@@ -312,7 +312,7 @@ class VidiEngine:
         """bias-free projection: weight-streaming GEMV for M <= 8 (decode), the split-K weight-streaming MFMA kernel for a prompt's
         9..128 rows (VIDI_SKINNY_GEMM=0: the tile GEMM, the A/B arm), the tile / persistent MFMA GEMM otherwise."""
         M = x.shape[0]
-        if self.gemv_mfma_rows and self.gemv_mfma_rows <= M <= 32 and hip.gemv_mfma_fits(M, w.shape[0], x.shape[1]):
+        if self.gemv_mfma_rows and self.gemv_mfma_rows <= M <= 32 and hip.gemv_mfma_fits(M, w.shape[0], x.shape[1], False, x, w):
             return hip.gemv_mfma(x, w, out)
         if M <= 8:
             return hip.gemv(x, w, out)
@@ -328,7 +328,7 @@ class VidiEngine:
     def proj_glu(self, x: torch.Tensor, wgu: torch.Tensor, out: torch.Tensor, act: int) -> torch.Tensor:
         """gated-MLP front half of a few decode rows (M <= 8): the matrix-pipe kernel from `gemv_mfma_rows` rows on, else the VALU GEMV"""
         M = x.shape[0]
-        if self.gemv_mfma_rows and M >= self.gemv_mfma_rows and hip.gemv_mfma_fits(M, wgu.shape[0] // 2, x.shape[1], True):
+        if self.gemv_mfma_rows and M >= self.gemv_mfma_rows and hip.gemv_mfma_fits(M, wgu.shape[0] // 2, x.shape[1], True, x, wgu):
             return hip.gemv_mfma(x, wgu, out, glu_act=act)
         return hip.gemv_glu(x, wgu, out, act)
 

@@ -456,8 +456,15 @@ def attn_cross_row_tiles_per_block(Rpad: int, softcap: Optional[float], dtype: t
     return int(load_library().vidi_attn_cross_row_tiles_per_block(int(Rpad), float(softcap or 0.0), DT_BF16 if dtype == torch.bfloat16 else DT_F16))
 
 
-def gemv_mfma_fits(M: int, N: int, K: int, glu: bool = False) -> bool:
-    return bool(load_library().vidi_gemv_mfma_fits(int(M), int(N), int(K), int(glu)))
+def gemv_mfma_fits(M: int, N: int, K: int, glu: bool = False, x: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None) -> bool:
+    """True iff vidi_gemv_mfma WILL take the call: the library's shape predicate and — when the operands are given — the leading-dimension
+    (multiples of 8 elements) and 16-byte base-alignment rules its dispatcher enforces (engine.proj falls back to gemv / gemm_skinny otherwise)"""
+    if not bool(load_library().vidi_gemv_mfma_fits(int(M), int(N), int(K), int(glu))):
+        return False
+    for t in (x, w):
+        if t is not None and (t.stride(0) % 8 or t.data_ptr() % 16 or t.stride(-1) != 1):
+            return False
+    return True
 
 
 def gemv_mfma(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, glu_act: int = -1) -> torch.Tensor:

@@ -393,9 +393,9 @@ class VidiForCausalLM:
                              f"(got {n_ret}).")                                    # HF's own rule
         if num_beams > 1 and kwargs.get("streamer") is not None:
             raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")   # HF's own rule
-        # the row-by-row paths below call generate() again per row with kwargs whose lengths are ALREADY resolved against the batch's padded
-        # prompt (HF resolves them once, against `inputs_embeds.shape[1]` of the whole batch): the nested call must not subtract again
-        resolved = bool(kwargs.pop("_lengths_resolved", False))
+        # HF resolves the generation lengths ONCE, against the whole batch's padded prompt (`inputs_embeds.shape[1]`); the row-by-row paths of
+        # `_generate_resolved` recurse into it (not into this function) with the resolved values, so nothing is subtracted twice and no caller-visible
+        # keyword can switch the resolution off
         max_new = kwargs.get("max_new_tokens", None)
         if max_new is None:
             # HF's `_prepare_generated_length` under `inputs_embeds` (how the reference drives it, gemma.py:646-655): `max_length` (default
@@ -406,12 +406,19 @@ class VidiForCausalLM:
             if max_new <= 0:
                 raise ValueError(f"Input length of input_ids is {n_prompt}, but `max_length` is set to {max_length}. This can lead to "
                                  "unexpected behavior. You should consider increasing `max_length` or, better yet, setting `max_new_tokens`.")
-            kwargs = dict(kwargs, max_new_tokens=int(max_new))               # the row-by-row paths below pass it on
-        max_new = int(max_new)
-        if kwargs.get("min_length") and not resolved:
+        kwargs = dict(kwargs, max_new_tokens=int(max_new))
+        if kwargs.get("min_length"):
             # `min_length` counts the embedded prompt too (HF's `_prepare_generated_length` under `inputs_embeds`): what is left applies to the new tokens
             n_prompt = int(strip_image_token(inputs, kwargs.get("attention_mask", None))[0].shape[1])
-            kwargs = dict(kwargs, min_length=max(int(kwargs["min_length"]) - n_prompt, 0))
+            kwargs["min_length"] = max(int(kwargs["min_length"]) - n_prompt, 0)
+        return self._generate_resolved(inputs, images, audios, audio_sizes, mm_state, kwargs)
+
+    def _generate_resolved(self, inputs, images, audios, audio_sizes, mm_state, kwargs):
+        """generate() behind its argument checks, with `max_new_tokens` / `min_length` already counted in NEW tokens (resolved once per call)"""
+        do_sample = bool(kwargs.get("do_sample", False))
+        num_beams = int(kwargs.get("num_beams", None) or 1)
+        n_ret = int(kwargs.get("num_return_sequences", None) or 1)
+        max_new = int(kwargs["max_new_tokens"])
         kwargs = dict(kwargs)
         eos = kwargs.get("eos_token_id", self.generation_config.eos_token_id)
         eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]) if e is not None]     # HF allows a list ([1, 107] for Gemma2)
@@ -437,14 +444,14 @@ class VidiForCausalLM:
             budget = self._batch_frames(images)
             rows = []
             for i in range(B):
-                kw = dict(kwargs, _lengths_resolved=True)
+                kw = dict(kwargs)
                 kw["attention_mask"] = None
                 am_i = None if attention_mask is None else attention_mask[i].bool().cpu()
                 ids_i = inputs[i].cpu() if am_i is None else inputs[i].cpu()[am_i]
                 mm_i = self.encode_mm_state(self._row(images, i), self._row(audios, i), None if audio_sizes is None else [audio_sizes[i]],
                                             vis_features=None if vis is None else vis[i], aud_features=None if aud is None else aud[i],
                                             budget_frames=budget)
-                rows.append(self.generate(ids_i[None], mm_state=mm_i, **kw))
+                rows.append(self._generate_resolved(ids_i[None], None, None, None, mm_i, kw))
                 del mm_i
             return self._stack_rows(rows, pad, kwargs)
         if mm_state is None and (images is not None or audios is not None):
@@ -454,9 +461,9 @@ class VidiForCausalLM:
             # on the tokenizer's side): rows never interact, so every row is decoded unpadded against the shared video state
             rows = []
             for i in range(inputs.shape[0]):
-                kw = dict(kwargs, _lengths_resolved=True)
+                kw = dict(kwargs)
                 kw["attention_mask"] = None
-                rows.append(self.generate(inputs[i].cpu()[attention_mask[i].bool().cpu()][None], mm_state=mm_state, **kw))
+                rows.append(self._generate_resolved(inputs[i].cpu()[attention_mask[i].bool().cpu()][None], None, None, None, mm_state, kw))
             return self._stack_rows(rows, pad, kwargs)
         ids, mask, pos = strip_image_token(inputs, attention_mask)
         if num_beams > 1:
