@@ -93,7 +93,7 @@ def test_fifty_concurrent_runs_on_two_streams_are_bit_identical(dt):
     torch.cuda.synchronize()
     assert len(results) == 50
     first = {k: v.cpu() for k, v in results[0].items()}
-    assert len(first) >= 18
+    assert len(first) >= 16, sorted(first)
     bad = {}
     for i, r in enumerate(results[1:], 1):
         for k, v in r.items():
