@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-preproc", action="store_true", help="skip the extra (untimed-in-`value`) GPU preprocessing leg")
     ap.add_argument("--src-hw", type=int, nargs=2, default=[480, 854], help="decoded frame size fed to the preprocessing leg")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of sampled frames / K/V-cache rows after the timed region")
+    ap.add_argument("--no-other-dtype", action="store_true", help="skip the (untimed-in-`value`) leg that runs the headline workload once in the other 16-bit dtype")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the (untimed-in-`value`) legs that run BASELINE configs[1] and configs[4] on this GPU "
                     "after the headline workload (default workload, one GPU only)")
     ap.add_argument("--attn-gain", type=float, default=ATTN_GAIN, help="factor on the decoder's random q_proj weights (a power of two is exact in "
@@ -700,10 +701,19 @@ def main():
         del mm, ts
         torch.cuda.empty_cache()
 
-        def run_config(T2, fps2, queries2, ragged2, ndec):
+        def run_config(T2, fps2, queries2, ragged2, ndec, eng=eng, model=model, pixel=pixel, mel=mel):
             secs2 = T2 / fps2
             Cw2, asz2 = math.ceil(secs2 / 30), int(round(secs2 * 100))
             px2, mel2 = pixel[:T2], mel[:Cw2]
+
+            def decode_eager(ts, mm, nxt, n):
+                for _ in range(n):
+                    emb = eng.embed_tokens(nxt)
+                    posn = ts.n_valid.clone(); ts.n_valid += 1
+                    hn = eng.text_forward(emb, posn, ts, mm, Lq=1)
+                    _, nxt = eng.logits_argmax(hn)
+                    int(nxt[0])
+                return nxt
             pl2 = [a.prompt_len] * queries2 if ragged2 is None else [ragged2[0] + round(i * (ragged2[1] - ragged2[0]) / max(1, queries2 - 1)) for i in range(queries2)]
             g2 = torch.Generator().manual_seed(2)
             ids2 = torch.randint(1000, min(200000, cfg.vocab_size), (queries2, max(pl2) + 1), generator=g2)
@@ -754,6 +764,21 @@ def main():
                      "note": "same run, same box, after the timed headline steps; one warm-up + one timed prefill each; never part of `value`"}
         except Exception as e:          # never lose the headline line to an extra leg
             other = {"error": repr(e)}
+        # the headline workload once more in the OTHER 16-bit dtype (the reference's inference dtype is fp16: builder.py:41, eval/inference.py:23;
+        # BASELINE quotes bf16): a second engine with the same seed's weights, one warm-up + one timed prefill + the decode steps
+        if other is not None and "error" not in other and not a.no_other_dtype:
+            try:
+                odt_name = "fp16" if a.dtype == "bf16" else "bf16"
+                odt = torch.float16 if odt_name == "fp16" else torch.bfloat16
+                model2 = VidiForCausalLM(cfg, init_random_weights(cfg, seed=3, dtype=odt, device=dev), dtype=odt, device=dev)
+                rec = run_config(T, a.fps, a.queries, a.ragged_prompts, a.decode_steps, eng=model2.engine, model=model2, pixel=pixel.to(odt), mel=mel.to(odt))
+                rec["dtype"] = odt_name
+                rec["relative_to_headline_dtype"] = rec["video_tokens_per_s"] / value
+                other[f"configs[2] headline workload in {odt_name} (one timed prefill)"] = rec
+                del model2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                other[f"headline workload in the other dtype"] = {"error": repr(e)}
 
     # ---- box-speed reference (untimed): frozen probe kernels, so that records from different boxes can be normalised ----
     box = None

@@ -69,6 +69,10 @@ def test_hot_kernels_do_not_spill(report):
         # section (8-40 v_writelane per tile switch) and the 128-MFMA K-loop bodies read back 0-7 of them per iteration (0 in the plain
         # epilogue instantiations) — i.e. < 1 % of a K = 1152 tile.  The ceiling keeps that from growing unnoticed; other kernels: none.
         limit = 72 if "gemm_w4_kernel" in name else (8 if ("gemm_kernel" in name or "attn_cross2_kernel" in name) else 0)    # (cross2: two parameter blocks)
+        if "attn_cross_rows_kernel" in name and not name.endswith("ELi0EEv15AttnCrossParamsS1_i"):
+            # the running-reference forms (MODE 1 / 2) park up to 9 scalars in VGPR lanes around their COLD re-reference path; the main loops
+            # hold none (test_asm_matrix_instructions_... reads that back from the ISA).  The fixed-reference form (MODE 0, the BASELINE dtype): 0.
+            limit = 12
         assert res.get("SGPRs Spill", 0) <= limit, (name, res.get("SGPRs Spill"), limit)
     assert checked > 0
 
@@ -182,6 +186,7 @@ def test_asm_matrix_instructions_of_the_many_row_cross_attention_keep_their_dist
             loop = [l for l in lines[h: ends[-1] + 1] if l.strip() and not l.strip().startswith(";")]
             assert not [l for l in loop if "v_accvgpr" in l], f"{m.group(1)}: the main loop copies accumulator registers: {[l.strip() for l in loop if 'v_accvgpr' in l][:3]}"
             assert not [l for l in loop if "scratch_" in l], f"{m.group(1)}: spills inside the main loop"
+            assert not [l for l in loop if "v_readlane" in l or "v_writelane" in l], f"{m.group(1)}: scalar spills (VGPR lanes) inside the main loop"
             assert sum("v_mfma" in l for l in loop) in (32, 16), "QK^T + PV of one sub-tile"
             # the key-padding mask rides in SGPRs (one s_load per sub-tile, a step ahead): an ordinary global load in the loop makes the compiler
             # drain the hand-counted K / V DMA ring with `s_waitcnt vmcnt(0)` in front of its use (the form up to round 5, on every product launch)
@@ -192,4 +197,4 @@ def test_asm_matrix_instructions_of_the_many_row_cross_attention_keep_their_dist
         n, _, _, min_reader, worst = H.scan(lines)
         assert n and min_reader >= 10, f"{m.group(1)}: an instruction reads a matrix result {min_reader} instructions behind its MFMA: {worst}"
         found += 1
-    assert found == 2, "bf16 kernels of both head dims"
+    assert found == 10, "both head dims x (bf16: fixed reference, running reference with / without a cap; fp16: running reference with / without a cap)"

@@ -649,27 +649,30 @@ def test_attn_cross(hip, dt, HD, nkv, G, Lq, N, start, softcap, masked, zsplit):
     report("attn_cross", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
 
 
-@pytest.mark.parametrize("softcap,expect_tiles", [(50.0, 4), (66.0, 4), (67.0, 1), (80.0, 1), (200.0, 1)])
-def test_attn_cross_fixed_reference_is_gated_on_the_cap_value(hip, softcap, expect_tiles):
-    """The many-row kernel's softmax has no running maximum: it is exact only while 2^(+-softcap log2 e) stays inside the number range around its
-    fixed reference, i.e. softcap log2 e <= 96 (softcap <= 66.5; Gemma2: 50).  The dispatcher must test the VALUE (a `softcap > 0` test sent a cap
-    of 80 there, where rows whose logits all sit at the low end underflow to l = 0 and the merge writes zeros).  The inputs PIN rows at both ends:
-    queries 20 x and -20 x a common key direction saturate every logit at +cap / -cap, plus ordinary rows; both kernels must match the oracle."""
-    dt = torch.bfloat16
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("softcap", [50.0, 66.0, 67.0, 80.0, 200.0, None])
+def test_attn_cross_many_rows_softmax_forms_and_saturated_rows(hip, dt, softcap):
+    """The many-row kernel has a softmax WITHOUT a running maximum (bf16 + a cap with softcap log2 e <= 96, i.e. <= 66.5: Gemma2's 50) and
+    forms with a per-row running reference (fp16; larger caps; no cap).  The launcher must pick by the cap's VALUE: round 5 tested
+    `softcap > 0`, and a cap of 80 in the fixed form underflows rows whose logits all sit at the low end to l = 0 (zeros out of the merge).
+    The inputs PIN rows at both ends — queries 20 x and -20 x a common key direction saturate every logit at +cap / -cap — next to ordinary
+    rows; a third of the keys is masked, the first 70 keys entirely (a slice that starts with nothing to reference)."""
     HD, nkv, G, Lq, N, zsplit = 256, 2, 2, 48, 1500, 3            # 96 rows = 3 row tiles
     nq = nkv * G
-    assert hip.attn_cross_row_tiles_per_block(96, softcap, dt) == expect_tiles
+    assert hip.attn_cross_row_tiles_per_block(96, softcap, dt) == 4
     g = torch.Generator().manual_seed(77)
     base = torch.randn(HD, generator=g)
     base = base / base.norm() * HD ** 0.5
     k = (base[None, None, :] + 0.1 * torch.randn((N, nkv, HD), generator=g)).to(dt)                   # every key close to one direction
     v = torch.randn((N, nkv, HD), generator=g).to(dt)
     q = torch.randn((Lq, nq, HD), generator=g)
-    q[:12] = 20.0 * base            # all logits of these rows at +cap
-    q[12:24] = -20.0 * base         # ... at -cap: the rows a too-large cap underflows
+    amp = 20.0 if softcap else 0.05                                 # (without a cap the logits are unbounded: keep exp() finite in the reference too)
+    q[:12] = amp * base             # all logits of these rows at +cap
+    q[12:24] = -amp * base          # ... at -cap: the rows a too-large cap underflows in the fixed form
     q = q.to(dt)
     mask = torch.ones(N, dtype=torch.bool)
-    mask[::7] = False
+    mask[::3] = False
+    mask[:70] = False
     scale = HD ** -0.5
     ref = _cross_ref(q, k, v, mask, scale, softcap, G)
     ntile = (N + 63) // 64
@@ -683,6 +686,45 @@ def test_attn_cross_fixed_reference_is_gated_on_the_cap_value(hip, softcap, expe
     hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
     assert float(out[12:24].float().abs().max()) > 0, "saturated-low rows came back as zeros (l underflowed)"
     report(f"attn_cross softcap {softcap}", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("softcap", [50.0, None])
+def test_attn_cross_running_reference_climbs(hip, dt, softcap):
+    """the running-reference forms re-reference a row whenever its maximum outgrows what the dtype can hold against the old reference: here
+    every row's logits CLIMB along the key axis (keys = ramp x direction, queries along it), over ~100 (capped) / ~60 (uncapped) binades from
+    the first sub-tile to the last, so a wave takes the cold path many times per slice; rows 0-15 climb, rows 16-31 fall (never re-referenced
+    after the first step: their early keys dominate and the late ones vanish), the rest are ordinary.  One slice and four, hd 128 and 256."""
+    for HD, zsplit in ((256, 1), (128, 4)):
+        nkv, G, Lq, N = 2, 2, 40, 2048
+        nq = nkv * G
+        g = torch.Generator().manual_seed(78)
+        base = torch.randn(HD, generator=g)
+        base = base / base.norm()
+        ramp = torch.linspace(-1.0, 1.0, N)[:, None, None]
+        k = (ramp * base[None, None, :] * HD ** 0.5 + 0.05 * torch.randn((N, nkv, HD), generator=g)).to(dt)
+        v = torch.randn((N, nkv, HD), generator=g).to(dt)
+        q = 0.3 * torch.randn((Lq, nq, HD), generator=g)
+        amp = (3.0 if softcap else 40.0) * HD ** 0.5                       # logits ~ +-amp' along the ramp (capped: tanh saturates both ends)
+        q[:16] += amp * base / HD ** 0.5 * (HD ** 0.5)
+        q[16:32] -= amp * base / HD ** 0.5 * (HD ** 0.5)
+        q = q.to(dt)
+        mask = torch.ones(N, dtype=torch.bool)
+        mask[5::11] = False
+        scale = HD ** -0.5
+        ref = _cross_ref(q, k, v, mask, scale, softcap, G)
+        ntile = N // 64
+        kc, vtc = pack_kv_cache(k, v, ntile, 0)
+        R = Lq * G
+        Rpad = (R + 31) // 32 * 32
+        opart, ml = hip.attn_cross_workspace(zsplit, nkv, Rpad, HD, "cuda")
+        mpad = mask.to(torch.uint8)
+        hip.attn_cross(dev(q.reshape(Lq, nq * HD).contiguous()), dev(kc), dev(vtc), dev(mpad), opart, ml, R=R, Rpad=Rpad, G=G, nkv=nkv, HD=HD,
+                       ntile64=ntile, key_start=0, n_keys=N, scale=scale, softcap=softcap, zsplit=zsplit)
+        out = torch.zeros((Lq, nq * HD), dtype=dt).cuda()
+        hip.attn_merge(opart, ml, out, W=zsplit, nkv=nkv, R=R, Rpad=Rpad, G=G, HD=HD)
+        assert bool(torch.isfinite(out.float()).all())
+        report(f"attn_cross climbing reference HD {HD} softcap {softcap}", out, ref, *tol(dt, max(0.05, ref.std().item()), k=2))
 
 
 def test_attn_cross_split_invariance(hip):

@@ -331,6 +331,49 @@ def test_batched_queries_share_one_video(tiny_setup):
     assert toks.shape == (len(prompts), 4)
 
 
+def test_ragged_batch_runs_on_the_valid_positions_only(tiny_setup, monkeypatch):
+    """K2 varlen (xattn.py:36-103 `_unpad_xattn_input` + flash_attn_varlen_func): a right-padded batch of 8 prompts runs every text-side
+    kernel on its 50 valid positions, not on the 8 x 10 = 80 padded ones (VIDI_TEXT_VARLEN=1, the default) — same logits at the valid
+    positions as the padded arm (VIDI_TEXT_VARLEN=0; both arms are held to single-prompt runs in test_batched_queries_share_one_video),
+    zeros at the pad positions, the same text K/V cache rows and the same greedy tokens."""
+    cfg, eng, w32, dt = tiny_setup
+    from vidi_amd.model import VidiForCausalLM, strip_image_token
+    from types import SimpleNamespace
+    monkeypatch.setenv("VIDI_TEXT_VARLEN", "0")
+    eng0, _ = make(cfg, dt)
+    assert eng.text_varlen and not eng0.text_varlen
+    px = seeded((3, 3, cfg.vis_image_size, cfg.vis_image_size), 126, 0.5).clamp(-1, 1).to(dt)
+    mel = seeded((1, cfg.aud_num_mel_bins, cfg.aud_nb_max_frames), 127, 0.3).to(dt)
+    prompts = [[2, 21, 22, 23, -200, 24, 25, 26], [2, 31, -200, 32], [2, 41, 42, -200, 43, 44, 45, 46, 47, 48, 49],
+               [2, -200, 51], [2, 61, 62, 63, 64, -200, 65], [2, 71, -200, 72, 73, 74], [2, 81, 82, -200, 83], [2, 91, -200, 92, 93]]
+    L = max(len(p) for p in prompts)
+    ids = torch.zeros((len(prompts), L), dtype=torch.int64)
+    am = torch.zeros((len(prompts), L), dtype=torch.int64)
+    for i, p in enumerate(prompts):
+        ids[i, : len(p)] = torch.tensor(p); am[i, : len(p)] = 1
+    outs = []
+    for e in (eng, eng0):
+        model = VidiForCausalLM.__new__(VidiForCausalLM)
+        model.config, model.dtype, model.device, model.engine = cfg, dt, torch.device("cuda"), e
+        model.generation_config = SimpleNamespace(eos_token_id=-12345, pad_token_id=0)
+        model.model = None
+        mm = model.encode_mm_state(px[None].cuda(), mel[None].cuda(), [100])
+        o = model.forward(ids, attention_mask=am, mm_state=mm)
+        toks = model.generate(ids, attention_mask=am, mm_state=mm, max_new_tokens=4, do_sample=False).cpu()
+        ts = o.past_key_values
+        outs.append((o.logits.float().cpu(), ts.kc.float().cpu(), ts.vc.float().cpu(), toks))
+    _, mask, _ = strip_image_token(ids, am)
+    (la, ka, va, ta), (lb, kb, vb, tb) = outs
+    assert int(mask.sum()) == sum(len(p) - 1 for p in prompts) < mask.numel()
+    at, rt = tol(dt, lb[mask].std().item(), tight=True)
+    report("varlen vs padded: logits at the valid positions", la[mask], lb[mask], at, rt)
+    assert float(la[~mask].abs().max()) == 0.0                                   # pad positions: never computed
+    km = mask[None, :, :, None].expand(ka.shape[0], -1, -1, ka.shape[-1])
+    report("varlen vs padded: text K cache rows", ka[:, :, : mask.shape[1]][km], kb[:, :, : mask.shape[1]][km], *tol(dt, 1.0, tight=True))
+    report("varlen vs padded: text V cache rows", va[:, :, : mask.shape[1]][km], vb[:, :, : mask.shape[1]][km], *tol(dt, 1.0, tight=True))
+    assert torch.equal(ta[:, :1], tb[:, :1]), (ta.tolist(), tb.tolist())
+
+
 def test_real_dims_two_layers():
     """Gemma2-9B layer dims (H=3584, 16/8 heads x 256, I=14336), 2 layers, tiny towers: mm stream + text"""
     from vidi_amd.config import tiny

@@ -459,12 +459,10 @@ int vidi_attn_merge2_dispatch(const AttnMergeParams& a, const AttnMergeParams& b
 // (VIDI_XATTN_ROWS=0: never, the A/B arm), else 1.  Callers size the key split with it (blocks = nkv x ceil(row tiles / this) x slices).
 int vidi_attn_cross_rtpb(int Rpad, float softcap, int dtype) {
     static const int on = [] { const char* e = getenv("VIDI_XATTN_ROWS"); return (e && atoi(e) == 0) ? 0 : 1; }();
-    // the shared-stream kernel's softmax has no running maximum: it needs the tanh softcap's bound on the logits — and a bound SMALL enough
-    // that p = 2^logit neither overflows nor underflows around the fixed reference 0: softcap x log2(e) <= 96, i.e. softcap <= 66.5 (Gemma2:
-    // 50) — and bf16's exponent range.  Anything else (no softcap: Vidi-7B; a config.json with a larger cap; fp16) keeps the per-tile
-    // kernel with its running maximum: a VALUE test, not a sign test (a cap of 80 would underflow low rows to l = 0 in the fixed form).
-    const bool bounded = softcap > 0.f && softcap * 1.4426950408889634f <= VIDI_XROWS_MAX_CAP2;
-    return (on && Rpad > 32 && bounded && dtype == VIDI_DT_BF16) ? 4 : 1;
+    // every dtype / softcap has a form of the shared-stream kernel (attn_cross_rows.hip: the fixed-reference softmax for bf16 with a cap whose
+    // VALUE admits it — softcap x log2(e) <= VIDI_XROWS_MAX_CAP2, not merely softcap > 0 —, a running reference otherwise)
+    (void)softcap;
+    return (on && Rpad > 32 && (dtype == VIDI_DT_BF16 || dtype == VIDI_DT_F16)) ? 4 : 1;
 }
 
 int vidi_attn_cross_rows_launch(const AttnCrossParams& a, const AttnCrossParams& b, int za, int zb, int HD, int dtype, hipStream_t st);      // attn_cross_rows.hip

@@ -29,7 +29,19 @@ typedef __attribute__((ext_vector_type(8))) unsigned int u32x8;
 // A wave writes the partial (numerator, reference, sum) of its row tile itself — the partial layout and the merge kernels of attn_cross.hip.
 // Values: the one-row-tile kernel's up to the softmax's reference (a power-of-two-free shift of the exponent: the probabilities differ in
 // their last bits) and the tanh's division (v_rcp here, IEEE there).
-template <typename T, int HD>
+//
+// Two softmax forms (MODE):
+//   XR_FIXED    bf16 + a softcap with softcap log2 e <= 96 (Gemma2 in bf16, the BASELINE dtype): no running maximum at all (see m_ref below);
+//   XR_RUN_CAP  fp16 + softcap (the reference's inference dtype), or a cap too large for the fixed form;
+//   XR_RUN      no softcap (Vidi-7B), both dtypes.
+// The running forms keep a per-row reference that only ever moves UP, and rarely: a step forms its probabilities against the reference of
+// the steps before it; only when one of them leaves the range T can hold (fp16: 2^14; bf16: 2^100) does the wave take a cold path that
+// re-references the row — the accumulators (AGPRs) are scaled through VGPRs there, the row sum with them, and the step's probabilities
+// are formed again.  The first step of a slice always takes it (the reference starts at "nothing seen"), afterwards a row takes it once per
+// ~8+ binades its maximum climbs: a handful of times per slice at worst.  The hot path is the fixed form's plus a 16-way maximum.
+enum { XR_FIXED = 0, XR_RUN_CAP = 1, XR_RUN = 2 };
+
+template <typename T, int HD, int MODE>
 __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, const int z, const int zsplit) {
     constexpr int QROW = HD * 2;
     constexpr int CPR = HD / 8;
@@ -104,12 +116,18 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
     // below that times |v|; the smallest probability, 2^-96, is a normal bf16 / fp32 number (bf16 has fp32's exponent range, fp16 does not:
     // see the dispatch).  The partial is (numerator, m_ref, l): the merge kernels take any reference.  Launches without a softcap (Vidi-7B),
     // with a larger one, or in fp16 go to the per-tile kernel, which keeps the running maximum.
-    static_assert(T::id == VIDI_DT_BF16, "the fixed-reference softmax needs T's exponent range to be fp32's");
+    static_assert(MODE != XR_FIXED || T::id == VIDI_DT_BF16, "the fixed-reference softmax needs T's exponent range to be fp32's");
+    constexpr bool CAP = MODE != XR_RUN;
     float l_run = 0.f;
     const float L2E = 1.4426950408889634f;
-    const float pre2 = 2.0f * (p.scale / p.softcap) * L2E;        // exp(2 y) = 2^(score * pre2), y = score * scale / cap
-    const float capl2 = p.softcap * L2E;
-    const float m_run = 0.f;                                       // the reference every partial of this launch reports
+    const float pre2 = CAP ? 2.0f * (p.scale / p.softcap) * L2E : p.scale * L2E;   // CAP: exp(2 y) = 2^(score * pre2), y = score * scale / cap; else: logit = score * pre2
+    const float capl2 = CAP ? p.softcap * L2E : 0.f;
+    // running forms: the row's reference (the same in both half-waves of a row); "nothing seen yet" is a large finite negative number, so
+    // that differences of references never form inf - inf
+    constexpr float NOREF = -1.0e30f;
+    constexpr float P_LIMIT = T::id == VIDI_DT_F16 ? 16384.0f : 1.2676506e30f;    // largest probability a step may hand to T (2^14; 2^100)
+    constexpr float HEADROOM = 6.0f;                                               // a re-referenced row's maximum sits at 2^6
+    float m_run = MODE == XR_FIXED ? 0.f : NOREF;                                  // the reference this wave's partial reports
 
     // Software pipeline over the sub-tiles, three stages deep (the wave is alone on its SIMD: whatever overlaps must overlap inside it, and a
     // wave issues in order).  Step i runs, score by score:
@@ -214,42 +232,69 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
             auto mp = [&](int r) __attribute__((always_inline)) { if (r < 2 * DT) T::mfma32_cA(o[r % DT], vf[(r / 4) & 1][r % 4], r < DT ? pp0 : pp1); };
             auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
             const float c2 = -2.0f * capl2;
+            const float sh = capl2 - m_run;                        // (fixed form: capl2)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r0 = 4 * g;
                 if (r0 + 4 < KST) load_k(g + 1);
                 if (r0 + 4 < 2 * DT) load_v(g + 1);
                 float x[4];
-                mq(r0);
+                if constexpr (CAP) {
+                    mq(r0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = s[r0 + e] * pre2;
-                x[0] = fast_exp2(x[0]);
-                fence();
-                mp(r0);
-                x[1] = fast_exp2(x[1]); x[2] = fast_exp2(x[2]);
-                fence();
-                mq(r0 + 1);
-                x[3] = fast_exp2(x[3]);
+                    for (int e = 0; e < 4; ++e) x[e] = s[r0 + e] * pre2;
+                    x[0] = fast_exp2(x[0]);
+                    fence();
+                    mp(r0);
+                    x[1] = fast_exp2(x[1]); x[2] = fast_exp2(x[2]);
+                    fence();
+                    mq(r0 + 1);
+                    x[3] = fast_exp2(x[3]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = x[e] + 1.0f;
-                fence();
-                mp(r0 + 1);
-                x[0] = __builtin_amdgcn_rcpf(x[0]); x[1] = __builtin_amdgcn_rcpf(x[1]);
-                fence();
-                mq(r0 + 2);
-                x[2] = __builtin_amdgcn_rcpf(x[2]); x[3] = __builtin_amdgcn_rcpf(x[3]);
-                fence();
-                mp(r0 + 2);
-                // logit in base-2 units  cap2 tanh(y) = cap2 - 2 cap2 / (exp(2 y) + 1)  (the FIXED reference is m_ref = 0)
+                    for (int e = 0; e < 4; ++e) x[e] = x[e] + 1.0f;
+                    fence();
+                    mp(r0 + 1);
+                    x[0] = __builtin_amdgcn_rcpf(x[0]); x[1] = __builtin_amdgcn_rcpf(x[1]);
+                    fence();
+                    mq(r0 + 2);
+                    x[2] = __builtin_amdgcn_rcpf(x[2]); x[3] = __builtin_amdgcn_rcpf(x[3]);
+                    fence();
+                    mp(r0 + 2);
+                    // logit in base-2 units  cap2 tanh(y) = cap2 - 2 cap2 / (exp(2 y) + 1)  minus the reference (fixed form: 0)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(c2, x[e], capl2);
-                pv[r0] = fast_exp2(x[0]);
-                fence();
-                mq(r0 + 3);
-                pv[r0 + 1] = fast_exp2(x[1]); pv[r0 + 2] = fast_exp2(x[2]);
-                fence();
-                mp(r0 + 3);
-                pv[r0 + 3] = fast_exp2(x[3]);
+                    for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(c2, x[e], sh);
+                    pv[r0] = fast_exp2(x[0]);
+                    fence();
+                    mq(r0 + 3);
+                    pv[r0 + 1] = fast_exp2(x[1]); pv[r0 + 2] = fast_exp2(x[2]);
+                    fence();
+                    mp(r0 + 3);
+                    pv[r0 + 3] = fast_exp2(x[3]);
+                } else {
+                    // no softcap: logit = score * scale * log2 e — one FMA and one exponential per score; the eight matrix instructions keep
+                    // their alternating order, each in front of a quarter of the group's VALU work
+                    mq(r0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(s[r0 + e], pre2, -m_run);
+                    fence();
+                    mp(r0);
+                    pv[r0] = fast_exp2(x[0]);
+                    fence();
+                    mq(r0 + 1);
+                    fence();
+                    mp(r0 + 1);
+                    pv[r0 + 1] = fast_exp2(x[1]);
+                    fence();
+                    mq(r0 + 2);
+                    fence();
+                    mp(r0 + 2);
+                    pv[r0 + 2] = fast_exp2(x[2]);
+                    fence();
+                    mq(r0 + 3);
+                    fence();
+                    mp(r0 + 3);
+                    pv[r0 + 3] = fast_exp2(x[3]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(pv[r0 + e]));       // (pure arithmetic: LLVM would sink it to its first user)
                 fence();
@@ -268,6 +313,53 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (((mv >> (8 * e)) & 0xffu) == 0) pv[4 * j + e] = 0.f;
+            }
+        }
+        if constexpr (MODE != XR_FIXED) {
+            // did a probability of this step leave T's range against the reference of the steps before?  (first step: every one did)
+            float pmax = pv[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) pmax = fmaxf(pmax, pv[r]);
+            const bool need_half = !(pmax <= P_LIMIT);                          // (also true for NaN / inf)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(need_half) != 0, 0)) {
+                // ---- cold path: re-reference the rows that need it ----
+                // the row's largest VALID score of this sub-tile (masked / beyond-the-end keys do not count), over both half-waves
+                float smax = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    bool ok = kb_local + krow32(r, hi) < p.n_keys;
+                    if (p.mask) ok = ok && (((hi ? mk[2 * (r >> 2) + 1] : mk[2 * (r >> 2)]) >> (8 * (r & 3))) & 0xffu) != 0;
+                    smax = ok ? fmaxf(smax, s[r]) : smax;
+                }
+                smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+                const bool need = __shfl_xor((int)need_half, 32, 64) != 0 || need_half;
+                float tmax = smax * pre2;                                       // its logit in base-2 units
+                if constexpr (CAP) tmax = capl2 - 2.0f * capl2 / (exp2f(tmax) + 1.0f);
+                // (a row whose keys are all masked in this sub-tile has nothing to re-reference: its probabilities are zeros)
+                const float new_ref = (need && smax > -1.0e38f) ? tmax - HEADROOM : m_run;
+                const float f = exp2f(m_run - new_ref);                         // <= 1 up to rounding; 0 from "nothing seen"
+                m_run = new_ref;
+                l_run *= f;
+                // the accumulators: PV(i - 1) was issued in this step's slots; its results must have landed before anything reads them
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[dt]));
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) asm volatile("s_nop 1" : "+a"(o[dt]));
+                // this step's probabilities against the new reference
+                const float sh2 = capl2 - m_run;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = s[r] * pre2;
+                    if constexpr (CAP) t = __builtin_fmaf(-2.0f * capl2, __builtin_amdgcn_rcpf(fast_exp2(t) + 1.0f), sh2);
+                    else t = t - m_run;
+                    bool ok = kb_local + krow32(r, hi) < p.n_keys;
+                    if (p.mask) ok = ok && (((hi ? mk[2 * (r >> 2) + 1] : mk[2 * (r >> 2)]) >> (8 * (r & 3))) & 0xffu) != 0;
+                    pv[r] = ok ? fast_exp2(t) : 0.f;
+                }
             }
         }
         float psum = 0.f;
@@ -315,19 +407,24 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
 }
 
 // one or two modalities' key regions in one launch (b.n_keys <= 0: only a); the first `za` z-slices sweep set a's keys
-template <typename T, int HD>
+template <typename T, int HD, int MODE>
 __global__ __launch_bounds__(256) void attn_cross_rows_kernel(AttnCrossParams a, AttnCrossParams b, int za) {
     const int bz = blockIdx.z;
-    if (bz < za) attn_cross_rows_body<T, HD>(a, bz, za);
-    else attn_cross_rows_body<T, HD>(b, bz - za, (int)gridDim.z - za);
+    if (bz < za) attn_cross_rows_body<T, HD, MODE>(a, bz, za);
+    else attn_cross_rows_body<T, HD, MODE>(b, bz - za, (int)gridDim.z - za);
 }
 
 int vidi_attn_cross_rows_launch(const AttnCrossParams& a, const AttnCrossParams& b, int za, int zb, int HD, int dtype, hipStream_t st) {
     const dim3 grid(a.nkv, (a.Rpad / 32 + 3) / 4, za + zb);
     const int lds = VIDI_XROWS_AHEAD * (32 * HD * 2) + (VIDI_XROWS_AHEAD + 2) * (HD * 64);          // K ring of AHEAD sub-tiles, V ring of AHEAD + 2
-#define LAUNCH(TT, HH)                                                                        \
+    if (((uintptr_t)a.mask & 3) || (zb > 0 && ((uintptr_t)b.mask & 3))) return VIDI_ERR_ALIGN;       // the mask is read by scalar dword loads
+    const bool cap = a.softcap > 0.f;
+    if (zb > 0 && (b.softcap > 0.f) != cap) return VIDI_ERR_ARG;
+    const bool fixed = cap && a.softcap * 1.4426950408889634f <= VIDI_XROWS_MAX_CAP2 && dtype == VIDI_DT_BF16 && (zb <= 0 || b.softcap == a.softcap);
+    const int mode = fixed ? XR_FIXED : (cap ? XR_RUN_CAP : XR_RUN);
+#define LAUNCH(TT, HH, MM)                                                                    \
     do {                                                                                      \
-        auto kern = attn_cross_rows_kernel<TT, HH>;                                           \
+        auto kern = attn_cross_rows_kernel<TT, HH, MM>;                                       \
         static bool done = false;                                                             \
         if (!done) {                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
@@ -336,9 +433,16 @@ int vidi_attn_cross_rows_launch(const AttnCrossParams& a, const AttnCrossParams&
         }                                                                                     \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, b, za);                         \
     } while (0)
-    if (dtype == VIDI_DT_BF16) { if (HD == 256) LAUNCH(BF16, 256); else LAUNCH(BF16, 128); }
-    else return VIDI_ERR_DTYPE;
+#define LAUNCH_HD(TT, MM) do { if (HD == 256) LAUNCH(TT, 256, MM); else LAUNCH(TT, 128, MM); } while (0)
+    if (dtype == VIDI_DT_BF16) {
+        if (mode == XR_FIXED) LAUNCH_HD(BF16, XR_FIXED);
+        else if (mode == XR_RUN_CAP) LAUNCH_HD(BF16, XR_RUN_CAP);
+        else LAUNCH_HD(BF16, XR_RUN);
+    } else if (dtype == VIDI_DT_F16) {
+        if (mode == XR_RUN_CAP) LAUNCH_HD(F16, XR_RUN_CAP);
+        else LAUNCH_HD(F16, XR_RUN);
+    } else return VIDI_ERR_DTYPE;
+#undef LAUNCH_HD
 #undef LAUNCH
     return (int)hipGetLastError();
 }
-

@@ -116,6 +116,10 @@ class VidiEngine:
         self.stream_norm2 = os.environ.get("VIDI_STREAM_NORM2", "1") != "0"
         # decode step: rope + cache append + T2T as one launch (VIDI_DECODE_ATTN=0: rope_cache + attn_text), T2V + T2A partial passes as
         # one launch (VIDI_CROSS_DUAL=0: one launch per modality) — the A/B arms of tools/ab_decode.py
+        # ragged batch of prompts (right- / left-padded + attention mask): the text stream runs on the VALID positions only — a row map as the
+        # reference's `_unpad_xattn_input` builds (xattn.py:36-103) carried through every projection, norm and the cross-attention; only the
+        # T2T attention sees the padded [B, Lq] frame (VIDI_TEXT_VARLEN=0: every kernel computes the pad positions too, the A/B arm)
+        self.text_varlen = os.environ.get("VIDI_TEXT_VARLEN", "1") != "0"
         self.skinny_gemm = os.environ.get("VIDI_SKINNY_GEMM", "1") != "0"      # prompts of 9..128 rows: csrc/gemm_skinny.h instead of the tile GEMM
         self.decode_attn = os.environ.get("VIDI_DECODE_ATTN", "1") != "0"
         self.cross_dual = os.environ.get("VIDI_CROSS_DUAL", "1") != "0"
@@ -907,6 +911,24 @@ class VidiEngine:
         has_img = mm is not None and mm.g_img > 0
         has_aud = mm is not None and mm.g_aud > 0
         nstream = 1 + int(has_img) + int(has_aud)
+        # ---- varlen: drop the pad positions of a ragged batch (flash_attn_varlen_func's view of the batch, xattn.py:36-103, 123) ----
+        # Every text-side kernel but the T2T attention is row-wise (or, the cross-attention, row-wise on the query side): they run on the
+        # packed valid rows.  The T2T launch keeps the [B, Lq] frame: q | k | v rows are scattered into a zeroed padded buffer in front of it
+        # and its output rows gathered back (two small copies per layer).  8 prompts of 24..52 tokens: 304 rows instead of 416.
+        Mp, rows_map = M, None
+        prt = self.probe if (self.probe is not None and "text_h" in self.probe) else None
+        if self.text_varlen and new_mask is not None and Lq > 1 and B > 1 and not dyn and prt is None:
+            valid = new_mask.reshape(-1).to(torch.bool)
+            rows_map = torch.nonzero(valid).squeeze(1)               # one host sync per ragged PREFILL (the reference syncs per layer: xattn.py:214-215)
+            if 0 < rows_map.numel() < M:
+                M = int(rows_map.numel())
+                hidden = hidden.index_select(0, rows_map)
+                cos_pad, sin_pad = cos, sin
+                cos, sin = cos.index_select(0, rows_map), sin.index_select(0, rows_map)
+                qkv_pad = self._buf("t_qkv_pad", (Mp, nqd + 2 * kvd), zero=True)          # pad rows: zeros for good (only valid rows are ever copied in)
+                att_pad = self._buf("t_att_pad", (Mp, nqd))
+            else:
+                rows_map = None
         hn = self._buf("t_h", (M, H))
         qkv = self._buf("t_qkv", (M, nqd + 2 * kvd))
         qr = self._buf("t_qr", (M, nqd))
@@ -924,7 +946,6 @@ class VidiEngine:
         qkv_ready = False
         nL = len(self.layers)
         final_out = None
-        prt = self.probe if (self.probe is not None and "text_h" in self.probe) else None
         for li, L in enumerate(self.layers):
             if prt is not None:
                 prt["text_h"].append(hidden.clone())
@@ -966,6 +987,13 @@ class VidiEngine:
                                pos_dev=ts.pos_dev)
                 hip.attn_text_dyn(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=1, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
                                   past_len_dev=ts.pos_dev, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
+            elif rows_map is not None:
+                qkv_pad.index_copy_(0, rows_map, qkv)                                               # packed rows -> their [B, Lq] slots
+                qr_pad = self._buf("t_qr_pad", (Mp, nqd))
+                hip.rope_cache(qkv_pad, qr_pad, ts.kc[li], ts.vc[li], cos_pad, sin_pad, B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd, pos0=p0)
+                hip.attn_text(qr_pad, ts.kc[li], ts.vc[li], ts.kmask, att_pad, B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
+                              past_len=p0, window=window, scale=sc, softcap=cfg.attn_logit_softcapping)
+                torch.index_select(att_pad, 0, rows_map, out=att[:M])
             else:
                 hip.rope_cache(qkv, qr, ts.kc[li], ts.vc[li], cos, sin, B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd, pos0=p0)
                 hip.attn_text(qr, ts.kc[li], ts.vc[li], ts.kmask, att[:M], B=B, Lq=Lq, Lmax=ts.Lmax, nq=nq, nkv=nkv, HD=hd,
@@ -1053,9 +1081,13 @@ class VidiEngine:
             ts.past_len = p0 + Lq
         if prt is not None:
             prt["text_h"].append(hidden.clone())                    # the residual stream after the last layer (before the final norm)
-        if final_out is not None:
-            return final_out
-        return hip.norm(self.norm_mode, hidden, self.final_norm, eps=eps)                               # gemma.py:411 / mistral.py:423
+        if final_out is None:
+            final_out = hip.norm(self.norm_mode, hidden, self.final_norm, eps=eps)                      # gemma.py:411 / mistral.py:423
+        if rows_map is not None:                                    # back into the caller's [B * Lq, H] frame (pad rows: zeros)
+            full = torch.zeros((Mp, H), dtype=final_out.dtype, device=self.dev)
+            full.index_copy_(0, rows_map, final_out)
+            return full
+        return final_out
 
     # ---- graph-captured greedy decode -------------------------------------------------
     def decode_step_dyn(self, ids: torch.Tensor, ts: TextState, mm: Optional[MMState]) -> torch.Tensor:
