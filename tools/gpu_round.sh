@@ -19,6 +19,21 @@ canary)
   # the WHOLE GPU suite once under the guard-zone device allocator (tests/canary/): every tensor its own hipMalloc with poisoned zones
   VIDI_CANARY=1 timeout 3000 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider --deselect tests/test_gpu_canary.py::test_kernel_and_model_suites_under_the_guard_zone_allocator > $OUT/canary.log 2>&1
   echo "canary rc=$?"; tail -5 $OUT/canary.log ;;
+xattn)
+  # many-row cross-attention micro-benchmark: the single prompt (39 tokens) and the 8-prompt batch (304 tokens), masked (the product's form whenever a
+  # key is invalid) and unmasked, bf16 fixed reference / fp16 + uncapped running reference, against the per-tile kernel (VIDI_XATTN_ROWS=0)
+  : > $OUT/ab_xattn.jsonl
+  for lq in 39 304; do for cfg in "bf16 50" "fp16 50" "bf16 0" "bf16 80"; do set -- $cfg; for m in 0 1; do for rows in 1 0; do
+    zs=$([ $lq -eq 39 ] && echo 10 || echo 6)
+    VIDI_XATTN_ROWS=$rows PYTHONPATH=. timeout 300 python tools/bench_xattn.py --keys 90000 --lq $lq --zsplit $zs --dtype $1 --softcap $2 --masked $m --iters 20 | sed "s/^{/{\"rows_kernel\": $rows, /" >> $OUT/ab_xattn.jsonl
+  done; done; done; done
+  echo "xattn rc=$?"; python - <<'PY'
+import json
+for l in open("gpurun_out/ab_xattn.jsonl"):
+    d = json.loads(l)
+    print("Lq", d["Lq"], d["dtype"], "cap", d["softcap"], "masked", int(d["masked"]), "rows_kernel", d["rows_kernel"], "tiles/block", d["row_tiles_per_block"], "ms %.3f" % d["ms"], "TFLOP/s %.0f" % d["TFLOPs"], "GB/s %.0f" % d["GBps"])
+PY
+  ;;
 probe)
   # what the GPU box has of the media decoders BASELINE configs[0] needs (recorded in DESIGN.md section 9)
   { echo "ffmpeg: $(which ffmpeg 2>&1 || echo absent)"; echo "ffprobe: $(which ffprobe 2>&1 || echo absent)"; python -c "import decord; print('decord', decord.__version__)" 2>&1 | tail -1;
