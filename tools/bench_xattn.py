@@ -38,6 +38,9 @@ def main():
     R = a.lq * G
     Rpad = (R + 31) // 32 * 32
     for zs in a.zsplit:
+        if zs == 0:          # the engine's rule (VidiEngine._cross_local): fill the 256 CUs with (kv head) x (row block) x (key slice) blocks
+            row_blocks = -(-(Rpad // 32) // hip.attn_cross_row_tiles_per_block(Rpad, cap, dt))
+            zs = max(1, min(256 // max(1, nkv * row_blocks), ((Nk + 31) // 32 + 7) // 8))
         opart, ml = hip.attn_cross_workspace(zs, nkv, Rpad, HD, "cuda")
         o = torch.empty((a.lq, nkv * G * HD), dtype=dt, device="cuda")
 

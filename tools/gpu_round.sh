@@ -24,14 +24,13 @@ xattn)
   # key is invalid) and unmasked, bf16 fixed reference / fp16 + uncapped running reference, against the per-tile kernel (VIDI_XATTN_ROWS=0)
   : > $OUT/ab_xattn.jsonl
   for lq in 39 304; do for cfg in "bf16 50" "fp16 50" "bf16 0" "bf16 80"; do set -- $cfg; for m in 0 1; do for rows in 1 0; do
-    zs=$([ $lq -eq 39 ] && echo 10 || echo 6)
-    VIDI_XATTN_ROWS=$rows PYTHONPATH=. timeout 300 python tools/bench_xattn.py --keys 90000 --lq $lq --zsplit $zs --dtype $1 --softcap $2 --masked $m --iters 20 | sed "s/^{/{\"rows_kernel\": $rows, /" >> $OUT/ab_xattn.jsonl
+    VIDI_XATTN_ROWS=$rows PYTHONPATH=. timeout 300 python tools/bench_xattn.py --keys 90000 --lq $lq --zsplit 0 --dtype $1 --softcap $2 --masked $m --iters 20 | sed "s/^{/{\"rows_kernel\": $rows, /" >> $OUT/ab_xattn.jsonl
   done; done; done; done
   echo "xattn rc=$?"; python - <<'PY'
 import json
 for l in open("gpurun_out/ab_xattn.jsonl"):
     d = json.loads(l)
-    print("Lq", d["Lq"], d["dtype"], "cap", d["softcap"], "masked", int(d["masked"]), "rows_kernel", d["rows_kernel"], "tiles/block", d["row_tiles_per_block"], "ms %.3f" % d["ms"], "TFLOP/s %.0f" % d["TFLOPs"], "GB/s %.0f" % d["GBps"])
+    print("Lq", d["Lq"], d["dtype"], "cap", d["softcap"], "masked", int(d["masked"]), "rows_kernel", d["rows_kernel"], "tiles/block", d["row_tiles_per_block"], "zsplit", d["zsplit"], "ms %.3f" % d["ms"], "TFLOP/s %.0f" % d["TFLOPs"], "GB/s %.0f" % d["GBps"])
 PY
   ;;
 probe)

@@ -305,14 +305,20 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
             for (int r = 0; r < 16; ++r)
                 if (kb_local + krow32(r, hi) >= p.n_keys) pv[r] = 0.f;
         }
+        bool mask_live = false;                                      // this sub-tile holds an invalid key (uniform)
         if (p.mask) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk));        // the scalar load issued a step ago (every ds_read of this step has been consumed by now)
+            // a sub-tile whose 32 keys are all valid — every one but the few around padding / blank frames — costs eight scalar compares
+            mask_live = (mk[0] & mk[1] & mk[2] & mk[3] & mk[4] & mk[5] & mk[6] & mk[7]) != 0x01010101u ||
+                        (mk[0] | mk[1] | mk[2] | mk[3] | mk[4] | mk[5] | mk[6] | mk[7]) != 0x01010101u;
+            if (mask_live) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned mv = hi ? mk[2 * j + 1] : mk[2 * j];  // keys 8 j + 4 hi .. + 3 of the sub-tile: register 4 j + e holds key krow32(4 j + e, hi)
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned mv = hi ? mk[2 * j + 1] : mk[2 * j];  // keys 8 j + 4 hi .. + 3 of the sub-tile: register 4 j + e holds key krow32(4 j + e, hi)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (((mv >> (8 * e)) & 0xffu) == 0) pv[4 * j + e] = 0.f;
+                    for (int e = 0; e < 4; ++e)
+                        if (((mv >> (8 * e)) & 0xffu) == 0) pv[4 * j + e] = 0.f;
+                }
             }
         }
         if constexpr (MODE != XR_FIXED) {
@@ -328,7 +334,7 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     bool ok = kb_local + krow32(r, hi) < p.n_keys;
-                    if (p.mask) ok = ok && (((hi ? mk[2 * (r >> 2) + 1] : mk[2 * (r >> 2)]) >> (8 * (r & 3))) & 0xffu) != 0;
+                    if (mask_live) ok = ok && (((hi ? mk[2 * (r >> 2) + 1] : mk[2 * (r >> 2)]) >> (8 * (r & 3))) & 0xffu) != 0;
                     smax = ok ? fmaxf(smax, s[r]) : smax;
                 }
                 smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
@@ -357,7 +363,7 @@ __device__ __forceinline__ void attn_cross_rows_body(const AttnCrossParams& p, c
                     if constexpr (CAP) t = __builtin_fmaf(-2.0f * capl2, __builtin_amdgcn_rcpf(fast_exp2(t) + 1.0f), sh2);
                     else t = t - m_run;
                     bool ok = kb_local + krow32(r, hi) < p.n_keys;
-                    if (p.mask) ok = ok && (((hi ? mk[2 * (r >> 2) + 1] : mk[2 * (r >> 2)]) >> (8 * (r & 3))) & 0xffu) != 0;
+                    if (mask_live) ok = ok && (((hi ? mk[2 * (r >> 2) + 1] : mk[2 * (r >> 2)]) >> (8 * (r & 3))) & 0xffu) != 0;
                     pv[r] = ok ? fast_exp2(t) : 0.f;
                 }
             }
