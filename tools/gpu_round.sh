@@ -132,6 +132,8 @@ PY
   ;;
 clock)
   bash tools/lab/run_clock.sh 2>&1 | tail -70 ;;
+towerbound)
+  bash tools/lab/run_tower_bound.sh 2>&1 | tail -90 ;;
 dist8)
   # eight ranks sharing the one GPU (gloo transport): the BASELINE 8-way partition of bench.py end to end on a 10-minute video, and the same video on one rank
   VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --frames 600 --steps 1 --warmup 1 --no-preproc --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8.json 2> $OUT/bench_dist8.err; echo "dist8 rc=$?"
