@@ -62,7 +62,7 @@ bench20)
   # the driver's command shape
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; echo "bench20 rc=$?"; python tools/show_bench.py $OUT/bench20.json 2>/dev/null | head -40 ;;
 prof)
-  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r5 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify --no-other-configs > $OUT/prof_bench.json 2> $OUT/prof.err)
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r6 -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-preproc --no-verify --no-other-configs > $OUT/prof_bench.json 2> $OUT/prof.err)
   echo "prof rc=$?"; find $OUT/prof -name '*kernel_stats.csv' | head -3
   # keep the summary, drop the per-dispatch trace (tens of MB)
   find $OUT/prof -name '*kernel_trace.csv' -delete; find $OUT/prof -name '*.db' -delete ;;
