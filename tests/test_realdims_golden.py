@@ -85,8 +85,15 @@ def _cache_rows(mm, li, keys, nkv, hd):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_hip_path_vs_reference_execution_at_real_dims(dt):
-    from util import logit_tol, report
+    from util import logit_tol, report as _report
     from vidi_amd.model import VidiForCausalLM
+    failures = []
+
+    def report(name, got, ref, atol, rtol):          # every check runs; the failures are raised together at the end
+        try:
+            _report(name, got, ref, atol, rtol)
+        except AssertionError as e:
+            failures.append(str(e))
     D, cfg, px, mel, ids, w = _setup()
     wt = {k: (v if ".mm_rand_pos_" in k else v.to(dt)) for k, v in w.items()}
     del w
@@ -144,7 +151,12 @@ def test_hip_path_vs_reference_execution_at_real_dims(dt):
     report("video token embeddings (2 x 196 tokens)", fi[0], ref, a_emb * sp(ref), r_act)
     ref = t(D, "audio_embeds")
     report("audio token embeddings (100 tokens)", fa[0], ref, a_emb * sp(ref), r_act)
+    # free-running K / V rows: behind two tower layers, the pool, the projector, the norms and (layer 1) a whole decoder layer, all in the
+    # model dtype: the bound of "activations after several layers" (tests/test_gpu_model.py:tol) — 5 % + 3 % (bf16), 1 % + 0.6 % (fp16);
+    # measured 3.7 % of the spread at layer 1 (7 of 172 032 values beyond 3 %)
+    a_fr, r_fr = (5e-2, 3e-2) if dt == torch.bfloat16 else (1e-2, 6e-3)
     for li in range(cfg.num_hidden_layers):
         k, v = _cache_rows(st, li, D["img_tok"].tolist(), nkv, hd)
-        report(f"free-running img K layer {li}", k, t(D, f"img_k_{li}"), a_act * sp(t(D, f"img_k_{li}")), r_act)
-        report(f"free-running img V layer {li}", v, t(D, f"img_v_{li}"), a_act * sp(t(D, f"img_v_{li}")), r_act)
+        report(f"free-running img K layer {li}", k, t(D, f"img_k_{li}"), a_fr * sp(t(D, f"img_k_{li}")), r_fr)
+        report(f"free-running img V layer {li}", v, t(D, f"img_v_{li}"), a_fr * sp(t(D, f"img_v_{li}")), r_fr)
+    assert not failures, "\n".join(failures)
