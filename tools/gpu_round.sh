@@ -38,6 +38,22 @@ probe)
   { echo "ffmpeg: $(which ffmpeg 2>&1 || echo absent)"; echo "ffprobe: $(which ffprobe 2>&1 || echo absent)"; python -c "import decord; print('decord', decord.__version__)" 2>&1 | tail -1;
     python -c "import cv2; print('cv2', cv2.__version__)" 2>&1 | tail -1; python -c "import av; print('av', av.__version__)" 2>&1 | tail -1; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; nproc; } > $OUT/probe_media.txt 2>&1
   cat $OUT/probe_media.txt ;;
+dist8g)
+  # EIGHT ranks sharing the one GPU (gloo transport): BASELINE's 8-way partition through bench.py end to end in both dist modes, 10-minute video
+  for m in gather_tokens sharded_stream; do
+    VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode $m --frames 600 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_$m.json 2> $OUT/bench_dist8_$m.err; echo "dist8 $m rc=$?"
+  done
+  timeout 600 python bench.py --frames 600 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_ref1.json 2> $OUT/bench_dist8_ref1.err; echo "dist8 ref rc=$?"
+  python - <<'PY'
+import json
+for n in ("dist8_gather_tokens", "dist8_sharded_stream", "dist8_ref1"):
+    try:
+        d = json.loads([l for l in open(f"gpurun_out/bench_{n}.json") if l.startswith("{")][-1])
+        print(n, "n_gpus", d["n_gpus"], "value", round(d["value"]), "dist_mode", d.get("dist_mode"), {k: round(v, 1) for k, v in d["stage_ms_per_step"].items()}, "first_token", d["first_token"], "sha", d.get("first_token_logits_sha256", "")[:12], "verify", d["verify"]["ok"], d["verify"]["kv_rows"], d["verify"]["frames_checked"])
+    except Exception as e:
+        print(n, "failed:", e)
+PY
+  ;;
 dist2g)
   # dist mode gather_tokens (BASELINE configs[3] as worded) next to the sharded stream, two ranks on the one GPU (gloo transport), 10-minute video
   for m in gather_tokens sharded_stream; do
