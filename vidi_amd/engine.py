@@ -340,6 +340,8 @@ class VidiEngine:
         """int32[1] device flag "the sample holds any non-zero value" (`torch.sum(torch.abs(x)) != 0`, multimodal.py:202, 246) of a
         WHOLE sample; the sharded encode passes it in because a rank only sees its own frames / windows."""
         flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if x.numel() == 0:                          # an empty shard (more ranks than frames / windows) holds no non-zero value
+            return flag
         if x.is_cuda:
             hip.any_nonzero(x.to(self.dtype).contiguous().view(-1), flag)
         elif bool((x != 0).any()):                  # host tensor (the CLI hands over CPU frames): a host reduction, no full-video upload
