@@ -39,11 +39,11 @@ probe)
     python -c "import cv2; print('cv2', cv2.__version__)" 2>&1 | tail -1; python -c "import av; print('av', av.__version__)" 2>&1 | tail -1; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; nproc; } > $OUT/probe_media.txt 2>&1
   cat $OUT/probe_media.txt ;;
 dist8g)
-  # EIGHT ranks sharing the one GPU (gloo transport): BASELINE's 8-way partition through bench.py end to end in both dist modes; 96 frames (12 per rank; 4 audio windows: four ranks without audio) — every rank of the gather mode holds the FULL K/V, eight of them share 288 GB here
+  # EIGHT ranks sharing the one GPU (gloo transport): BASELINE's 8-way partition through bench.py end to end in both dist modes; 48 frames (6 per rank; 2 audio windows: six ranks without audio) — every rank of the gather mode holds the FULL K/V, eight of them share 288 GB here
   for m in gather_tokens sharded_stream; do
-    VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode $m --frames 96 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_$m.json 2> $OUT/bench_dist8_$m.err; echo "dist8 $m rc=$?"
+    VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode $m --frames 48 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_$m.json 2> $OUT/bench_dist8_$m.err; echo "dist8 $m rc=$?"
   done
-  timeout 600 python bench.py --frames 96 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_ref1.json 2> $OUT/bench_dist8_ref1.err; echo "dist8 ref rc=$?"
+  timeout 600 python bench.py --frames 48 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_ref1.json 2> $OUT/bench_dist8_ref1.err; echo "dist8 ref rc=$?"
   python - <<'PY'
 import json
 for n in ("dist8_gather_tokens", "dist8_sharded_stream", "dist8_ref1"):
