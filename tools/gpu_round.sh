@@ -44,12 +44,18 @@ dist8g)
     VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode $m --frames 48 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_$m.json 2> $OUT/bench_dist8_$m.err; echo "dist8 $m rc=$?"
   done
   timeout 600 python bench.py --frames 48 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_ref1.json 2> $OUT/bench_dist8_ref1.err; echo "dist8 ref rc=$?"
+  # the gather mode's bit-identity with one rank holds when a rank's shard takes the SAME GEMM kernels as the whole video (vidi_gemm picks the 128 x 128
+  # tile kernel below 192 tiles of 256 x 256, i.e. below 14 frames per rank for the N = 1 152 tower GEMMs; another MFMA shape sums in another order):
+  # 112 frames = 14 per rank (no verify leg: eight full K/V copies + their probed twins do not fit one GPU)
+  VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode gather_tokens --frames 112 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --no-verify --decode-steps 4 > $OUT/bench_dist8_gather_tokens_112.json 2> $OUT/bench_dist8_gather_tokens_112.err; echo "dist8 gather 112 rc=$?"
+  timeout 600 python bench.py --frames 112 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --no-verify --decode-steps 4 > $OUT/bench_dist8_ref1_112.json 2> $OUT/bench_dist8_ref1_112.err; echo "dist8 ref 112 rc=$?"
   python - <<'PY'
 import json
-for n in ("dist8_gather_tokens", "dist8_sharded_stream", "dist8_ref1"):
+for n in ("dist8_gather_tokens", "dist8_sharded_stream", "dist8_ref1", "dist8_gather_tokens_112", "dist8_ref1_112"):
     try:
         d = json.loads([l for l in open(f"gpurun_out/bench_{n}.json") if l.startswith("{")][-1])
-        print(n, "n_gpus", d["n_gpus"], "value", round(d["value"]), "dist_mode", d.get("dist_mode"), {k: round(v, 1) for k, v in d["stage_ms_per_step"].items()}, "first_token", d["first_token"], "sha", d.get("first_token_logits_sha256", "")[:12], "verify", d["verify"]["ok"], d["verify"]["kv_rows"], d["verify"]["frames_checked"])
+        v = d.get("verify") or {}
+        print(n, "n_gpus", d["n_gpus"], "frames", d["config"]["frames"], "value", round(d["value"]), "dist_mode", d.get("dist_mode"), {k: round(x, 1) for k, x in d["stage_ms_per_step"].items()}, "first_token", d["first_token"], "sha", d.get("first_token_logits_sha256", "")[:12], "verify", v.get("ok"), v.get("kv_rows"), v.get("frames_checked"))
     except Exception as e:
         print(n, "failed:", e)
 PY
