@@ -44,14 +44,14 @@ dist8g)
     VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode $m --frames 48 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_$m.json 2> $OUT/bench_dist8_$m.err; echo "dist8 $m rc=$?"
   done
   timeout 600 python bench.py --frames 48 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --decode-steps 8 > $OUT/bench_dist8_ref1.json 2> $OUT/bench_dist8_ref1.err; echo "dist8 ref rc=$?"
-  # the gather mode's bit-identity with one rank holds when a rank's shard takes the SAME GEMM kernels as the whole video (vidi_gemm picks the 128 x 128
-  # tile kernel below 192 tiles of 256 x 256, i.e. below 14 frames per rank for the N = 1 152 tower GEMMs; another MFMA shape sums in another order):
-  # 112 frames = 14 per rank (no verify leg: eight full K/V copies + their probed twins do not fit one GPU)
-  VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --dist-mode gather_tokens --frames 112 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --no-verify --decode-steps 4 > $OUT/bench_dist8_gather_tokens_112.json 2> $OUT/bench_dist8_gather_tokens_112.err; echo "dist8 gather 112 rc=$?"
-  timeout 600 python bench.py --frames 112 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --no-verify --decode-steps 4 > $OUT/bench_dist8_ref1_112.json 2> $OUT/bench_dist8_ref1_112.err; echo "dist8 ref 112 rc=$?"
+  # the gather mode's bit-identity with one rank holds when every GEMM of a rank's shard takes the SAME kernel as on the whole video: vidi_gemm picks the
+  # 128 x 128 tile kernel below 192 tiles of 256 x 256 (another MFMA shape sums in another order) — below 14 frames per rank for the N = 1 152 tower
+  # GEMMs, below 3 511 token rows per rank for the projector (18 frames at 196 tokens / frame; BASELINE: 450 frames, 11 250 rows per rank).  World 4 x 24 frames:
+  VIDI_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 4 --dist-mode gather_tokens --frames 96 --steps 1 --warmup 1 --no-preproc --no-other-configs --no-kernel-timer --decode-steps 4 > $OUT/bench_dist4_gather_tokens_96.json 2> $OUT/bench_dist4_gather_tokens_96.err; echo "dist4 gather 96 rc=$?"
+  timeout 600 python bench.py --frames 96 --steps 1 --warmup 1 --no-preproc --no-cpu-baseline --no-other-configs --no-kernel-timer --decode-steps 4 > $OUT/bench_dist4_ref1_96.json 2> $OUT/bench_dist4_ref1_96.err; echo "dist4 ref 96 rc=$?"
   python - <<'PY'
 import json
-for n in ("dist8_gather_tokens", "dist8_sharded_stream", "dist8_ref1", "dist8_gather_tokens_112", "dist8_ref1_112"):
+for n in ("dist8_gather_tokens", "dist8_sharded_stream", "dist8_ref1", "dist4_gather_tokens_96", "dist4_ref1_96"):
     try:
         d = json.loads([l for l in open(f"gpurun_out/bench_{n}.json") if l.startswith("{")][-1])
         v = d.get("verify") or {}
