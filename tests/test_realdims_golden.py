@@ -160,3 +160,97 @@ def test_hip_path_vs_reference_execution_at_real_dims(dt):
         report(f"free-running img K layer {li}", k, t(D, f"img_k_{li}"), a_fr * sp(t(D, f"img_k_{li}")), r_fr)
         report(f"free-running img V layer {li}", v, t(D, f"img_v_{li}"), a_fr * sp(t(D, f"img_v_{li}")), r_fr)
     assert not failures, "\n".join(failures)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Vidi-7B at ITS real dims: Mistral 4096 / 32·8 x 128 / 14 336, SiLU-GLU, no softcaps, untied head, the learned Conv2DPool's
+# 14 x 14 x 1152 -> 1152 convolution — tests/golden/make_golden_realdims_7b.py ran the reference's DattnMistralForCausalLM.forward
+# ---------------------------------------------------------------------------------------------------------------------------------
+GOLD7 = os.path.join(HERE, "golden", "reference_realdims_7b.npz")
+
+
+def _setup7():
+    import make_golden_realdims_7b as MR
+    from vidi_amd.weights import init_random_weights
+    D = np.load(GOLD7)
+    assert int(D["weight_seed"][0]) == MR.WEIGHT_SEED and int(D["input_seed"][0]) == MR.INPUT_SEED
+    cfg = MR.realdims_config()
+    px, mel, ids = MR.make_inputs(cfg)
+    assert torch.equal(ids, torch.from_numpy(D["input_ids"]))
+    w = init_random_weights(cfg, seed=MR.WEIGHT_SEED, dtype=torch.float32, device="cpu")
+    return D, cfg, px, mel, ids, w
+
+
+def test_oracle_reproduces_the_reference_at_vidi7b_real_dims():
+    import vidi_oracle as O
+    from util import report
+    D, cfg, px, mel, ids, w = _setup7()
+    names = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    ocfg = O.OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in names}, vis_select_layer=cfg.mm_vision_select_layer, arch="mistral")
+    torch.set_num_threads(8)
+    close = lambda name, got, ref: report(name, got, ref, 1e-3 * float(ref.float().std()), 1.5e-3)      # noqa: E731
+    with torch.no_grad():
+        toks, dbg = O.generate_greedy(ids, list(px), list(mel), D["audio_sizes"].tolist(), w, ocfg, 1, return_debug=True)
+    assert bool(dbg["image_mask"].all()) and bool(dbg["audio_mask"].all())
+    close("7B image embeds (learned pool: 4 tokens per frame)", dbg["image_embeds"][0], t(D, "image_embeds"))
+    close("7B audio embeds", dbg["audio_embeds"][0], t(D, "audio_embeds"))
+    for li in range(cfg.num_hidden_layers):
+        k, v = dbg["caches"].image[li]
+        close(f"7B img K layer {li}", k[0], t(D, f"img_k_{li}"))
+        close(f"7B img V layer {li}", v[0], t(D, f"img_v_{li}"))
+    close("7B last hidden", dbg["prefill_hidden"][0], t(D, "prefill_hidden_last"))
+    ref = t(D, "prefill_logits")
+    report("7B logits of the last position", dbg["prefill_logits"], ref, 2e-4 * float(ref.std()), 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_path_vs_reference_execution_at_vidi7b_real_dims(dt):
+    """Vidi-7B at its real dims against the reference's own execution, no oracle in between: token embeddings through the learned Conv2DPool
+    (the GEMM loader's window gather at k = 14, C = 1152), teacher-forced K / V rows (the reference's embeddings in), free-running last-position
+    logits.  Same bounds as the Vidi1.5 test above."""
+    from util import logit_tol, report as _report
+    from vidi_amd.model import VidiForCausalLM
+    failures = []
+
+    def report(name, got, ref, atol, rtol):
+        try:
+            _report(name, got, ref, atol, rtol)
+        except AssertionError as e:
+            failures.append(str(e))
+    D, cfg, px, mel, ids, w = _setup7()
+    wt = {k: (v if ".mm_rand_pos_" in k else v.to(dt)) for k, v in w.items()}
+    del w
+    model = VidiForCausalLM(cfg, wt, dtype=dt, device="cuda")
+    eng = model.engine
+    nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+    a_act, r_act = (3e-2, 2e-2) if dt == torch.bfloat16 else (6e-3, 4e-3)
+    a_kv, r_kv = (2e-2, 1.2e-2) if dt == torch.bfloat16 else (3e-3, 3e-3)
+    a_fr, r_fr = (5e-2, 3e-2) if dt == torch.bfloat16 else (1e-2, 6e-3)
+    sp = lambda x: float(x.float().std())       # noqa: E731
+    img, au = t(D, "image_embeds").to(dt).cuda(), t(D, "audio_embeds").to(dt).cuda()
+    ones = lambda n: torch.ones(n, dtype=torch.uint8, device="cuda")       # noqa: E731
+    mm = eng.mm_stream_prefill(img, ones(img.shape[0]), au, ones(au.shape[0]), pre_normalized=False)
+    rows = list(range(img.shape[0]))
+    for li in range(cfg.num_hidden_layers):
+        k, v = _cache_rows(mm, li, rows, nkv, hd)
+        a, r = (a_kv, r_kv) if li == 0 else (a_act, r_act)
+        report(f"7B teacher-forced img K layer {li} (4096 -> 8 x 128)", k, t(D, f"img_k_{li}"), a * sp(t(D, f"img_k_{li}")), r)
+        report(f"7B teacher-forced img V layer {li}", v, t(D, f"img_v_{li}"), a * sp(t(D, f"img_v_{li}")), r)
+    del mm
+    out = model.forward(ids, images=px.to(dt).cuda(), audios=mel.to(dt).cuda(), audio_sizes=D["audio_sizes"].tolist(), logits_to_keep=1)
+    ref = t(D, "prefill_logits")
+    lg = logit_tol(dt, ref) if dt == torch.bfloat16 else 1.5e-2 * float(ref.std())
+    report("7B logits of the last position", out.logits[:, -1], ref, lg, 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11)
+    fi, mi, fa, ma = model.encode_videos(px.to(dt).cuda(), mel.to(dt).cuda(), D["audio_sizes"].tolist())
+    assert bool(mi.all()) and bool(ma.all()) and fi.shape[1] == 12 and fa.shape[1] == 100
+    ref = t(D, "image_embeds")
+    report("7B video token embeddings (learned Conv2DPool, 3 x 4 tokens)", fi[0], ref, a_act * 4.0 / 3.0 * sp(ref), r_act)
+    ref = t(D, "audio_embeds")
+    report("7B audio token embeddings", fa[0], ref, a_act * 4.0 / 3.0 * sp(ref), r_act)
+    st = out.past_image_key_values
+    for li in range(cfg.num_hidden_layers):
+        k, v = _cache_rows(st, li, rows, nkv, hd)
+        report(f"7B free-running img K layer {li}", k, t(D, f"img_k_{li}"), a_fr * sp(t(D, f"img_k_{li}")), r_fr)
+        report(f"7B free-running img V layer {li}", v, t(D, f"img_v_{li}"), a_fr * sp(t(D, f"img_v_{li}")), r_fr)
+    assert not failures, "\n".join(failures)
