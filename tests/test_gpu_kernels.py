@@ -705,9 +705,9 @@ def test_attn_cross_running_reference_climbs(hip, dt, softcap):
         k = (ramp * base[None, None, :] * HD ** 0.5 + 0.05 * torch.randn((N, nkv, HD), generator=g)).to(dt)
         v = torch.randn((N, nkv, HD), generator=g).to(dt)
         q = 0.3 * torch.randn((Lq, nq, HD), generator=g)
-        amp = (3.0 if softcap else 40.0) * HD ** 0.5                       # logits ~ +-amp' along the ramp (capped: tanh saturates both ends)
-        q[:16] += amp * base / HD ** 0.5 * (HD ** 0.5)
-        q[16:32] -= amp * base / HD ** 0.5 * (HD ** 0.5)
+        amp = (3.0 if softcap else 40.0) * HD ** 0.5                       # |q . k| scale up to amp along the ramp (capped: tanh saturates both ends)
+        q[:16] += amp * base
+        q[16:32] -= amp * base
         q = q.to(dt)
         mask = torch.ones(N, dtype=torch.bool)
         mask[5::11] = False
